@@ -1,0 +1,489 @@
+// fjgpu_api.hip -- C ABI of libfjgpu.so (include/fjgpu.h): device scene
+// residency, the wavefront batch loop, and the ray-batch trace entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fjgpu.h"
+#include "fjgpu_build.h"
+#include "fjgpu_kernels.h"
+
+namespace {
+
+thread_local std::string t_last_error;
+
+int fail(int code, const std::string &msg)
+{
+  t_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+  return fail(FJGPU_ENODEV, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DeviceBuffers {
+  std::vector<void *> ptrs;
+  ~DeviceBuffers() { for (void *p : ptrs) (void) hipFree(p); }
+  template <class T> int upload(const T *src, size_t n, const T **out)
+  {
+    *out = nullptr;
+    if (n == 0 || src == nullptr) return 0;
+    void *d = nullptr;
+    if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return -1;
+    ptrs.push_back(d);
+    if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    *out = static_cast<const T *>(d);
+    return 0;
+  }
+  template <class T> int alloc(size_t n, T **out)
+  {
+    void *d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return -1;
+    ptrs.push_back(d);
+    *out = static_cast<T *>(d);
+    return 0;
+  }
+};
+
+}  // namespace
+
+struct fjgpu_scene {
+  int device;
+  DScene S;                        // device pointers inside
+  DeviceBuffers mem;               // scene-lifetime allocations
+  double cam_fov;
+  int n_light_samples;
+  // options
+  long batch_tiles;
+  long count_events;
+  long count_all_shadow;
+  // work buffers (lazily sized)
+  std::unique_ptr<DeviceBuffers> work;
+  size_t work_samples, work_rays;
+  double *d_suv;
+  float *d_accum;
+  DRay *d_rays[2];
+  DPath *d_paths[2];
+  DHit *d_hits;
+  DLightRec *d_lrecs;
+  DCounters *d_cnt;
+  TileDesc *d_tiles;
+  double *d_jit, *d_tim;
+  size_t tab_len;
+  int tiles_cap;
+};
+
+extern "C" {
+
+const char *fjgpu_last_error(void) { return t_last_error.c_str(); }
+
+int fjgpu_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fjgpu_tile_count(const fj_render_desc *render)
+{
+  if (!render) return 0;
+  std::vector<fjgpu::TileRect> t;
+  fjgpu::GenerateTiles(*render, &t);
+  return (int) t.size();
+}
+
+int fjgpu_tile_rect(const fj_render_desc *render, int tile_id, int32_t rect[4])
+{
+  if (!render) return FJGPU_EINVAL;
+  std::vector<fjgpu::TileRect> t;
+  fjgpu::GenerateTiles(*render, &t);
+  if (tile_id < 0 || tile_id >= (int) t.size()) return FJGPU_EINVAL;
+  rect[0] = t[tile_id].xmin; rect[1] = t[tile_id].ymin; rect[2] = t[tile_id].xmax; rect[3] = t[tile_id].ymax;
+  return 0;
+}
+
+int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
+{
+  if (!out) return fail(FJGPU_EINVAL, "null output handle");
+  *out = nullptr;
+  fjgpu::HostScene hs;
+  std::string err;
+  const int be = fjgpu::BuildHostScene(desc, &hs, &err);
+  if (be) return fail(be, err);
+  for (int i = 0; i < desc->n_shaders; i++) {
+    const int t = desc->shaders[i].type;
+    if (t == FJ_SHADER_HAIR || t == FJ_SHADER_PATHTRACING)
+      return fail(FJGPU_EUNSUPPORTED, "HairShader / PathtracingShader are not on the device path yet");
+  }
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(FJGPU_ENODEV, "no HIP device visible: the fjgpu core has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(FJGPU_EINVAL, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  std::unique_ptr<fjgpu_scene> sc(new fjgpu_scene());
+  sc->device = device;
+  sc->batch_tiles = 0;
+  sc->count_events = 1;
+  sc->count_all_shadow = 1;
+  sc->work_samples = sc->work_rays = 0;
+  sc->tab_len = 0;
+  sc->tiles_cap = 0;
+  sc->d_jit = sc->d_tim = nullptr;
+  DeviceBuffers &M = sc->mem;
+  int e = 0;
+
+  std::vector<DPrimSet> dps(hs.primsets.size());
+  for (size_t i = 0; i < hs.primsets.size(); i++) {
+    const fjgpu::HostPrimSet &h = hs.primsets[i];
+    DPrimSet &d = dps[i];
+    std::memset(&d, 0, sizeof(d));
+    d.type = h.type;
+    d.root = h.root;
+    d.n_prims = h.n_prims;
+    std::memcpy(d.bounds, h.bounds, sizeof(d.bounds));
+    e |= M.upload(h.nodes.data(), h.nodes.size(), &d.nodes);
+    e |= M.upload(h.prim_ids.data(), h.prim_ids.size(), &d.prim_ids);
+    if (h.type == FJ_PRIMSET_MESH) {
+      const fj_mesh_desc &m = *h.mesh;
+      e |= M.upload(h.tri_verts.data(), h.tri_verts.size(), &d.tri_verts);
+      e |= M.upload(m.P, (size_t) m.n_points * 3, &d.P);
+      e |= M.upload(m.N, m.N ? (size_t) m.n_points * 3 : 0, &d.N);
+      e |= M.upload(m.uv, m.uv ? (size_t) m.n_points * 2 : 0, &d.uv);
+      e |= M.upload(m.indices, (size_t) m.n_faces * 3, &d.indices);
+      e |= M.upload(m.face_group, m.face_group ? (size_t) m.n_faces : 0, &d.face_group);
+    } else {
+      e |= M.upload(h.curve_cp.data(), h.curve_cp.size(), &d.curve_cp);
+      e |= M.upload(h.curve_width.data(), h.curve_width.size(), &d.curve_width);
+      e |= M.upload(h.curve_Cd.data(), h.curve_Cd.size(), &d.curve_Cd);
+      e |= M.upload(h.curve_depth.data(), h.curve_depth.size(), &d.curve_depth);
+    }
+  }
+  std::vector<DTexture> dtex(desc->n_textures);
+  for (int i = 0; i < desc->n_textures; i++) {
+    const fj_texture_desc &t = desc->textures[i];
+    dtex[i].width = t.width; dtex[i].height = t.height; dtex[i].nchannels = t.nchannels; dtex[i].tilesize = t.tilesize;
+    const size_t n = (t.width && t.tiles) ? (size_t) (t.width / t.tilesize) * (t.height / t.tilesize) * t.tilesize * t.tilesize * t.nchannels : 0;
+    e |= M.upload(t.tiles, n, &dtex[i].tiles);
+    if (!dtex[i].tiles) dtex[i].width = dtex[i].height = 0;
+  }
+  DScene &S = sc->S;
+  std::memset(&S, 0, sizeof(S));
+  e |= M.upload(dps.data(), dps.size(), &S.primsets);
+  e |= M.upload(hs.instances.data(), hs.instances.size(), &S.instances);
+  e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
+  e |= M.upload(hs.group_instances.data(), hs.group_instances.size(), &S.group_instances);
+  e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
+  e |= M.upload(dtex.data(), dtex.size(), &S.textures);
+  e |= M.upload(hs.light_samples.data(), hs.light_samples.size(), &S.light_samples);
+  if (e) return fail(FJGPU_ENOMEM, "device allocation / upload failed while creating the scene");
+  S.n_light_samples = (int) hs.light_samples.size();
+  S.n_instances = (int) hs.instances.size();
+  S.n_groups = (int) hs.groups.size();
+  S.n_primsets = (int) hs.primsets.size();
+  S.target_group = hs.target_group;
+  std::memcpy(S.cam_M, hs.cam_M, sizeof(S.cam_M));
+  S.cam_znear = hs.cam_znear;
+  S.cam_zfar = hs.cam_zfar;
+  sc->cam_fov = hs.cam_fov;
+  sc->n_light_samples = S.n_light_samples;
+  HIP_TRY(hipDeviceSynchronize());
+  *out = sc.release();
+  return 0;
+}
+
+void fjgpu_scene_destroy(fjgpu_scene *scene)
+{
+  if (!scene) return;
+  (void) hipSetDevice(scene->device);
+  (void) hipDeviceSynchronize();
+  delete scene;
+}
+
+int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
+{
+  if (!scene || !name) return fail(FJGPU_EINVAL, "bad option call");
+  const std::string n(name);
+  if (n == "batch_tiles") { scene->batch_tiles = value; return 0; }
+  if (n == "count_nodes") { scene->count_events = value != 0; return 0; }
+  if (n == "count_all_shadow") { scene->count_all_shadow = value != 0; return 0; }
+  return fail(FJGPU_EINVAL, "unknown option " + n);
+}
+
+}  // extern "C"
+
+namespace {
+
+struct BatchTile { fjgpu::TileRect r; int nx, ny; uint32_t offset; };
+
+int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t tab_len)
+{
+  if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap) {
+    sc->work.reset(new DeviceBuffers());
+    DeviceBuffers &W = *sc->work;
+    int e = 0;
+    e |= W.alloc(samples * 2, &sc->d_suv);
+    e |= W.alloc(samples * 4, &sc->d_accum);
+    for (int k = 0; k < 2; k++) { e |= W.alloc(rays, &sc->d_rays[k]); e |= W.alloc(rays, &sc->d_paths[k]); }
+    e |= W.alloc(rays, &sc->d_hits);
+    e |= W.alloc(rays, &sc->d_lrecs);
+    e |= W.alloc(1, &sc->d_cnt);
+    e |= W.alloc((size_t) tiles, &sc->d_tiles);
+    if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }
+    sc->work_samples = samples; sc->work_rays = rays; sc->tiles_cap = tiles;
+  }
+  if (tab_len > sc->tab_len) {
+    // the tables live with the scene (small): 3 draws per sample of the largest tile
+    std::vector<double> draws;
+    fjgpu::XorShiftTable(2 * tab_len, &draws);
+    if (sc->mem.upload(draws.data(), 2 * tab_len, const_cast<const double **>(&sc->d_jit))) return -1;
+    if (sc->mem.upload(draws.data(), tab_len, const_cast<const double **>(&sc->d_tim))) return -1;
+    sc->tab_len = tab_len;
+  }
+  return 0;
+}
+
+uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" {
+
+int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *tile_ids, int n_tiles,
+    float *d_fb, void *hip_stream, fjgpu_stats *stats)
+{
+  if (!sc || !r || !d_fb) return fail(FJGPU_EINVAL, "null argument");
+  if (r->sampler_type != 0) return fail(FJGPU_EUNSUPPORTED, "only the fixed grid sampler is on the device path");
+  if (r->xres <= 0 || r->yres <= 0 || r->tile_w <= 0 || r->tile_h <= 0 || r->rate_x <= 0 || r->rate_y <= 0)
+    return fail(FJGPU_EINVAL, "bad render settings");
+  HIP_TRY(hipSetDevice(sc->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+
+  std::vector<fjgpu::TileRect> all;
+  fjgpu::GenerateTiles(*r, &all);
+  std::vector<int> ids;
+  if (tile_ids) ids.assign(tile_ids, tile_ids + n_tiles);
+  else for (size_t i = 0; i < all.size(); i++) ids.push_back((int) i);
+  for (int id : ids) if (id < 0 || id >= (int) all.size()) return fail(FJGPU_EINVAL, "tile id out of range");
+
+  int margin[2];
+  fjgpu::SamplerMargin(*r, margin);
+  const size_t full_tile_samples = (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
+
+  // batch size: about 4 M samples per batch unless told otherwise
+  long bt = sc->batch_tiles;
+  if (bt <= 0) bt = std::max<long>(1, (long) ((4u << 20) / full_tile_samples));
+  bt = std::min<long>(bt, (long) ids.size());
+  if (bt < 1) bt = 1;
+  const size_t cap_samples = full_tile_samples * (size_t) bt;
+  const size_t cap_rays = cap_samples * 2 + 1024;
+  if (ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples))
+    return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
+
+  // camera (Renderer::preprocess_camera + Camera::compute_uv_size)
+  DScene S = sc->S;
+  const double aspect = r->xres / (double) r->yres;
+  S.cam_uv_size[1] = fjgpu::CameraUvSizeY(sc->cam_fov);
+  S.cam_uv_size[0] = S.cam_uv_size[1] * aspect;
+
+  GenParams gp;
+  gp.rate_x = r->rate_x; gp.rate_y = r->rate_y; gp.margin_x = margin[0]; gp.margin_y = margin[1];
+  gp.udelta = 1. / (r->rate_x * r->xres);
+  gp.vdelta = 1. / (r->rate_y * r->yres);
+  gp.jitter = r->jitter;
+  gp.jittered = r->jitter > 0 ? 1 : 0;
+  gp.pad = 0;
+  ShadeParams shp;
+  shp.max_diffuse_depth = r->max_diffuse_depth; shp.max_reflect_depth = r->max_reflect_depth; shp.max_refract_depth = r->max_refract_depth;
+  shp.count_all_shadow = (int) sc->count_all_shadow;
+  shp.ray_capacity = (uint32_t) cap_rays; shp.light_capacity = (uint32_t) cap_rays;
+  ShadowParams swp;
+  swp.cos_half_pi = std::cos(3.14159265358979323846 / 2.);
+  swp.cos_pi = std::cos(3.14159265358979323846);
+  swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, sc->n_light_samples)));
+  swp.cast_shadow = r->cast_shadow;
+  ResolveParams rp;
+  rp.xres = r->xres; rp.yres = r->yres; rp.rate_x = r->rate_x; rp.rate_y = r->rate_y;
+  rp.npx_x = r->rate_x + 2 * margin[0]; rp.npx_y = r->rate_y + 2 * margin[1];
+  rp.fw = (double) r->filter_w; rp.fh = (double) r->filter_h;
+
+  hipEvent_t ev[2];
+  HIP_TRY(hipEventCreate(&ev[0]));
+  HIP_TRY(hipEventCreate(&ev[1]));
+  fjgpu_stats acc;
+  std::memset(&acc, 0, sizeof(acc));
+  float ms = 0;
+  auto timed = [&](double *bucket, auto &&launch) -> int {
+    (void) hipEventRecord(ev[0], st);
+    const int le = launch();
+    (void) hipEventRecord(ev[1], st);
+    if (le) return le;
+    if (hipEventSynchronize(ev[1]) != hipSuccess) return -1;
+    (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
+    *bucket += ms;
+    return 0;
+  };
+  int rc = 0;
+  hipEvent_t ev_all[2];
+  HIP_TRY(hipEventCreate(&ev_all[0]));
+  HIP_TRY(hipEventCreate(&ev_all[1]));
+  (void) hipEventRecord(ev_all[0], st);
+
+  for (size_t b0 = 0; b0 < ids.size() && rc == 0; b0 += (size_t) bt) {
+    const int nb = (int) std::min<size_t>((size_t) bt, ids.size() - b0);
+    std::vector<TileDesc> td(nb);
+    uint32_t off = 0, max_ts = 0;
+    int max_px = 0;
+    for (int k = 0; k < nb; k++) {
+      const fjgpu::TileRect &t = all[ids[b0 + k]];
+      TileDesc &d = td[k];
+      d.xmin = t.xmin; d.ymin = t.ymin; d.xmax = t.xmax; d.ymax = t.ymax; d.id = t.id;
+      d.nx = r->rate_x * (t.xmax - t.xmin) + 2 * margin[0];
+      d.ny = r->rate_y * (t.ymax - t.ymin) + 2 * margin[1];
+      d.sample_offset = off;
+      off += (uint32_t) d.nx * (uint32_t) d.ny;
+      max_ts = std::max(max_ts, (uint32_t) d.nx * (uint32_t) d.ny);
+      max_px = std::max(max_px, (t.xmax - t.xmin) * (t.ymax - t.ymin));
+    }
+    const uint32_t n_samples = off;
+    if ((hipMemcpyAsync(sc->d_tiles, td.data(), sizeof(TileDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = -1; break; }
+    (void) hipMemsetAsync(sc->d_accum, 0, sizeof(float) * 4 * (size_t) n_samples, st);
+    (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
+
+    rc = timed(&acc.gen_ms, [&]() {
+      return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->d_rays[0], sc->d_paths[0]);
+    });
+    if (rc) break;
+    acc.rays.camera += n_samples;
+
+    uint32_t count = n_samples;
+    int cur = 0;
+    for (int level = 0; count > 0 && rc == 0 && level < 64; level++) {
+      rc = timed(&acc.trace_ms, [&]() {
+        return launch_trace_closest(st, S, sc->d_rays[cur], sc->d_paths[cur], sc->d_hits, count, sc->d_cnt, (int) sc->count_events);
+      });
+      if (rc) break;
+      acc.trace_launches++;
+      rc = timed(&acc.shade_ms, [&]() {
+        return launch_shade(st, S, shp, sc->d_rays[cur], sc->d_paths[cur], sc->d_hits, count, sc->d_accum,
+            sc->d_rays[1 - cur], sc->d_paths[1 - cur], sc->d_lrecs, sc->d_cnt);
+      });
+      if (rc) break;
+      DCounters hc;
+      if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
+      if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); break; }
+      if (hc.light_count) {
+        rc = timed(&acc.trace_ms, [&]() {
+          return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_cnt, (int) sc->count_events);
+        });
+        if (rc) break;
+        acc.trace_launches++;
+      }
+      count = hc.next_count;
+      // reset the queue heads for the next level
+      (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);
+      cur = 1 - cur;
+    }
+    if (rc) break;
+
+    rc = timed(&acc.resolve_ms, [&]() {
+      return launch_resolve(st, rp, sc->d_tiles, nb, max_px, sc->d_suv, sc->d_accum, d_fb);
+    });
+    if (rc) break;
+    DCounters hc;
+    if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
+    acc.rays.shadow += hc.rays[CXT_SHADOW_RAY];
+    acc.rays.diffuse += hc.rays[CXT_DIFFUSE_RAY];
+    acc.rays.reflect += hc.rays[CXT_REFLECT_RAY];
+    acc.rays.refract += hc.rays[CXT_REFRACT_RAY];
+    acc.nodes_visited += hc.nodes;
+    acc.prims_tested += hc.prims;
+    acc.insts_tested += hc.insts;
+    acc.rays_traced += hc.traced;
+    acc.batches++;
+  }
+  (void) hipEventRecord(ev_all[1], st);
+  const hipError_t se = hipStreamSynchronize(st);
+  if (rc == 0 && se == hipSuccess) {
+    (void) hipEventElapsedTime(&ms, ev_all[0], ev_all[1]);
+    acc.total_ms = ms;
+  }
+  (void) hipEventDestroy(ev[0]); (void) hipEventDestroy(ev[1]);
+  (void) hipEventDestroy(ev_all[0]); (void) hipEventDestroy(ev_all[1]);
+  if (rc > 0 || rc == -1) return fail(FJGPU_ENODEV, std::string("HIP failure in the wavefront loop: ") + hipGetErrorString(hipGetLastError()));
+  if (rc) return rc;
+  if (se != hipSuccess) return fail(FJGPU_ENODEV, std::string("stream synchronize: ") + hipGetErrorString(se));
+  if (stats) *stats = acc;
+  return 0;
+}
+
+int fjgpu_render_frame(fjgpu_scene *sc, const fj_render_desc *r, float *h_fb, fjgpu_stats *stats)
+{
+  if (!sc || !r || !h_fb) return fail(FJGPU_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(sc->device));
+  const size_t n = (size_t) r->xres * r->yres * 4;
+  float *d_fb = nullptr;
+  HIP_TRY(hipMalloc(&d_fb, n * sizeof(float)));
+  (void) hipMemset(d_fb, 0, n * sizeof(float));
+  const int rc = fjgpu_render_tiles(sc, r, nullptr, 0, d_fb, nullptr, stats);
+  hipError_t ce = hipSuccess;
+  if (rc == 0) ce = hipMemcpy(h_fb, d_fb, n * sizeof(float), hipMemcpyDeviceToHost);
+  (void) hipFree(d_fb);
+  if (rc) return rc;
+  if (ce != hipSuccess) return fail(FJGPU_ENODEV, std::string("framebuffer copy: ") + hipGetErrorString(ce));
+  return 0;
+}
+
+int fjgpu_trace(fjgpu_scene *sc, int group, int n, const double *rays, double *out_t, int32_t *out_ids,
+    double *out_uv, fjgpu_stats *stats)
+{
+  if (!sc || !rays || !out_t || !out_ids || n < 0) return fail(FJGPU_EINVAL, "null argument");
+  if (group < 0 || group >= sc->S.n_groups) return fail(FJGPU_EINVAL, "group out of range");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(sc->device));
+  DeviceBuffers W;
+  DRay *d_rays; DHit *d_hits; DCounters *d_cnt;
+  if (W.alloc((size_t) n, &d_rays) || W.alloc((size_t) n, &d_hits) || W.alloc(1, &d_cnt))
+    return fail(FJGPU_ENOMEM, "device allocation failed");
+  HIP_TRY(hipMemcpy(d_rays, rays, sizeof(DRay) * (size_t) n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_cnt, 0, sizeof(DCounters)));
+  DScene S = sc->S;
+  S.target_group = group;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  (void) hipEventRecord(e0, nullptr);
+  const int le = launch_trace_closest(nullptr, S, d_rays, nullptr, d_hits, (uint32_t) n, d_cnt, (int) sc->count_events);
+  (void) hipEventRecord(e1, nullptr);
+  if (le) return fail(FJGPU_ENODEV, std::string("trace launch: ") + hipGetErrorString((hipError_t) le));
+  HIP_TRY(hipDeviceSynchronize());
+  float ms = 0;
+  (void) hipEventElapsedTime(&ms, e0, e1);
+  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+  std::vector<DHit> h((size_t) n);
+  HIP_TRY(hipMemcpy(h.data(), d_hits, sizeof(DHit) * (size_t) n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    out_t[i] = h[i].inst >= 0 ? h[i].t : DBL_MAX;
+    out_ids[2 * i] = h[i].inst;
+    out_ids[2 * i + 1] = h[i].inst >= 0 ? h[i].prim : -1;
+    if (out_uv) { out_uv[2 * i] = h[i].inst >= 0 ? h[i].u : 0; out_uv[2 * i + 1] = h[i].inst >= 0 ? h[i].v : 0; }
+  }
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    DCounters hc;
+    HIP_TRY(hipMemcpy(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost));
+    stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->insts_tested = hc.insts; stats->rays_traced = hc.traced;
+    stats->trace_ms = ms; stats->total_ms = ms; stats->trace_launches = 1;
+  }
+  return 0;
+}
+
+}  // extern "C"

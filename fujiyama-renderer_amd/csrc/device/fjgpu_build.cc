@@ -1,0 +1,351 @@
+// fjgpu_build.cc -- host-side build of the device scene.
+//
+// Replaces the reference's build_accelerators() (src/fj_scene_interface.cc:1161-1202):
+// instead of a uniform grid per mesh (src/fj_grid_accelerator.cc:69-160) the GPU
+// core uses a binned-SAH BVH2 per primitive set ("BLAS") whose leaves hold up to
+// four pre-gathered f64 triangles, laid out for coalesced 64-byte node fetches.
+// Closest-hit results do not depend on the culling structure; the
+// triangle test itself is the reference's FP64 Moller-Trumbore.
+//
+// The instance level (BVHAccelerator over ObjectInstances, src/fj_object_group.cc:27)
+// has at most a few dozen entries and is kept as a flat per-group list with
+// world-space AABBs.
+#include "fjgpu_build.h"
+#include "fjgpu.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace fjgpu {
+
+namespace {
+
+const double ACC_PADDING = .0001;     // Accelerator PADDING, src/fj_accelerator.cc:13
+
+struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
+
+// f64 -> f32 rounded toward -inf / +inf, then one extra ulp outward
+inline float down2(double v)
+{
+  float f = (float) v;
+  if ((double) f > v) f = std::nextafterf(f, -INFINITY);
+  return std::nextafterf(f, -INFINITY);
+}
+inline float up2(double v)
+{
+  float f = (float) v;
+  if ((double) f < v) f = std::nextafterf(f, INFINITY);
+  return std::nextafterf(f, INFINITY);
+}
+
+struct Builder {
+  std::vector<PrimRef> prims;
+  std::vector<DNode> nodes;
+  std::atomic<uint32_t> next_node;
+  std::atomic<int> max_depth;
+  int max_leaf;
+
+  static void grow(float *mn, float *mx, const float *a, const float *b)
+  {
+    for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], a[k]); mx[k] = std::max(mx[k], b[k]); }
+  }
+  static float half_area(const float *mn, const float *mx)
+  {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+
+  uint32_t leaf_ref(int begin, int count) const { return FJ_LEAF_FLAG | ((uint32_t) begin << 3) | (uint32_t) (count - 1); }
+
+  // returns child ref for range [begin,end); writes its bounds into mn/mx
+  uint32_t build(int begin, int end, int depth, int par_depth, float *mn, float *mx)
+  {
+    const int n = end - begin;
+    for (int k = 0; k < 3; k++) { mn[k] = FLT_MAX; mx[k] = -FLT_MAX; }
+    float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = begin; i < end; i++) {
+      grow(mn, mx, prims[i].bmin, prims[i].bmax);
+      grow(cmn, cmx, prims[i].c, prims[i].c);
+    }
+    int d = max_depth.load();
+    while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+    if (n <= max_leaf) {
+      // leaves of <= 4 prims are always accepted at or below max_leaf
+      if (n <= 2 || depth >= FJ_BVH_MAX_DEPTH - 2) return leaf_ref(begin, n);
+    }
+
+    // binned SAH on the axis with the widest centroid extent
+    int axis = 0;
+    float ext = cmx[0] - cmn[0];
+    for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > ext) { ext = cmx[k] - cmn[k]; axis = k; }
+    int mid = -1;
+    // remaining depth budget: subtrees deeper than this are split at the object median
+    const int budget = FJ_BVH_MAX_DEPTH - 2 - depth;
+    const double cap = std::ldexp((double) max_leaf, std::max(0, budget - 1));
+    const bool force_median = (double) n > cap * 0.5 && budget < 30;
+    if (ext > 0 && !force_median) {
+      const int NB = 16;
+      int cnt[NB];
+      float bmn[NB][3], bmx[NB][3];
+      for (int b = 0; b < NB; b++) { cnt[b] = 0; for (int k = 0; k < 3; k++) { bmn[b][k] = FLT_MAX; bmx[b][k] = -FLT_MAX; } }
+      const float scale = NB * (1.f - 1e-6f) / ext;
+      for (int i = begin; i < end; i++) {
+        int b = (int) ((prims[i].c[axis] - cmn[axis]) * scale);
+        b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+        cnt[b]++;
+        grow(bmn[b], bmx[b], prims[i].bmin, prims[i].bmax);
+      }
+      float rarea[NB];
+      int rcnt[NB];
+      float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      int c = 0;
+      for (int b = NB - 1; b > 0; b--) {
+        if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
+        c += cnt[b];
+        rcnt[b] = c;
+        rarea[b] = c ? half_area(amn, amx) : 0.f;
+      }
+      for (int k = 0; k < 3; k++) { amn[k] = FLT_MAX; amx[k] = -FLT_MAX; }
+      c = 0;
+      float best = FLT_MAX;
+      int best_b = -1;
+      for (int b = 0; b < NB - 1; b++) {
+        if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
+        c += cnt[b];
+        if (c == 0 || rcnt[b + 1] == 0) continue;
+        const float cost = half_area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
+        if (cost < best) { best = cost; best_b = b; }
+      }
+      if (best_b >= 0) {
+        // leaf cost vs split cost (traversal cost 1 node ~ 1.2 triangle tests)
+        const float parent_area = half_area(mn, mx);
+        if (n <= max_leaf && best + 1.2f * parent_area >= parent_area * n) return leaf_ref(begin, n);
+        const float split = cmn[axis] + (best_b + 1) / scale;
+        PrimRef *m = std::partition(&prims[begin], &prims[begin] + n, [&](const PrimRef &p) {
+          int b = (int) ((p.c[axis] - cmn[axis]) * scale);
+          b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+          return b <= best_b;
+        });
+        (void) split;
+        mid = (int) (m - &prims[0]);
+      }
+    }
+    if (mid <= begin || mid >= end) {
+      if (n <= max_leaf) return leaf_ref(begin, n);
+      mid = begin + n / 2;
+      std::nth_element(&prims[begin], &prims[mid], &prims[begin] + n,
+          [axis](const PrimRef &a, const PrimRef &b) { return a.c[axis] < b.c[axis]; });
+    }
+
+    const uint32_t me = next_node.fetch_add(1);
+    float lmn[3], lmx[3], rmn[3], rmx[3];
+    uint32_t lc, rc;
+    if (par_depth > 0 && n > 20000) {
+      std::thread th([&]() { lc = build(begin, mid, depth + 1, par_depth - 1, lmn, lmx); });
+      rc = build(mid, end, depth + 1, par_depth - 1, rmn, rmx);
+      th.join();
+    } else {
+      lc = build(begin, mid, depth + 1, 0, lmn, lmx);
+      rc = build(mid, end, depth + 1, 0, rmn, rmx);
+    }
+    DNode &nd = nodes[me];
+    for (int k = 0; k < 3; k++) { nd.lmin[k] = lmn[k]; nd.lmax[k] = lmx[k]; nd.rmin[k] = rmn[k]; nd.rmax[k] = rmx[k]; }
+    nd.lc = lc; nd.rc = rc; nd.pad[0] = nd.pad[1] = 0;
+    return me;
+  }
+};
+
+void build_blas(HostPrimSet *ps, std::vector<PrimRef> &refs)
+{
+  Builder b;
+  b.prims.swap(refs);
+  const int n = (int) b.prims.size();
+  b.nodes.resize(n > 1 ? n : 1);
+  b.next_node = 0;
+  b.max_depth = 0;
+  b.max_leaf = FJ_MAX_LEAF_PRIMS;
+  float mn[3], mx[3];
+  if (n == 0) {
+    ps->root = FJ_LEAF_FLAG;   // never dereferenced: n_prims == 0 is checked first
+  } else {
+    ps->root = b.build(0, n, 0, 4, mn, mx);
+  }
+  b.nodes.resize(b.next_node.load() ? b.next_node.load() : 1);
+  ps->nodes.swap(b.nodes);
+  ps->max_depth = b.max_depth;
+  ps->prim_ids.resize(n);
+  for (int i = 0; i < n; i++) ps->prim_ids[i] = b.prims[i].id;
+  ps->n_prims = n;
+}
+
+int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
+{
+  ps->type = FJ_PRIMSET_MESH;
+  ps->mesh = &m;
+  ps->curve = nullptr;
+  if (m.velocity) { *err = "mesh velocity (motion blur) is not on the device path yet"; return FJGPU_EUNSUPPORTED; }
+  if (m.n_faces > (1 << 28)) { *err = "mesh too large"; return FJGPU_EINVAL; }
+  for (int k = 0; k < 3; k++) { ps->bounds[k] = m.bounds[k] - ACC_PADDING; ps->bounds[3 + k] = m.bounds[3 + k] + ACC_PADDING; }
+  std::vector<PrimRef> refs(m.n_faces);
+  for (int f = 0; f < m.n_faces; f++) {
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int k = 0; k < 3; k++) {
+      const int p = m.indices[3 * f + k];
+      if (p < 0 || p >= m.n_points) { *err = "mesh index out of range"; return FJGPU_EINVAL; }
+      for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], m.P[3 * p + c]); mx[c] = std::max(mx[c], m.P[3 * p + c]); }
+    }
+    PrimRef &r = refs[f];
+    for (int c = 0; c < 3; c++) { r.bmin[c] = down2(mn[c]); r.bmax[c] = up2(mx[c]); r.c[c] = (float) (.5 * (mn[c] + mx[c])); }
+    r.id = (uint32_t) f;
+  }
+  build_blas(ps, refs);
+  ps->tri_verts.resize((size_t) ps->n_prims * 9);
+  for (int i = 0; i < ps->n_prims; i++) {
+    const int f = (int) ps->prim_ids[i];
+    for (int k = 0; k < 3; k++) {
+      const int p = m.indices[3 * f + k];
+      for (int c = 0; c < 3; c++) ps->tri_verts[(size_t) i * 9 + 3 * k + c] = m.P[3 * p + c];
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err);   // fjgpu_curve_build.cc
+
+int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
+{
+  if (!d) { *err = "null scene description"; return FJGPU_EINVAL; }
+  out->n_meshes = d->n_meshes;
+  out->primsets.resize(d->n_meshes + d->n_curves);
+  for (int i = 0; i < d->n_meshes; i++) {
+    const int e = build_mesh(d->meshes[i], &out->primsets[i], err);
+    if (e) return e;
+  }
+  for (int i = 0; i < d->n_curves; i++) {
+    const int e = BuildCurveSet(d->curves[i], &out->primsets[d->n_meshes + i], err);
+    if (e) return e;
+  }
+
+  out->instances.resize(d->n_instances);
+  for (int i = 0; i < d->n_instances; i++) {
+    const fj_instance_desc &s = d->instances[i];
+    DInstance &o = out->instances[i];
+    std::memset(&o, 0, sizeof(o));
+    const fj_xform_desc &x = s.xform;
+    if (x.n_translate != 1 || x.n_rotate != 1 || x.n_scale != 1) {
+      *err = "time-sampled object transforms (motion blur) are not on the device path yet";
+      return FJGPU_EUNSUPPORTED;
+    }
+    double M[16], Minv[16];
+    MakeTransform(x, 0, M, Minv);
+    std::memcpy(o.M, M, sizeof(o.M));
+    std::memcpy(o.Minv, Minv, sizeof(o.Minv));
+    if (s.primset_type == FJ_PRIMSET_MESH) {
+      if (s.primset < 0 || s.primset >= d->n_meshes) { *err = "instance mesh index out of range"; return FJGPU_EINVAL; }
+      o.primset = s.primset;
+    } else if (s.primset_type == FJ_PRIMSET_CURVE) {
+      if (s.primset < 0 || s.primset >= d->n_curves) { *err = "instance curve index out of range"; return FJGPU_EINVAL; }
+      o.primset = d->n_meshes + s.primset;
+    } else { *err = "unknown primitive set type"; return FJGPU_EINVAL; }
+    TransformBounds(M, out->primsets[o.primset].bounds, o.wbounds);
+    // widen the culling box by a relative epsilon: it must contain every point
+    // M * (o' + t d') the object-space test can report
+    for (int k = 0; k < 3; k++) {
+      const double pad = 1e-9 * (std::fabs(o.wbounds[k]) + std::fabs(o.wbounds[3 + k]) + 1);
+      o.wbounds[k] -= pad; o.wbounds[3 + k] += pad;
+    }
+    o.n_shaders = s.n_shaders;
+    for (int k = 0; k < FJ_MAX_SHADING_GROUPS; k++) {
+      o.shaders[k] = s.shaders[k];
+      if (o.shaders[k] >= d->n_shaders) { *err = "shader index out of range"; return FJGPU_EINVAL; }
+    }
+    const int tg[3] = {s.reflect_target, s.refract_target, s.shadow_target};
+    for (int t : tg) if (t < 0 || t >= d->n_groups) { *err = "trace target group out of range"; return FJGPU_EINVAL; }
+    o.reflect_target = tg[0]; o.refract_target = tg[1]; o.shadow_target = tg[2];
+  }
+
+  out->shaders.assign(d->shaders, d->shaders + d->n_shaders);
+  for (const fj_shader_desc &s : out->shaders) {
+    const int tx[3] = {s.diffuse_map, s.bump_map, s.texture};
+    for (int t : tx) if (t >= d->n_textures) { *err = "texture index out of range"; return FJGPU_EINVAL; }
+  }
+
+  out->groups.resize(d->n_groups);
+  out->group_instances.clear();
+  for (int g = 0; g < d->n_groups; g++) {
+    DGroup &G = out->groups[g];
+    G.first = (int) out->group_instances.size();
+    G.count = d->groups[g].n_instances;
+    G.all_opaque = 1;
+    G.pad = 0;
+    for (int k = 0; k < G.count; k++) {
+      const int inst = d->groups[g].instances[k];
+      if (inst < 0 || inst >= d->n_instances) { *err = "group instance index out of range"; return FJGPU_EINVAL; }
+      out->group_instances.push_back(inst);
+      // occluder opacity: only PlasticShader has a settable Os (plastic_shader.cc:177-178)
+      const DInstance &I = out->instances[inst];
+      for (int s = 0; s < I.n_shaders && s < FJ_MAX_SHADING_GROUPS; s++) {
+        const int sid = I.shaders[s];
+        if (sid >= 0 && d->shaders[sid].type == FJ_SHADER_PLASTIC && d->shaders[sid].opacity < 1.f) G.all_opaque = 0;
+      }
+    }
+  }
+  if (d->target_group < 0 || d->target_group >= d->n_groups) { *err = "renderer target group out of range"; return FJGPU_EINVAL; }
+  out->target_group = d->target_group;
+
+  // SlNewLightSamples for the deterministic lights (src/fj_shading.cc:380-404):
+  // PointLight::get_samples (src/fj_point_light.cc:21-34), DomeLight::get_samples
+  // (src/fj_dome_light.cc:30-51); transforms are evaluated at time 0.
+  out->light_samples.clear();
+  for (int i = 0; i < d->n_lights; i++) {
+    const fj_light_desc &L = d->lights[i];
+    double M[16], Minv[16];
+    MakeTransform(L.xform, 0, M, Minv);
+    if (L.type == FJ_POINT_LIGHT) {
+      DLightSample s;
+      // Transform.translate of the lerped sample (channel value itself)
+      s.P[0] = L.xform.translate[0].v[0]; s.P[1] = L.xform.translate[0].v[1]; s.P[2] = L.xform.translate[0].v[2];
+      if (L.xform.n_translate > 1 && !(L.xform.translate[0].time >= 0)) {
+        *err = "time-sampled light transforms are not on the device path yet";
+        return FJGPU_EUNSUPPORTED;
+      }
+      for (int k = 0; k < 3; k++) s.Cl[k] = L.intensity * L.color[k];   // PointLight::illuminate
+      s.light = i;
+      out->light_samples.push_back(s);
+    } else if (L.type == FJ_DOME_LIGHT) {
+      const int n = std::min(L.sample_count, L.n_dome_samples);
+      const float si = L.intensity / L.sample_count;                   // Light::sample_intensity_
+      for (int k = 0; k < n; k++) {
+        const fj_dome_sample &ds = L.dome_samples[k];
+        const double p[3] = {ds.dir[0] * FLT_MAX, ds.dir[1] * FLT_MAX, ds.dir[2] * FLT_MAX};
+        DLightSample s;
+        for (int r = 0; r < 3; r++) s.P[r] = M[4 * r] * p[0] + M[4 * r + 1] * p[1] + M[4 * r + 2] * p[2] + M[4 * r + 3];
+        for (int c = 0; c < 3; c++) s.Cl[c] = si * ds.color[c];
+        s.light = i;
+        out->light_samples.push_back(s);
+      }
+    } else {
+      *err = "GridLight / SphereLight draw from a shared racy RNG in the reference and are not on the device path";
+      return FJGPU_EUNSUPPORTED;
+    }
+  }
+
+  const fj_xform_desc &cx = d->camera.xform;
+  if (cx.n_translate != 1 || cx.n_rotate != 1 || cx.n_scale != 1) {
+    *err = "time-sampled camera transforms (motion blur) are not on the device path yet";
+    return FJGPU_EUNSUPPORTED;
+  }
+  double M[16], Minv[16];
+  MakeTransform(cx, 0, M, Minv);
+  std::memcpy(out->cam_M, M, sizeof(out->cam_M));
+  out->cam_fov = d->camera.fov; out->cam_znear = d->camera.znear; out->cam_zfar = d->camera.zfar;
+  return 0;
+}
+
+}  // namespace fjgpu

@@ -1,0 +1,59 @@
+// fjgpu_build.h -- host-side preparation of the device scene (runs once per
+// scene, outside the timed region, like the reference's build_accelerators()).
+#ifndef FJGPU_BUILD_H
+#define FJGPU_BUILD_H
+
+#include "fjgpu_types.h"
+
+#include <string>
+#include <vector>
+
+namespace fjgpu {
+
+struct HostPrimSet {
+  int type;
+  std::vector<DNode> nodes;
+  std::vector<double> tri_verts;      // mesh: [n][9]
+  std::vector<uint32_t> prim_ids;
+  std::vector<double> curve_cp;       // curves: [n][12]
+  std::vector<double> curve_width;    // [n][2]
+  std::vector<float> curve_Cd;        // [n][6]
+  std::vector<int8_t> curve_depth;    // [n]
+  uint32_t root;
+  double bounds[6];
+  int n_prims;
+  int max_depth;
+  const fj_mesh_desc *mesh;
+  const fj_curve_desc *curve;
+};
+
+struct HostScene {
+  std::vector<HostPrimSet> primsets;          // meshes first, then curve sets
+  std::vector<DInstance> instances;
+  std::vector<DGroup> groups;
+  std::vector<int32_t> group_instances;
+  std::vector<fj_shader_desc> shaders;
+  std::vector<DLightSample> light_samples;
+  int n_meshes;
+  int target_group;
+  double cam_M[12];
+  double cam_fov, cam_znear, cam_zfar;
+};
+
+// returns 0 or a negative FJGPU_E* code with *err set
+int BuildHostScene(const fj_scene_desc *desc, HostScene *out, std::string *err);
+
+// reference-exact host math used while flattening (fjgpu_xform.cc)
+void MakeTransform(const fj_xform_desc &x, double time, double M[16], double Minv[16]);
+void TransformBounds(const double M[16], const double in[6], double out[6]);
+
+// frame tiling / sampling tables (fjgpu_tables.cc)
+struct TileRect { int id, xmin, ymin, xmax, ymax; };
+void GenerateTiles(const fj_render_desc &r, std::vector<TileRect> *tiles);
+void SamplerMargin(const fj_render_desc &r, int margin[2]);
+// first n draws of the default-seeded XorShift as f64 in [0,1]
+void XorShiftTable(size_t n, std::vector<double> *out);
+double CameraUvSizeY(double fov);
+
+}  // namespace fjgpu
+#endif

@@ -1,0 +1,49 @@
+// fjgpu_kernels.h -- launch parameters and host launchers of fjgpu_kernels.hip
+#ifndef FJGPU_KERNELS_H
+#define FJGPU_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "fjgpu_types.h"
+
+struct TileDesc {              // one tile of the current batch
+  int32_t xmin, ymin, xmax, ymax;
+  int32_t nx, ny;              // samples incl. filter margin: rate * size + 2 * margin
+  uint32_t sample_offset;      // first sample slot of this tile in the batch arrays
+  int32_t id;
+};
+
+struct GenParams {
+  int32_t rate_x, rate_y, margin_x, margin_y;
+  double udelta, vdelta, jitter;
+  int32_t jittered, pad;
+};
+
+struct ShadeParams {
+  int32_t max_diffuse_depth, max_reflect_depth, max_refract_depth;
+  int32_t count_all_shadow;    // 1: trace zero-weight light records too (reference ray counts)
+  uint32_t ray_capacity, light_capacity;
+};
+
+struct ShadowParams {
+  double cos_half_pi, cos_pi;  // cos(PI/2.), cos(PI) evaluated by the host libm
+  uint32_t lanes;              // lanes per light record: power of two <= 64
+  int32_t cast_shadow;
+};
+
+struct ResolveParams {
+  int32_t xres, yres, rate_x, rate_y, npx_x, npx_y;
+  double fw, fh;
+};
+
+int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, const TileDesc *d_tiles, int n_tiles,
+    uint32_t max_tile_samples, const double *jit, const double *tim, double *s_uv, DRay *rays, DPath *paths);
+int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, const DPath *paths, DHit *hits,
+    uint32_t n, DCounters *cnt, int count_events);
+int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const DRay *rays, const DPath *paths,
+    const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt);
+int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
+    float *s_accum, DCounters *cnt, int count_events);
+int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
+    const double *s_uv, const float *s_accum, float *fb);
+
+#endif

@@ -1,0 +1,764 @@
+// fjgpu_kernels.hip -- hand-written HIP kernels of the MI355X (gfx950, wave64)
+// ray-intersection + integrator core.  Compiled with -ffp-contract=off: every
+// FP64 expression that decides a hit or feeds geometry keeps the reference's
+// operation order (citations per function); culling arithmetic (slab tests on
+// widened boxes) is free to differ because it can only reject provable misses.
+//
+// Kernel map:
+//   k_gen_camera     FixedGridSampler::generate_samples + Camera::GetRay
+//   k_trace_closest  Accelerator::Intersect over a group: instance loop ->
+//                    BLAS (BVH2, LDS traversal stack) -> FP64 Moller-Trumbore
+//   k_shade          trace_surface's attribute setup + the shader plugins;
+//                    emits light records and child rays (ballot compaction)
+//   k_shadow         SlIlluminance: (record, light) pairs, shadow rays,
+//                    wave-segment reduction, accumulation into the sample
+//   k_resolve        reconstruct_image / apply_pixel_filter
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "fjgpu_types.h"
+#include "fjgpu_kernels.h"
+
+#define BLOCK 256
+
+// ------------------------------------------------------------------ vectors
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// Normalize, reference src/fj_vector.h:339-345: a * (1./len), len == 0 -> a
+__device__ __forceinline__ V3 normalize(V3 a)
+{
+  const double len = sqrt(dot(a, a));
+  if (len == 0) return a;
+  const double inv = 1. / len;
+  return a * inv;
+}
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+// MatTransformPoint / MatTransformVector, reference src/fj_matrix.cc:208-222
+__device__ __forceinline__ V3 xpoint(const double *m, V3 p)
+{
+  return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
+            m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+__device__ __forceinline__ V3 xvector(const double *m, V3 v)
+{
+  return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z,
+            m[4] * v.x + m[5] * v.y + m[6] * v.z,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+// ------------------------------------------------------------ culling tests
+// Conservative slab test (culling only).  NaN from 0 * inf is ignored by
+// fmin/fmax, which return the non-NaN operand.
+__device__ __forceinline__ bool slab(const double bmin[3], const double bmax[3], V3 o, V3 inv,
+    double tmin, double tmax, double *tnear)
+{
+  const double x0 = (bmin[0] - o.x) * inv.x, x1 = (bmax[0] - o.x) * inv.x;
+  const double y0 = (bmin[1] - o.y) * inv.y, y1 = (bmax[1] - o.y) * inv.y;
+  const double z0 = (bmin[2] - o.z) * inv.z, z1 = (bmax[2] - o.z) * inv.z;
+  const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), tmin));
+  const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tmax));
+  *tnear = tn;
+  return tn <= tf;
+}
+
+__device__ __forceinline__ bool slab_f32box(const float *bmin, const float *bmax, V3 o, V3 inv,
+    double tmin, double tmax, double *tnear)
+{
+  const double mn[3] = {(double) bmin[0], (double) bmin[1], (double) bmin[2]};
+  const double mx[3] = {(double) bmax[0], (double) bmax[1], (double) bmax[2]};
+  return slab(mn, mx, o, inv, tmin, tmax, tnear);
+}
+
+// ------------------------------------------------------- triangle test (a21)
+// TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
+// EPSILON 1e-6 (:12); no t-sign test here -- the range test is the caller's
+// (PrimitiveSet::RayIntersect, src/fj_primitive_set.cc:10-26).
+__device__ __forceinline__ bool tri_ray(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
+{
+  const V3 edge1 = v1 - v0;
+  const V3 edge2 = v2 - v0;
+  const V3 pvec = cross(dir, edge2);
+  const double det = dot(edge1, pvec);
+  if (det > -1e-6 && det < 1e-6) return false;
+  const double inv_det = 1.0 / det;
+  const V3 tvec = orig - v0;
+  const double uu = dot(tvec, pvec) * inv_det;
+  if (uu < 0.0 || uu > 1.0) return false;
+  const V3 qvec = cross(tvec, edge1);
+  const double vv = dot(dir, qvec) * inv_det;
+  if (vv < 0.0 || uu + vv > 1.0) return false;
+  *t = dot(edge2, qvec) * inv_det;
+  *u = uu;
+  *v = vv;
+  return true;
+}
+
+// ----------------------------------------------------------------- traversal
+struct Best { double t, u, v; int inst, prim; };
+
+struct LocalCounters { uint32_t nodes, prims, insts; };
+
+// Closest (ANYHIT == false) or first (ANYHIT == true) hit of one ray against
+// one group.  `stack` points at this lane's column of the LDS stack
+// (entries are BLOCK apart: lane-consecutive addresses, conflict free).
+// Semantics reproduced: a hit counts iff tmin <= t <= tmax with
+// the ORIGINAL ray range (RayInRange, src/fj_ray.h:29-32); the closest one wins
+// with strict '<' (src/fj_bvh_accelerator.cc:183, src/fj_grid_accelerator.cc:263);
+// at exactly equal t inside one mesh the larger primitive id wins (the grid's
+// LIFO cell lists test it first).
+template <bool ANYHIT>
+__device__ bool trace_group(const DScene &S, int group, V3 o, V3 d, double tmin, double tmax,
+    uint32_t *stack, Best *best, LocalCounters *lc)
+{
+  const DGroup G = S.groups[group];
+  best->t = DBL_MAX;
+  best->inst = -1;
+  best->prim = -1;
+  best->u = best->v = 0;
+  const V3 winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+
+  for (int gi = 0; gi < G.count; gi++) {
+    const int ii = S.group_instances[G.first + gi];
+    const DInstance *I = &S.instances[ii];
+    lc->insts++;
+    double tn;
+    const double tfar = ANYHIT ? tmax : fmin(tmax, best->t);
+    if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
+
+    // ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: ray to
+    // object space with M^-1; dir is NOT renormalised so t is preserved
+    const V3 oo = xpoint(I->Minv, o);
+    const V3 od = xvector(I->Minv, d);
+    const V3 inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+    const DPrimSet *P = &S.primsets[I->primset];
+    if (P->n_prims == 0) continue;
+    if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+
+    int sp = 0;
+    uint32_t cur = P->root;
+    for (;;) {
+      if (cur & FJ_LEAF_FLAG) {
+        const uint32_t first = (cur & 0x7fffffffu) >> 3;
+        const uint32_t cnt = (cur & 7u) + 1;
+        for (uint32_t k = 0; k < cnt; k++) {
+          const double *vp = P->tri_verts + (size_t) (first + k) * 9;
+          double t, u, v;
+          lc->prims++;
+          if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+          if (!(tmin <= t && t <= tmax)) continue;
+          const int pid = (int) P->prim_ids[first + k];
+          if (t < best->t || (t == best->t && best->inst == ii && pid > best->prim)) {
+            best->t = t; best->u = u; best->v = v; best->inst = ii; best->prim = pid;
+            if (ANYHIT) return true;
+          }
+        }
+        if (sp == 0) break;
+        cur = stack[(--sp) * BLOCK];
+        continue;
+      }
+      const DNode *nd = &P->nodes[cur];
+      lc->nodes++;
+      // 64-byte node: four 16-byte loads
+      const float4 a = reinterpret_cast<const float4 *>(nd)[0];
+      const float4 b = reinterpret_cast<const float4 *>(nd)[1];
+      const float4 c = reinterpret_cast<const float4 *>(nd)[2];
+      const uint4 e = reinterpret_cast<const uint4 *>(nd)[3];
+      const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+      const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+      const double tf2 = ANYHIT ? tmax : fmin(tmax, best->t);
+      double tl, tr;
+      const bool hl = slab_f32box(lmin, lmax, oo, inv, tmin, tf2, &tl);
+      const bool hr = slab_f32box(rmin, rmax, oo, inv, tmin, tf2, &tr);
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        stack[(sp++) * BLOCK] = left_first ? e.y : e.x;
+        cur = left_first ? e.x : e.y;
+      } else if (hl) cur = e.x;
+      else if (hr) cur = e.y;
+      else {
+        if (sp == 0) break;
+        cur = stack[(--sp) * BLOCK];
+      }
+    }
+  }
+  return best->inst >= 0;
+}
+
+// ------------------------------------------------------------------ k_trace
+__global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+    DHit *hits, uint32_t n, DCounters *cnt, int count_events)
+{
+  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const DRay r = rays[i];
+  const int group = paths ? paths[i].group : S.target_group;
+  Best b;
+  LocalCounters lc = {0, 0, 0};
+  trace_group<false>(S, group, mk(r.o[0], r.o[1], r.o[2]), mk(r.d[0], r.d[1], r.d[2]), r.tmin, r.tmax,
+      s_stack + threadIdx.x, &b, &lc);
+  DHit h;
+  h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
+  hits[i] = h;
+  if (count_events) {
+    atomicAdd(&cnt->nodes, (unsigned long long) lc.nodes);
+    atomicAdd(&cnt->prims, (unsigned long long) lc.prims);
+    atomicAdd(&cnt->insts, (unsigned long long) lc.insts);
+    atomicAdd(&cnt->traced, 1ull);
+  }
+}
+
+// --------------------------------------------------------------- k_gen_camera
+// FixedGridSampler::generate_samples (src/fj_fixed_grid_sampler.cc:33-84) with the
+// per-tile XorShift streams read from host-built tables (the stream restarts
+// for every tile, so draw k is the same number in every tile), then
+// Camera::GetRay (src/fj_camera.cc:79-110) with the host-built camera matrix.
+__global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, const TileDesc *tiles,
+    const double *jitter_tab, const double *time_tab, double *s_uv, DRay *rays, DPath *paths)
+{
+  const TileDesc T = tiles[blockIdx.y];
+  const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t ns = (uint32_t) T.nx * (uint32_t) T.ny;
+  if (k >= ns) return;
+  const int x = (int) (k % (uint32_t) T.nx), y = (int) (k / (uint32_t) T.nx);
+  const int xoffset = T.xmin * gp.rate_x - gp.margin_x;
+  const int yoffset = T.ymin * gp.rate_y - gp.margin_y;
+
+  double u = (.5 + x + xoffset) * gp.udelta;
+  double v = 1 - (.5 + y + yoffset) * gp.vdelta;
+  if (gp.jittered) {
+    const double u_jitter = jitter_tab[2 * (size_t) k] * gp.jitter;
+    const double v_jitter = jitter_tab[2 * (size_t) k + 1] * gp.jitter;
+    u += gp.udelta * (u_jitter - .5);
+    v += gp.vdelta * (v_jitter - .5);
+  }
+  const uint32_t slot = T.sample_offset + k;
+  s_uv[2 * (size_t) slot] = u;
+  s_uv[2 * (size_t) slot + 1] = v;
+  (void) time_tab;   // static camera / geometry: the per-sample time does not enter the path
+
+  const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
+  const V3 tw = xpoint(S.cam_M, target);
+  const V3 eye = mk(S.cam_M[3], S.cam_M[7], S.cam_M[11]);
+  const V3 dir = normalize(tw - eye);
+
+  DRay r;
+  r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
+  r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
+  r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
+  rays[slot] = r;
+  DPath p;
+  p.sample = slot;
+  p.T[0] = p.T[1] = p.T[2] = 1.f;
+  p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
+  p.group = S.target_group;
+  p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
+  p.flags = 0; p.rng = 0; p.pad = 0;
+  paths[slot] = p;
+}
+
+// -------------------------------------------------------------------- shading
+__device__ __forceinline__ double clampd(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
+
+// Texture::Lookup, src/fj_texture.cc:51-78 + MipInput::ReadTile clamp (src/fj_mipmap.cc:153-170)
+__device__ void tex_lookup(const DTexture &tex, float u, float v, float out[4])
+{
+  if (tex.width == 0 || tex.tiles == nullptr) { out[0] = 1.f; out[1] = .63f; out[2] = .63f; out[3] = 1.f; return; }
+  const int ts = tex.tilesize;
+  const int xnt = tex.width / ts, ynt = tex.height / ts;
+  const float tu = u - floorf(u);
+  const float tv = v - floorf(v);
+  const float su = tu * xnt;
+  const float sv = (1 - tv) * ynt;
+  int xt = (int) floorf(su), yt = (int) floorf(sv);
+  xt = xt < 0 ? 0 : (xt > xnt - 1 ? xnt - 1 : xt);
+  yt = yt < 0 ? 0 : (yt > ynt - 1 ? ynt - 1 : yt);
+  const int xp = (int) ((su - floorf(su)) * 64);
+  const int yp = (int) ((sv - floorf(sv)) * 64);
+  if (xp < 0 || xp >= ts || yp < 0 || yp >= ts) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
+  const float *p = tex.tiles + ((size_t) (yt * xnt + xt) * ts * ts + (size_t) (yp * ts + xp)) * tex.nchannels;
+  switch (tex.nchannels) {
+  case 1: out[0] = out[1] = out[2] = p[0]; out[3] = 1.f; break;
+  case 3: out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = 1.f; break;
+  case 4: out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3]; break;
+  default: out[0] = out[1] = out[2] = out[3] = 0.f; break;
+  }
+}
+
+__device__ __forceinline__ V3 faceforward(V3 I, V3 N) { return (dot(I, N) < 0) ? N : mk(-N.x, -N.y, -N.z); }   // src/fj_shading.cc:42-51
+
+__device__ double fresnel(V3 I, V3 N, double ior)   // SlFresnel, src/fj_shading.cc:53-73
+{
+  double c = -1 * dot(I, N);
+  double eta;
+  if (c > 0) eta = ior;
+  else { eta = 1. / ior; c *= -1; }
+  const double k2 = .0;
+  const double F0 = ((1. - eta) * (1. - eta) + k2) / ((1. + eta) * (1. + eta) + k2);
+  return F0 + (1. - F0) * pow(1. - c, 5.);
+}
+
+__device__ __forceinline__ V3 reflect(V3 I, V3 N)   // SlReflect, :90-98
+{
+  const double c = -1 * dot(I, N);
+  return mk(I.x + 2 * c * N.x, I.y + 2 * c * N.y, I.z + 2 * c * N.z);
+}
+
+__device__ V3 refract(V3 I, V3 N, double ior)        // SlRefract, :100-138
+{
+  V3 n;
+  double eta;
+  double c1 = -1 * dot(I, N);
+  if (c1 < 0) { c1 *= -1; eta = 1 / ior; n = mk(-N.x, -N.y, -N.z); }
+  else { eta = ior; n = N; }
+  const double radicand = 1 - eta * eta * (1 - c1 * c1);
+  if (radicand < 0.) return reflect(I, N);
+  const double nc = eta * c1 - sqrt(radicand);
+  return mk(eta * I.x + nc * n.x, eta * I.y + nc * n.y, eta * I.z + nc * n.z);
+}
+
+__device__ __forceinline__ float luminance4(const float c[4]) { return (float) (.298912 * c[0] + .586611 * c[1] + .114478 * c[2]); }
+
+// SlBumpMapping, src/fj_shading.cc:418-464
+__device__ V3 bump_mapping(const DTexture &bump, V3 dPdu, V3 dPdv, float tu, float tv, double amplitude, V3 N)
+{
+  if (bump.width == 0 || bump.height == 0) return N;
+  const float du = (float) (1. / bump.width);
+  const float dv = (float) (1. / bump.height);
+  float c0[4], c1[4];
+  tex_lookup(bump, tu - du, tv, c0);
+  tex_lookup(bump, tu + du, tv, c1);
+  const float Bu = (luminance4(c0) - luminance4(c1)) / (2 * du);
+  tex_lookup(bump, tu, tv - dv, c0);
+  tex_lookup(bump, tu, tv + dv, c1);
+  const float Bv = (luminance4(c0) - luminance4(c1)) / (2 * dv);
+  V3 a = cross(N, dPdu), b = cross(N, dPdv);
+  a = mk(a.x * du, a.y * du, a.z * du);
+  b = mk(b.x * du, b.y * du, b.z * du);
+  const V3 nb = mk(N.x + amplitude * (Bv * a.x - Bu * b.x),
+                   N.y + amplitude * (Bv * a.y - Bu * b.y),
+                   N.z + amplitude * (Bv * a.z - Bu * b.z));
+  return normalize(nb);
+}
+
+// wave-aggregated append: one atomic per wave, slots by ballot prefix count
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter)
+{
+  const unsigned long long mask = __ballot(want);
+  if (!want) return 0xffffffffu;
+  const unsigned lane = __lane_id();
+  const unsigned leader = (unsigned) __ffsll((long long) mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
+  base = __shfl(base, leader);
+  return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+struct ChildRay {
+  bool want;
+  V3 o, d;
+  double tmin, tmax;
+  float T[3];
+  uint8_t cxt, dd, rd, td;
+  int group;
+  float fc[3];
+  uint32_t flags;
+};
+
+__device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t sample, uint32_t rng,
+    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity)
+{
+  const uint32_t slot = wave_append(c.want, &cnt->next_count);
+  if (!c.want) return;
+  if (slot >= capacity) { cnt->overflow = 1; return; }
+  DRay r;
+  r.o[0] = c.o.x; r.o[1] = c.o.y; r.o[2] = c.o.z;
+  r.d[0] = c.d.x; r.d[1] = c.d.y; r.d[2] = c.d.z;
+  r.tmin = c.tmin; r.tmax = c.tmax;
+  next_rays[slot] = r;
+  DPath p;
+  p.sample = sample;
+  p.T[0] = c.T[0]; p.T[1] = c.T[1]; p.T[2] = c.T[2];
+  p.cxt = c.cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
+  p.group = c.group;
+  p.fc[0] = c.fc[0]; p.fc[1] = c.fc[1]; p.fc[2] = c.fc[2];
+  p.flags = c.flags; p.rng = rng; p.pad = 0;
+  next_paths[slot] = p;
+  atomicAdd(&cnt->rays[c.cxt], 1ull);
+}
+
+// trace_surface's SurfaceInput setup + Shader::Evaluate for the device shaders.
+// Radiance is accumulated as throughput-weighted terms: every shader term of
+// the reference is linear in the radiance returned by its child SlTrace calls,
+// so `Cs = local + sum_k w_k * C_child_k` unrolls into per-path products
+// (DESIGN.md 6).
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,
+    const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths,
+    DLightRec *lrecs, DCounters *cnt)
+{
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = i < n;
+  DHit h;
+  h.inst = -1;
+  if (active) h = hits[i];
+  const bool hit = active && h.inst >= 0;
+
+  ChildRay c0, c1;   // up to two children (glass); plastic uses c0
+  c0.want = c1.want = false;
+  bool want_light = false;
+  DLightRec lr;
+  uint32_t sample = 0, rng = 0;
+
+  if (hit) {
+    const DRay r = rays[i];
+    DPath p = paths[i];
+    sample = p.sample;
+    rng = p.rng;
+    const DInstance *I = &S.instances[h.inst];
+    const DPrimSet *P = &S.primsets[I->primset];
+    const V3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = mk(r.d[0], r.d[1], r.d[2]);
+
+    // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
+    const V3 oo = xpoint(I->Minv, ro);
+    const V3 od = xvector(I->Minv, rd);
+    const int32_t *ix = P->indices + 3 * (size_t) h.prim;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
+    if (P->N) { n0 = ld3(P->N + 3 * (size_t) i0); n1 = ld3(P->N + 3 * (size_t) i1); n2 = ld3(P->N + 3 * (size_t) i2); }
+    V3 N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;          // TriComputeNormal, src/fj_triangle.cc:44-49
+    float tu = 0.f, tv = 0.f;
+    V3 dPdu = mk(0, 0, 0), dPdv = mk(0, 0, 0);
+    const bool has_uv = P->uv != nullptr;
+    float t0u = 0, t0v = 0, t1u = 0, t1v = 0, t2u = 0, t2v = 0;
+    if (has_uv) {
+      t0u = P->uv[2 * (size_t) i0]; t0v = P->uv[2 * (size_t) i0 + 1];
+      t1u = P->uv[2 * (size_t) i1]; t1v = P->uv[2 * (size_t) i1 + 1];
+      t2u = P->uv[2 * (size_t) i2]; t2v = P->uv[2 * (size_t) i2 + 1];
+      const float tt = (float) (1 - h.u - h.v);                  // f32 barycentric, src/fj_mesh.cc:285
+      tu = (float) (tt * t0u + h.u * t1u + h.v * t2u);
+      tv = (float) (tt * t0v + h.u * t1v + h.v * t2v);
+    }
+    V3 Pw = oo + h.t * od;                                        // RayPointAt in object space
+    // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)
+    Pw = xpoint(I->M, Pw);
+    N = normalize(xvector(I->M, N));
+
+    // --- shader lookup: ObjectInstance::GetShader (src/fj_object_instance.cc:177-191)
+    const int sg = P->face_group ? P->face_group[h.prim] : 0;
+    int sid;
+    if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
+    else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
+
+    // pending pow(filter, t_hit) of a refraction child (glass_shader.cc:117-121)
+    if (p.flags & 1u) {
+      p.T[0] = (float) (p.T[0] * pow((double) p.fc[0], h.t));
+      p.T[1] = (float) (p.T[1] * pow((double) p.fc[1], h.t));
+      p.T[2] = (float) (p.T[2] * pow((double) p.fc[2], h.t));
+    }
+
+    float Cs[3] = {.5f, 1.f, 0.f};   // NO_SHADER_COLOR, src/fj_shading.cc:24
+    float Os = 1.f;
+    bool add_cs = true;
+    const V3 Iw = rd;
+    if (sid >= 0) {
+      const fj_shader_desc *sh = &S.shaders[sid];
+      switch (sh->type) {
+      case FJ_SHADER_CONSTANT: {   // constant_shader.cc:72-96
+        if (sh->texture >= 0) {
+          float ct[4];
+          tex_lookup(S.textures[sh->texture], tu, tv, ct);
+          Cs[0] = ct[0] * sh->diffuse[0]; Cs[1] = ct[1] * sh->diffuse[1]; Cs[2] = ct[2] * sh->diffuse[2];
+        } else { Cs[0] = sh->diffuse[0]; Cs[1] = sh->diffuse[1]; Cs[2] = sh->diffuse[2]; }
+        Os = 1.f;
+        break;
+      }
+      case FJ_SHADER_PLASTIC: {    // plastic_shader.cc:101-179
+        V3 Nf = faceforward(Iw, N);
+        if (sh->bump_map >= 0) {
+          if (has_uv) {
+            // TriComputeDerivatives (src/fj_triangle.cc:51-74) on the object-space
+            // vertices, then the instance's M as a vector transform
+            const V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            const V3 dP1 = p1 - p0, dP2 = p2 - p0;
+            const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;
+            const float determinant = du1 * dv2 - dv1 * du2;
+            if (determinant != 0) {
+              const float invdet = (float) (1. / determinant);
+              dPdu = ((double) dv2 * dP1 - (double) dv1 * dP2) * (double) invdet;
+              dPdv = ((double) (-du2) * dP1 + (double) du1 * dP2) * (double) invdet;
+            }
+            dPdu = xvector(I->M, dPdu);
+            dPdv = xvector(I->M, dPdv);
+          }
+          Nf = bump_mapping(S.textures[sh->bump_map], dPdu, dPdv, tu, tv, (double) sh->bump_amplitude, Nf);
+        }
+        add_cs = false;
+        if (S.n_light_samples > 0) {
+          float dm[4] = {1.f, 1.f, 1.f, 1.f};
+          if (sh->diffuse_map >= 0) tex_lookup(S.textures[sh->diffuse_map], tu, tv, dm);
+          want_light = true;
+          lr.P[0] = Pw.x; lr.P[1] = Pw.y; lr.P[2] = Pw.z;
+          lr.N[0] = Nf.x; lr.N[1] = Nf.y; lr.N[2] = Nf.z;
+          lr.W[0] = p.T[0] * (sh->diffuse[0] * dm[0]);
+          lr.W[1] = p.T[1] * (sh->diffuse[1] * dm[1]);
+          lr.W[2] = p.T[2] * (sh->diffuse[2] * dm[2]);
+          lr.Cd[0] = lr.Cd[1] = lr.Cd[2] = 0.f;
+          for (int k = 0; k < 6; k++) lr.aux[k] = 0;
+          lr.sample = sample;
+          lr.group = I->shadow_target;
+          lr.kind = 0;
+          lr.cxt = p.cxt;
+          if (lr.W[0] == 0.f && lr.W[1] == 0.f && lr.W[2] == 0.f && !sp.count_all_shadow) want_light = false;
+        }
+        if (sh->do_reflect && (int) p.rdepth + 1 <= sp.max_reflect_depth) {
+          const V3 R = normalize(reflect(Iw, Nf));
+          const double Kr = fresnel(Iw, Nf, (double) (1.f / sh->ior));
+          c0.want = true;
+          c0.o = Pw; c0.d = R; c0.tmin = .001; c0.tmax = 1000;
+          c0.T[0] = (float) (Kr * sh->reflect[0]) * p.T[0];
+          c0.T[1] = (float) (Kr * sh->reflect[1]) * p.T[1];
+          c0.T[2] = (float) (Kr * sh->reflect[2]) * p.T[2];
+          c0.cxt = CXT_REFLECT_RAY; c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
+          c0.group = I->reflect_target;
+          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+        }
+        Os = sh->opacity;
+        break;
+      }
+      case FJ_SHADER_GLASS: {      // glass_shader.cc:88-130 (N is not face-forwarded)
+        add_cs = false;
+        const double Kr = fresnel(Iw, N, (double) (1.f / sh->ior));
+        const double Kt = 1 - Kr;
+        if ((int) p.rdepth + 1 <= sp.max_reflect_depth) {
+          c0.want = true;
+          c0.o = Pw; c0.d = normalize(reflect(Iw, N)); c0.tmin = .0001; c0.tmax = 1000;
+          c0.T[0] = (float) Kr * p.T[0]; c0.T[1] = (float) Kr * p.T[1]; c0.T[2] = (float) Kr * p.T[2];
+          c0.cxt = CXT_REFLECT_RAY; c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
+          c0.group = I->reflect_target;
+          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+        }
+        if ((int) p.tdepth + 1 <= sp.max_refract_depth) {
+          c1.want = true;
+          c1.o = Pw; c1.d = normalize(refract(Iw, N, (double) (1.f / sh->ior))); c1.tmin = .0001; c1.tmax = 1000;
+          c1.T[0] = (float) Kt * p.T[0]; c1.T[1] = (float) Kt * p.T[1]; c1.T[2] = (float) Kt * p.T[2];
+          c1.cxt = CXT_REFRACT_RAY; c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
+          c1.group = I->refract_target;
+          const bool filt = sh->do_color_filter && dot(Iw, N) < 0;
+          c1.fc[0] = sh->filter_color[0]; c1.fc[1] = sh->filter_color[1]; c1.fc[2] = sh->filter_color[2];
+          c1.flags = filt ? 1u : 0u;
+        }
+        Os = 1.f;
+        break;
+      }
+      default:
+        // hair / pathtracing need curve primitives / per-path RNG: rejected at scene creation
+        add_cs = false;
+        break;
+      }
+    }
+    Os = (float) clampd(Os, 0, 1);
+    float *acc = s_accum + 4 * (size_t) sample;
+    if (add_cs) {
+      const float r0 = p.T[0] * Cs[0], r1 = p.T[1] * Cs[1], r2 = p.T[2] * Cs[2];
+      if (r0 != 0.f) atomicAdd(acc + 0, r0);
+      if (r1 != 0.f) atomicAdd(acc + 1, r1);
+      if (r2 != 0.f) atomicAdd(acc + 2, r2);
+    }
+    if (p.cxt == CXT_CAMERA_RAY) acc[3] = Os;   // one camera ray per sample
+  }
+
+  // ---- compaction: ballot + prefix count, one atomic per wave and queue
+  const uint32_t lslot = wave_append(want_light, &cnt->light_count);
+  if (want_light) {
+    if (lslot < sp.light_capacity) lrecs[lslot] = lr;
+    else cnt->overflow = 1;
+  }
+  emit_child(c0, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c1, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
+}
+
+// ------------------------------------------------------------------- k_shadow
+// SlIlluminance (src/fj_shading.cc:296-359) for every (light record, light
+// sample) pair.  `lanes` consecutive lanes (a power of two <= 64) serve one
+// record and stride over the light samples; the per-record sum is formed with
+// a butterfly reduction inside the lane segment, and one lane adds
+// W * sum_i Kd_i * Cl_i * (1 - alpha_i) to the sample.
+__global__ void __launch_bounds__(BLOCK) k_shadow(DScene S, ShadowParams sp, const DLightRec *lrecs, uint32_t n,
+    float *s_accum, DCounters *cnt, int count_events)
+{
+  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
+  const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t rec = gtid / sp.lanes;
+  const uint32_t sub = gtid % sp.lanes;
+  const bool active = rec < n;
+
+  float sum[3] = {0.f, 0.f, 0.f};
+  uint32_t nshadow = 0;
+  LocalCounters lc = {0, 0, 0};
+  DLightRec R;
+  if (active) {
+    R = lrecs[rec];
+    const V3 Ps = mk(R.P[0], R.P[1], R.P[2]);
+    const V3 axis = mk(R.N[0], R.N[1], R.N[2]);
+    const V3 nml_axis = normalize(axis);
+    const double cos_limit = R.kind == 0 ? sp.cos_half_pi : sp.cos_pi;
+    const bool anyhit = S.groups[R.group].all_opaque != 0;
+    for (uint32_t l = sub; l < (uint32_t) S.n_light_samples; l += sp.lanes) {
+      const DLightSample LS = S.light_samples[l];
+      V3 Ln = mk(LS.P[0] - Ps.x, LS.P[1] - Ps.y, LS.P[2] - Ps.z);
+      const double distance = sqrt(dot(Ln, Ln));
+      if (distance > 0) {
+        const double inv = 1. / distance;
+        Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
+      }
+      const double cosangle = dot(nml_axis, Ln);
+      if (cosangle < cos_limit) continue;
+      float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
+      if (Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001) continue;
+      if (sp.cast_shadow) {
+        nshadow++;
+        Best b;
+        bool hit;
+        if (anyhit) hit = trace_group<true>(S, R.group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
+        else hit = trace_group<false>(S, R.group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
+        if (hit) {
+          // the occluder's shader runs in shadow context and only its Os is used
+          // (src/fj_shading.cc:338-355,548-569): opacity for plastic, 1 otherwise
+          float Os = 1.f;
+          const DInstance *I = &S.instances[b.inst];
+          const DPrimSet *P = &S.primsets[I->primset];
+          const int sg = (P->face_group && b.prim >= 0) ? P->face_group[b.prim] : 0;
+          int sid;
+          if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
+          else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
+          if (sid >= 0 && S.shaders[sid].type == FJ_SHADER_PLASTIC) Os = S.shaders[sid].opacity;
+          Os = (float) clampd(Os, 0, 1);
+          const float ac = 1 - Os;
+          Cl[0] *= ac; Cl[1] *= ac; Cl[2] *= ac;
+        }
+      }
+      if (R.kind == 0) {             // plastic_shader.cc:131-137
+        float Kd = (float) dot(axis, Ln);
+        Kd = (float) (Kd > 0 ? (double) Kd : 0.);
+        sum[0] += Kd * Cl[0]; sum[1] += Kd * Cl[1]; sum[2] += Kd * Cl[2];
+      }
+    }
+  }
+  // butterfly reduction inside the lane segment (all 64 lanes participate)
+  for (uint32_t off = sp.lanes >> 1; off > 0; off >>= 1) {
+    sum[0] += __shfl_xor(sum[0], (int) off);
+    sum[1] += __shfl_xor(sum[1], (int) off);
+    sum[2] += __shfl_xor(sum[2], (int) off);
+  }
+  if (active && sub == 0) {
+    float *acc = s_accum + 4 * (size_t) R.sample;
+    const float r0 = R.W[0] * sum[0], r1 = R.W[1] * sum[1], r2 = R.W[2] * sum[2];
+    if (r0 != 0.f) atomicAdd(acc + 0, r0);
+    if (r1 != 0.f) atomicAdd(acc + 1, r1);
+    if (r2 != 0.f) atomicAdd(acc + 2, r2);
+  }
+  if (nshadow) atomicAdd(&cnt->rays[CXT_SHADOW_RAY], (unsigned long long) nshadow);
+  if (count_events && (lc.nodes | lc.prims | lc.insts | nshadow)) {
+    atomicAdd(&cnt->nodes, (unsigned long long) lc.nodes);
+    atomicAdd(&cnt->prims, (unsigned long long) lc.prims);
+    atomicAdd(&cnt->insts, (unsigned long long) lc.insts);
+    atomicAdd(&cnt->traced, (unsigned long long) nshadow);
+  }
+}
+
+// ------------------------------------------------------------------ k_resolve
+// reconstruct_image + apply_pixel_filter (src/fj_renderer.cc:939-995) with
+// eval_gaussian (src/fj_filter.cc:49-58): f32 accumulators += f64 products, in
+// the reference's window order (y-major).
+__global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileDesc *tiles,
+    const double *s_uv, const float *s_accum, float *fb)
+{
+  const TileDesc T = tiles[blockIdx.y];
+  const int tw = T.xmax - T.xmin, th = T.ymax - T.ymin;
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= tw * th) return;
+  const int px = T.xmin + k % tw, py = T.ymin + k / tw;
+  const size_t base = (size_t) T.sample_offset + (size_t) (py - T.ymin) * rp.rate_y * T.nx + (size_t) (px - T.xmin) * rp.rate_x;
+  float pix[4] = {0.f, 0.f, 0.f, 0.f};
+  float wgt_sum = 0.f;
+  for (int sy = 0; sy < rp.npx_y; sy++)
+    for (int sx = 0; sx < rp.npx_x; sx++) {
+      const size_t s = base + (size_t) sy * T.nx + sx;
+      const double u = s_uv[2 * s], v = s_uv[2 * s + 1];
+      const float4 d = reinterpret_cast<const float4 *>(s_accum)[s];
+      const double filtx = rp.xres * u - (px + .5);
+      const double filty = rp.yres * (1 - v) - (py + .5);
+      const double xx = 2 * filtx / rp.fw;
+      const double yy = 2 * filty / rp.fh;
+      const double wgt = exp(-2 * (xx * xx + yy * yy));
+      pix[0] = (float) (pix[0] + wgt * (double) d.x);
+      pix[1] = (float) (pix[1] + wgt * (double) d.y);
+      pix[2] = (float) (pix[2] + wgt * (double) d.z);
+      pix[3] = (float) (pix[3] + wgt * (double) d.w);
+      wgt_sum = (float) (wgt_sum + wgt);
+    }
+  const float inv_sum = 1.f / wgt_sum;
+  float4 out;
+  out.x = pix[0] * inv_sum; out.y = pix[1] * inv_sum; out.z = pix[2] * inv_sum; out.w = pix[3] * inv_sum;
+  reinterpret_cast<float4 *>(fb)[(size_t) py * rp.xres + px] = out;
+}
+
+// ----------------------------------------------------------- host launchers
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
+
+int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, const TileDesc *d_tiles, int n_tiles,
+    uint32_t max_tile_samples, const double *jit, const double *tim, double *s_uv, DRay *rays, DPath *paths)
+{
+  dim3 grid((max_tile_samples + BLOCK - 1) / BLOCK, n_tiles);
+  hipLaunchKernelGGL(k_gen_camera, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, const DPath *paths, DHit *hits,
+    uint32_t n, DCounters *cnt, int count_events)
+{
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_trace_closest, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const DRay *rays, const DPath *paths,
+    const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt)
+{
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_shade, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
+      s_accum, next_rays, next_paths, lrecs, cnt);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
+    float *s_accum, DCounters *cnt, int count_events)
+{
+  if (n == 0) return 0;
+  const unsigned long long threads = (unsigned long long) n * sp.lanes;
+  hipLaunchKernelGGL(k_shadow, dim3((unsigned) ((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, n,
+      s_accum, cnt, count_events);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
+    const double *s_uv, const float *s_accum, float *fb)
+{
+  dim3 grid((max_tile_pixels + BLOCK - 1) / BLOCK, n_tiles);
+  hipLaunchKernelGGL(k_resolve, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, s_accum, fb);
+  LAUNCH_CHECK();
+  return 0;
+}

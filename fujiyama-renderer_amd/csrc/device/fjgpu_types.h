@@ -1,0 +1,141 @@
+// fjgpu_types.h -- device-resident data layout of the MI355X core.
+// Shared by the host-side scene builder (fjgpu_build.cc) and the HIP kernels.
+#ifndef FJGPU_TYPES_H
+#define FJGPU_TYPES_H
+
+#include <stdint.h>
+#include "fj_scene_desc.h"
+
+// ---- BLAS node: 64 B = one cache-line-half, two child AABBs + two child refs.
+// Boxes are f32, rounded OUTWARD from the f64 primitive bounds and widened by
+// one more ulp, so the f64 slab test on them can never cull a primitive whose
+// f64 Moller-Trumbore test would report a hit.
+// child ref: bit 31 set -> leaf, payload = (first_prim << 3) | (count - 1);
+//            else index of the child DNode.
+struct DNode {
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  uint32_t lc, rc;
+  uint32_t pad[2];
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
+#define FJ_LEAF_FLAG 0x80000000u
+#define FJ_MAX_LEAF_PRIMS 4
+#define FJ_BVH_MAX_DEPTH 40          // traversal stack entries per lane
+
+// ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
+struct DPrimSet {
+  const DNode *nodes;
+  const double *tri_verts;     // [n_prims][9]  pre-gathered v0 v1 v2 in BLAS leaf order (72 B / tri)
+  const uint32_t *prim_ids;    // [n_prims]     original primitive id of leaf slot k
+  const double *P;             // [n_points][3] object-space positions (attribute fetch)
+  const double *N;             // [n_points][3] or null
+  const float *uv;             // [n_points][2] or null
+  const int32_t *indices;      // [n_faces][3]
+  const int32_t *face_group;   // [n_faces] or null
+  // curves
+  const double *curve_cp;      // [n_curves][12] pre-gathered control points (BLAS order)
+  const double *curve_width;   // [n_curves][2]  end widths (BLAS order)
+  const float *curve_Cd;       // [n_curves][6]  end colours (BLAS order)
+  const int8_t *curve_depth;   // [n_curves]     cached split depth (BLAS order)
+  double bounds[6];            // Accelerator::bounds_ = primset bounds + 1e-4 (object space)
+  uint32_t root;               // child ref of the root
+  int32_t type;                // FJ_PRIMSET_*
+  int32_t n_prims;
+  int32_t pad;
+};
+
+// ---- object instance: matrices precomputed on the host with the reference's
+// arithmetic (static transforms; time-sampled TRS is a "next" row)
+struct DInstance {
+  double M[12];                // rows 0..2 of the 4x4 (row 3 is 0 0 0 1)
+  double Minv[12];
+  double wbounds[6];           // world AABB (merge_sampled_bounds)
+  int32_t primset;             // index into DPrimSet table
+  int32_t n_shaders;
+  int32_t shaders[FJ_MAX_SHADING_GROUPS];
+  int32_t reflect_target, refract_target, shadow_target;
+  int32_t pad[3];
+};
+
+struct DGroup {
+  int32_t first, count;        // slice of the group-instance index array
+  int32_t all_opaque;          // every shader reachable in the group has Os == 1 -> any-hit shadows
+  int32_t pad;
+};
+
+struct DTexture {
+  const float *tiles;
+  int32_t width, height, nchannels, tilesize;
+};
+
+struct DLightSample {
+  double P[3];
+  float Cl[3];                 // Light::Illuminate result (position independent for point / dome)
+  int32_t light;
+};
+
+struct DScene {
+  const DPrimSet *primsets;
+  const DInstance *instances;
+  const DGroup *groups;
+  const int32_t *group_instances;
+  const fj_shader_desc *shaders;
+  const DTexture *textures;
+  const DLightSample *light_samples;
+  int32_t n_light_samples;
+  int32_t n_instances, n_groups, n_primsets;
+  int32_t target_group;
+  // camera (static): eye, matrix rows, uv_size
+  double cam_M[12];
+  double cam_uv_size[2];
+  double cam_znear, cam_zfar;
+};
+
+// ---- wavefront records
+struct DRay {                  // 64 B, Ray of src/fj_ray.h:11-22
+  double o[3], d[3], tmin, tmax;
+};
+
+enum { CXT_CAMERA_RAY = 0, CXT_SHADOW_RAY, CXT_DIFFUSE_RAY, CXT_REFLECT_RAY, CXT_REFRACT_RAY };
+
+struct DPath {                 // 48 B per-ray path state
+  uint32_t sample;             // destination sample slot in the batch
+  float T[3];                  // RGB throughput down to this ray
+  uint8_t cxt, ddepth, rdepth, tdepth;   // ray context + diffuse / reflect / refract depths
+  int32_t group;               // trace target group
+  float fc[3];                 // pending pow(filter, t_hit) colour (glass / pathtracing refraction)
+  uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit
+  uint32_t rng;                // pathtracing: per-path counter
+  uint32_t pad;
+};
+static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
+
+struct DHit {                  // 32 B
+  double t, u, v;
+  int32_t inst, prim;          // inst < 0: miss
+};
+
+struct DLightRec {             // one shading event that gathers direct light
+  double P[3];
+  double N[3];                 // illuminance axis (Nf for plastic, N for hair)
+  double aux[6];               // hair: tangent (3), I (3)
+  float W[3];                  // throughput * diffuse * diffuse_map (plastic) or throughput (hair)
+  float Cd[3];                 // hair: Cd * diffuse
+  uint32_t sample;
+  int32_t group;               // shadow target of the shaded object
+  int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair)
+  int32_t cxt;                 // context of the shading ray (shadow contexts never light)
+};
+
+struct DCounters {
+  unsigned long long rays[5];  // per context (fj_ray_counts order: camera shadow diffuse reflect refract)
+  unsigned long long nodes, prims, insts, traced;
+  uint32_t next_count;         // entries appended to the next ray queue
+  uint32_t light_count;        // entries appended to the light-record queue
+  uint32_t overflow;
+  uint32_t work_head;          // persistent-thread work counter
+};
+
+#endif

@@ -1,0 +1,244 @@
+// fj_host_procedures.cc -- built-in geometry procedures of libfjscene.so.
+//
+// StanfordPlyProcedure: PLY -> Mesh with the behaviour of the reference's
+// procedures/stanfordply_procedure/ply2mesh.cc:51-171 (x y z as Real, optional
+// uv1/uv2 as float, polygons fan-triangulated (v0, v[k+1], v[k+2]), then
+// Mesh::ComputeNormals and Mesh::ComputeBounds).  The PLY reader itself is our
+// own (the reference vendors plyfile.c); it accepts ascii and both binary
+// byte orders with arbitrary extra properties.
+#include "fj_host.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace fjhost {
+
+namespace {
+
+enum PlyType { T_NONE, T_I8, T_U8, T_I16, T_U16, T_I32, T_U32, T_F32, T_F64 };
+
+PlyType parse_type(const std::string &s)
+{
+  if (s == "char" || s == "int8") return T_I8;
+  if (s == "uchar" || s == "uint8") return T_U8;
+  if (s == "short" || s == "int16") return T_I16;
+  if (s == "ushort" || s == "uint16") return T_U16;
+  if (s == "int" || s == "int32") return T_I32;
+  if (s == "uint" || s == "uint32") return T_U32;
+  if (s == "float" || s == "float32") return T_F32;
+  if (s == "double" || s == "float64") return T_F64;
+  return T_NONE;
+}
+
+int type_size(PlyType t)
+{
+  switch (t) {
+  case T_I8: case T_U8: return 1;
+  case T_I16: case T_U16: return 2;
+  case T_I32: case T_U32: case T_F32: return 4;
+  case T_F64: return 8;
+  default: return 0;
+  }
+}
+
+struct PlyProp { std::string name; bool is_list; PlyType count_type, type; };
+struct PlyElem { std::string name; long count; std::vector<PlyProp> props; };
+
+struct Reader {
+  std::ifstream f;
+  int format;   // 0 ascii, 1 little, 2 big
+  bool ok;
+  double read_number(PlyType t)
+  {
+    if (format == 0) {
+      double v = 0;
+      if (!(f >> v)) ok = false;
+      return v;
+    }
+    unsigned char b[8];
+    const int n = type_size(t);
+    f.read(reinterpret_cast<char *>(b), n);
+    if (!f) { ok = false; return 0; }
+    if (format == 2) for (int i = 0; i < n / 2; i++) std::swap(b[i], b[n - 1 - i]);
+    switch (t) {
+    case T_I8: { int8_t v; std::memcpy(&v, b, 1); return v; }
+    case T_U8: { uint8_t v; std::memcpy(&v, b, 1); return v; }
+    case T_I16: { int16_t v; std::memcpy(&v, b, 2); return v; }
+    case T_U16: { uint16_t v; std::memcpy(&v, b, 2); return v; }
+    case T_I32: { int32_t v; std::memcpy(&v, b, 4); return v; }
+    case T_U32: { uint32_t v; std::memcpy(&v, b, 4); return v; }
+    case T_F32: { float v; std::memcpy(&v, b, 4); return v; }
+    case T_F64: { double v; std::memcpy(&v, b, 8); return v; }
+    default: return 0;
+    }
+  }
+};
+
+}  // namespace
+
+int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
+{
+  Reader rd;
+  rd.ok = true;
+  rd.format = -1;
+  rd.f.open(path.c_str(), std::ios::binary);
+  if (!rd.f) { *err = "couldn't open input file: " + path; return -1; }
+
+  std::string line;
+  std::getline(rd.f, line);
+  if (line.substr(0, 3) != "ply") { *err = "not a PLY file: " + path; return -1; }
+  std::vector<PlyElem> elems;
+  while (std::getline(rd.f, line)) {
+    if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+    std::istringstream iss(line);
+    std::string key;
+    iss >> key;
+    if (key == "format") {
+      std::string fmt;
+      iss >> fmt;
+      rd.format = fmt == "ascii" ? 0 : (fmt == "binary_little_endian" ? 1 : (fmt == "binary_big_endian" ? 2 : -1));
+    } else if (key == "element") {
+      PlyElem e;
+      iss >> e.name >> e.count;
+      elems.push_back(e);
+    } else if (key == "property" && !elems.empty()) {
+      PlyProp p;
+      std::string t;
+      iss >> t;
+      if (t == "list") {
+        std::string ct, vt;
+        iss >> ct >> vt >> p.name;
+        p.is_list = true; p.count_type = parse_type(ct); p.type = parse_type(vt);
+      } else {
+        iss >> p.name;
+        p.is_list = false; p.count_type = T_NONE; p.type = parse_type(t);
+      }
+      if (p.type == T_NONE) { *err = "bad PLY property type in " + path; return -1; }
+      elems.back().props.push_back(p);
+    } else if (key == "end_header") {
+      break;
+    }
+  }
+  if (rd.format < 0) { *err = "unknown PLY format in " + path; return -1; }
+
+  std::vector<double> P;
+  std::vector<float> uv;
+  std::vector<int32_t> indices;
+  bool has_uv = false;
+  long nverts = 0;
+  std::vector<double> list_vals;
+  for (const PlyElem &e : elems) {
+    const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+    int ix = -1, iy = -1, iz = -1, iu = -1, iv = -1, ilist = -1;
+    for (size_t k = 0; k < e.props.size(); k++) {
+      const std::string &n = e.props[k].name;
+      if (is_vertex) {
+        if (n == "x") ix = (int) k; else if (n == "y") iy = (int) k; else if (n == "z") iz = (int) k;
+        else if (n == "uv1") iu = (int) k; else if (n == "uv2") iv = (int) k;
+      } else if (is_face && e.props[k].is_list && (n == "vertex_indices" || n == "vertex_index")) ilist = (int) k;
+    }
+    if (is_vertex) {
+      nverts = e.count;
+      P.assign(3 * (size_t) nverts, 0.);
+      has_uv = iu >= 0 || iv >= 0;
+      if (has_uv) uv.assign(2 * (size_t) nverts, 0.f);
+    }
+    for (long i = 0; i < e.count && rd.ok; i++) {
+      for (size_t k = 0; k < e.props.size(); k++) {
+        const PlyProp &p = e.props[k];
+        if (!p.is_list) {
+          const double v = rd.read_number(p.type);
+          if (is_vertex) {
+            if ((int) k == ix) P[3 * i] = v; else if ((int) k == iy) P[3 * i + 1] = v; else if ((int) k == iz) P[3 * i + 2] = v;
+            else if ((int) k == iu) uv[2 * i] = (float) v; else if ((int) k == iv) uv[2 * i + 1] = (float) v;
+          }
+        } else {
+          const int n = (int) rd.read_number(p.count_type);
+          list_vals.resize(n > 0 ? n : 0);
+          for (int j = 0; j < n; j++) list_vals[j] = rd.read_number(p.type);
+          if (is_face && (int) k == ilist)
+            for (int j = 0; j < n - 2; j++) {     // n triangles in a polygon is (n vertices - 2)
+              indices.push_back((int32_t) list_vals[0]);
+              indices.push_back((int32_t) list_vals[j + 1]);
+              indices.push_back((int32_t) list_vals[j + 2]);
+            }
+        }
+      }
+    }
+  }
+  if (!rd.ok) { *err = "truncated PLY file: " + path; return -1; }
+  for (int32_t i : indices)
+    if (i < 0 || i >= nverts) { *err = "PLY face index out of range: " + path; return -1; }
+
+  mesh->P.swap(P);
+  mesh->indices.swap(indices);
+  mesh->uv.swap(uv);
+  mesh->N.clear();
+  mesh->velocity.clear();
+  mesh->face_group.clear();
+  mesh->ComputeNormals();
+  mesh->ComputeBounds();
+  return 0;
+}
+
+int RunCurveGenerator(Scene *sc, Procedure *proc, std::string *err);
+
+int RunProcedure(Scene *sc, Procedure *proc, std::string *err)
+{
+  if (proc->plugin->name == "StanfordPlyProcedure") {
+    // stanfordply_procedure.cc: properties "mesh", "filepath", "io_mode" ("r" reads)
+    if (proc->mesh < 0) { *err = "StanfordPlyProcedure: no mesh assigned"; return -1; }
+    auto fp = proc->strings.find("filepath");
+    if (fp == proc->strings.end()) { *err = "StanfordPlyProcedure: no filepath"; return -1; }
+    auto mode = proc->strings.find("io_mode");
+    if (mode != proc->strings.end() && mode->second != "r") { *err = "StanfordPlyProcedure: only io_mode r is supported"; return -1; }
+    return ReadPlyFile(fp->second, sc->meshes[proc->mesh].get(), err);
+  }
+  if (proc->plugin->name == "CurveGeneratorProcedure") return RunCurveGenerator(sc, proc, err);
+  *err = "procedure " + proc->plugin->name + " is not built in";
+  return -1;
+}
+
+// CurveGeneratorProcedure is restated with the curve primitives (config 5)
+int RunCurveGenerator(Scene *, Procedure *, std::string *err)
+{
+  *err = "CurveGeneratorProcedure: not available yet";
+  return -1;
+}
+
+// Dome light importance sampling (Light::Preprocess for DomeLight,
+// reference src/fj_dome_light.cc:58-97) -- restated with config 6 (IBL).
+int PreprocessDomeLight(Scene *, Light *)
+{
+  g_last_error = "DomeLight: importance sampling preprocess not available yet";
+  return -1;
+}
+
+// .fb writer: the reference's plain-text PTO format, src/fj_framebuffer_io.cc:46-68
+int WriteFrameBuffer(const std::string &filename, const fj::FrameBuffer &fb)
+{
+  std::ofstream strm(filename.c_str());
+  if (!strm) return -1;
+  strm << "#PTO Plain Text Object" << std::endl;   // WritePtoHeader, src/fj_pto.h:15-21
+  strm << "#Fujiyama Renderer FrameBuffer\n";
+  strm << "resolution " << fb.GetWidth() << " " << fb.GetHeight() << '\n';
+  strm << "channel_count " << fb.GetChannelCount() << '\n';
+  strm << "begin pixels\n";
+  const int nc = fb.GetChannelCount();
+  for (int y = 0; y < fb.GetHeight(); y++)
+    for (int x = 0; x < fb.GetWidth(); x++) {
+      const float *p = fb.GetReadOnly(x, y, 0);
+      float c[4] = {0, 0, 0, 0};
+      if (nc == 1) { c[0] = c[1] = c[2] = p[0]; c[3] = 1; }
+      else if (nc == 3) { c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = 1; }
+      else if (nc == 4) { c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3]; }
+      strm << c[0] << " " << c[1] << " " << c[2] << " " << c[3] << '\n';
+    }
+  strm << "end pixels\n";
+  return 0;
+}
+
+}  // namespace fjhost

@@ -1,0 +1,64 @@
+"""ctypes mirrors of the plain-C structs in include/*.h and library loading."""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+
+
+class RayCounts(C.Structure):          # fj_ray_counts
+    _fields_ = [(n, C.c_uint64) for n in ("camera", "shadow", "diffuse", "reflect", "refract")]
+
+    def total(self):
+        return self.camera + self.shadow + self.diffuse + self.reflect + self.refract
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RenderDesc(C.Structure):         # fj_render_desc
+    _fields_ = [
+        ("xres", C.c_int32), ("yres", C.c_int32),
+        ("tile_w", C.c_int32), ("tile_h", C.c_int32),
+        ("rate_x", C.c_int32), ("rate_y", C.c_int32),
+        ("filter_w", C.c_float), ("filter_h", C.c_float),
+        ("region", C.c_int32 * 4),
+        ("jitter", C.c_float), ("cast_shadow", C.c_int32),
+        ("time_start", C.c_double), ("time_end", C.c_double),
+        ("max_diffuse_depth", C.c_int32), ("max_reflect_depth", C.c_int32), ("max_refract_depth", C.c_int32),
+        ("sampler_type", C.c_int32),
+    ]
+
+    def copy(self):
+        out = RenderDesc()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(RenderDesc))
+        return out
+
+
+class GpuStats(C.Structure):           # fjgpu_stats
+    _fields_ = [
+        ("rays", RayCounts),
+        ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("insts_tested", C.c_uint64),
+        ("rays_traced", C.c_uint64),
+        ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("gen_ms", C.c_double),
+        ("resolve_ms", C.c_double), ("total_ms", C.c_double),
+        ("trace_launches", C.c_uint32), ("batches", C.c_uint32),
+    ]
+
+
+class RenderStats(C.Structure):        # fj_render_stats
+    _fields_ = [("render_seconds", C.c_double), ("prepare_seconds", C.c_double), ("rays", RayCounts)]
+
+
+class MissingNativeLibrary(RuntimeError):
+    pass
+
+
+def load(name):
+    """Load lib/<name>; the product has no fallback when it is missing."""
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise MissingNativeLibrary(
+            "%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C fujiyama-renderer_amd/csrc). There is no CPU fallback." % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)

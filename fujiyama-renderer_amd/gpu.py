@@ -1,0 +1,105 @@
+"""ctypes face of lib/libfjgpu.so (include/fjgpu.h): the HIP core."""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+
+_lib = None
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ffi.load("libfjgpu.so")
+        L.fjgpu_last_error.restype = C.c_char_p
+        L.fjgpu_device_count.restype = C.c_int
+        L.fjgpu_scene_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.fjgpu_scene_destroy.argtypes = [C.c_void_p]
+        L.fjgpu_scene_destroy.restype = None
+        L.fjgpu_tile_count.argtypes = [C.POINTER(ffi.RenderDesc)]
+        L.fjgpu_tile_rect.argtypes = [C.POINTER(ffi.RenderDesc), C.c_int, C.POINTER(C.c_int32)]
+        L.fjgpu_render_tiles.argtypes = [C.c_void_p, C.POINTER(ffi.RenderDesc), C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.POINTER(ffi.GpuStats)]
+        L.fjgpu_render_frame.argtypes = [C.c_void_p, C.POINTER(ffi.RenderDesc), C.c_void_p, C.POINTER(ffi.GpuStats)]
+        L.fjgpu_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(ffi.GpuStats)]
+        L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GpuError("fjgpu error %d: %s" % (rc, lib().fjgpu_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    return lib().fjgpu_device_count()
+
+
+class Scene(object):
+    """Device-resident scene (BLAS, instances, lights, shaders, textures)."""
+
+    def __init__(self, scene_desc_ptr, device=0):
+        self._h = C.c_void_p()
+        _check(lib().fjgpu_scene_create(scene_desc_ptr, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().fjgpu_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        _check(lib().fjgpu_set_option(self._h, name.encode(), int(value)))
+
+    def render_frame(self, render):
+        """All tiles -> numpy [H, W, 4] float32 plus GpuStats."""
+        fb = np.zeros((render.yres, render.xres, 4), dtype=np.float32)
+        st = ffi.GpuStats()
+        _check(lib().fjgpu_render_frame(self._h, C.byref(render), fb.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return fb, st
+
+    def render_tiles(self, render, tile_ids, d_framebuffer_ptr, stream=None):
+        """Listed tiles into a DEVICE framebuffer (raw pointer, e.g. torch data_ptr())."""
+        st = ffi.GpuStats()
+        if tile_ids is None:
+            ids_p, n = None, 0
+        else:
+            ids = np.ascontiguousarray(tile_ids, dtype=np.int32)
+            ids_p, n = ids.ctypes.data_as(C.c_void_p), len(ids)
+        _check(lib().fjgpu_render_tiles(self._h, C.byref(render), ids_p, n, C.c_void_p(d_framebuffer_ptr),
+                                        C.c_void_p(stream or 0), C.byref(st)))
+        return st
+
+    def trace(self, group, rays):
+        """Closest hits of rays [n, 8] (orig, dir, tmin, tmax) -> t [n], ids [n, 2], uv [n, 2], stats."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64)
+        n = rays.shape[0]
+        t = np.empty(n, dtype=np.float64)
+        ids = np.empty((n, 2), dtype=np.int32)
+        uv = np.empty((n, 2), dtype=np.float64)
+        st = ffi.GpuStats()
+        _check(lib().fjgpu_trace(self._h, group, n, rays.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
+                                 ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return t, ids, uv, st
+
+
+def tile_count(render):
+    return lib().fjgpu_tile_count(C.byref(render))
+
+
+def tile_rect(render, tile_id):
+    r = (C.c_int32 * 4)()
+    _check(lib().fjgpu_tile_rect(C.byref(render), tile_id, r))
+    return tuple(r)

@@ -1,0 +1,165 @@
+"""Workload definitions: the five BASELINE.json configs (+ reduced variants).
+
+Each builder returns scene-description text (the command language of the
+reference's `scene` parser) for a scene with the same structure as the
+reference's scenes/{teapot,happy_buddhas,xyzrgb_dragon}.scn -- same cameras,
+object transforms, shader assignments, shadow groups, 32 point lights of
+intensity 1/32 at y = 12 -- but with the seeded synthetic assets of synth.py in
+place of the downloadable scans / HDR maps.
+"""
+import os
+
+import numpy as np
+
+from . import synth
+from .fujiyama import SceneInterface
+
+
+def point_lights(si, n=32, seed=7):
+    """n point lights over the scene: x,z uniform in [0,14), y = 12, I = 1/n."""
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        x, z = rng.uniform(0, 14, size=2)
+        name = "light%d" % i
+        si.NewLight(name, "PointLight")
+        si.SetProperty3(name, "translate", float(np.float32(x)), 12, float(np.float32(z)))
+        si.SetProperty1(name, "intensity", 1.0 / n)
+
+
+def _ply(si, mesh, path):
+    proc = mesh + "_proc"
+    si.NewMesh(mesh)
+    si.NewProcedure(proc, "stanfordply_procedure")
+    si.AssignMesh(proc, "mesh", mesh)
+    si.SetStringProperty(proc, "filepath", path)
+    si.SetStringProperty(proc, "io_mode", "r")
+    si.RunProcedure(proc)
+
+
+def _renderer(si, res, spp, extra=()):
+    si.NewFrameBuffer("fb1", "rgba")
+    si.NewRenderer("ren1")
+    si.AssignCamera("ren1", "cam1")
+    si.AssignFrameBuffer("ren1", "fb1")
+    si.SetProperty2("ren1", "resolution", res[0], res[1])
+    si.SetProperty2("ren1", "pixelsamples", spp[0], spp[1])
+    for name, vals in extra:
+        getattr(si, "SetProperty%d" % len(vals))("ren1", name, *vals)
+    si.RenderScene("ren1")
+
+
+def _stage(si, assets, dome_rotate=None, floor_translate=None, sky=True):
+    """floor (plastic) + sky dome (constant shader with the sky texture)."""
+    si.NewShader("floor_shader", "plastic_shader")
+    si.NewShader("dome_shader", "constant_shader")
+    _ply(si, "floor_mesh", assets["floor"])
+    _ply(si, "dome_mesh", assets["dome"])
+    si.NewObjectInstance("floor1", "floor_mesh")
+    if floor_translate:
+        si.SetProperty3("floor1", "translate", *floor_translate)
+    si.AssignShader("floor1", "DEFAULT_SHADING_GROUP", "floor_shader")
+    si.NewObjectInstance("dome1", "dome_mesh")
+    si.SetProperty3("dome1", "scale", .5, .5, .5)
+    if dome_rotate:
+        si.SetProperty3("dome1", "rotate", *dome_rotate)
+    si.AssignShader("dome1", "DEFAULT_SHADING_GROUP", "dome_shader")
+    if sky:
+        si.NewTexture("tex1", assets["sky"])
+        si.AssignTexture("dome_shader", "texture", "tex1")
+
+
+def teapot(asset_dir, res=(256, 256), spp=(1, 1), mesh="teapot", nlights=32, extra=()):
+    """C1: glass object on a plastic floor under a textured dome (teapot.scn)."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("glass_shader", "GlassShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 0, 1, 7)
+    si.SetProperty3("cam1", "rotate", -5.710593137499643, 0, 0)
+    point_lights(si, nlights)
+    si.NewShader("teapot_shader", "glass_shader")
+    _ply(si, "teapot_mesh", a[mesh])
+    si.NewObjectInstance("teapot1", "teapot_mesh")
+    si.AssignShader("teapot1", "DEFAULT_SHADING_GROUP", "teapot_shader")
+    _stage(si, a, dome_rotate=(0, 30, 0), floor_translate=(-2, 0, -2))
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "teapot1")
+    si.AssignObjectGroup("teapot1", "shadow_target", "group1")
+    si.AssignObjectGroup("floor1", "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+def buddhas(asset_dir, res=(1280, 720), spp=(4, 4), mesh="buddha", nlights=32, extra=()):
+    """C2: 4 x 4 instances of one mesh (BVH over instances), happy_buddhas.scn."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 5, 4, 5)
+    si.SetProperty3("cam1", "rotate", -19.471220634490692, 45, 0)
+    point_lights(si, nlights)
+    rng = np.random.RandomState(11)
+    for i in range(16):
+        s = "buddha_shader%d" % i
+        si.NewShader(s, "plastic_shader")
+        c = rng.uniform(0, .5, size=3)
+        si.SetProperty3(s, "diffuse", *[float(np.float32(v)) for v in c])
+    _ply(si, "buddha_mesh", a[mesh])
+    for i in range(16):
+        o = "buddha%d" % i
+        si.NewObjectInstance(o, "buddha_mesh")
+        si.SetProperty3(o, "translate", -1.5 * (i // 4), 0, -1.5 * (i % 4))
+        si.SetProperty3(o, "rotate", 0, 30 * i, 0)
+        si.SetProperty3(o, "scale", .6, .6, .6)
+        si.AssignShader(o, "DEFAULT_SHADING_GROUP", "buddha_shader%d" % i)
+    _stage(si, a, floor_translate=(-2, 0, -2))
+    si.NewObjectGroup("group1")
+    for i in range(16):
+        si.AddObjectToGroup("group1", "buddha%d" % i)
+    for i in range(16):
+        si.AssignObjectGroup("buddha%d" % i, "shadow_target", "group1")
+    si.AssignObjectGroup("floor1", "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+def dragon(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="dragon", nlights=32, extra=()):
+    """C3 (headline): one dense mesh, mirror-like plastic (ior 50, diffuse 0)."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 0, 1.5, 7)
+    si.SetProperty3("cam1", "rotate", -5.710593137499643, 0, 0)
+    point_lights(si, nlights)
+    si.NewShader("dragon_shader0", "plastic_shader")
+    si.SetProperty1("dragon_shader0", "ior", 50)
+    si.SetProperty3("dragon_shader0", "diffuse", 0, 0, 0)
+    _ply(si, "dragon_mesh", a[mesh])
+    si.NewObjectInstance("dragon1", "dragon_mesh")
+    si.SetProperty3("dragon1", "scale", .5, .5, .5)
+    si.SetProperty3("dragon1", "rotate", 0, -35, 0)
+    si.SetProperty3("dragon1", "translate", .2, 0, 0)
+    si.AssignShader("dragon1", "DEFAULT_SHADING_GROUP", "dragon_shader0")
+    _stage(si, a, dome_rotate=(0, 180, 0))
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "dragon1")
+    si.AssignObjectGroup("dragon1", "shadow_target", "group1")
+    si.AssignObjectGroup("floor1", "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon}
+
+
+def default_asset_dir():
+    return os.environ.get("FJ_ASSET_DIR", "/tmp/fj_assets")

@@ -1,0 +1,107 @@
+/* fjgpu.h -- C ABI of the MI355X ray-intersection + integrator core
+ * (libfjgpu.so, hand-written HIP for gfx950).
+ *
+ * This is the compute half of the drop-in boundary.  In the reference the
+ * whole path lives behind one call,
+ *     Renderer::RenderScene()            src/fj_renderer.cc:667-684
+ * reached from SiRenderScene()           src/fj_scene_interface.cc:247-278
+ * after prepare_render() has computed bounds, created the implicit groups and
+ * built the accelerators (same file :1204-1222).  A maintainer of the
+ * reference binds these entry points at exactly that spot:
+ *
+ *   fjgpu_scene_create   replaces build_accelerators()       src/fj_scene_interface.cc:1161-1202
+ *                        (GridAccelerator::build             src/fj_grid_accelerator.cc:69-160,
+ *                         BVHAccelerator::build              src/fj_bvh_accelerator.cc:79-107)
+ *   fjgpu_render_tiles   replaces execute_rendering()'s      src/fj_renderer.cc:747-791
+ *                        MtRunParallelLoop(render_tile)      src/fj_renderer.cc:1098-1121
+ *                        i.e. FixedGridSampler::generate_samples, Camera::GetRay,
+ *                        SlTrace / SlIlluminance / the shader plugins,
+ *                        reconstruct_image + apply_pixel_filter, FrameBuffer::SetColor
+ *   fjgpu_trace          exposes Accelerator::Intersect      src/fj_accelerator.cc:94-113
+ *                        for ray batches (parity tests, SlSurfaceRayIntersect users)
+ *
+ * Plain pointers and sizes only; no C++ or torch types; no globals besides the
+ * last-error string; every function returns 0 or a negative FJGPU_E* code.
+ * There is no CPU fallback: without a GPU every compute call fails loudly.
+ */
+#ifndef FJGPU_H
+#define FJGPU_H
+
+#include <stdint.h>
+#include "fj_scene_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  FJGPU_OK = 0,
+  FJGPU_ENODEV = -1,        /* no HIP device / HIP runtime error */
+  FJGPU_EINVAL = -2,        /* malformed description */
+  FJGPU_EUNSUPPORTED = -3,  /* feature outside the device path (named in the error string) */
+  FJGPU_ENOMEM = -4
+};
+
+typedef struct fjgpu_scene fjgpu_scene;
+
+/* Per-launch device counters, summed over the call (all optional to read) */
+typedef struct fjgpu_stats {
+  fj_ray_counts rays;          /* same events the reference would count */
+  uint64_t nodes_visited;      /* BLAS nodes fetched (64 B each) */
+  uint64_t prims_tested;       /* triangle / curve tests (72 B each) */
+  uint64_t insts_tested;       /* instance records fetched (192 B each) */
+  uint64_t rays_traced;        /* rays entering a trace kernel (closest + shadow) */
+  double   trace_ms;           /* HIP-event time of the trace kernels (closest + shadow) */
+  double   shade_ms;           /* shading / queue kernels */
+  double   gen_ms;             /* sample + camera-ray generation */
+  double   resolve_ms;         /* pixel filter */
+  double   total_ms;           /* first launch -> last kernel done */
+  uint32_t trace_launches;
+  uint32_t batches;
+} fjgpu_stats;
+
+/* Number of visible HIP devices (0 when there is none). */
+int fjgpu_device_count(void);
+
+/* Build the device scene on HIP device `device`: BLAS per mesh / curve set,
+ * instance table with precomputed matrices, groups, lights, shaders and
+ * textures resident in HBM.  The description is copied. */
+int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out);
+void fjgpu_scene_destroy(fjgpu_scene *scene);
+
+/* Tiling of a frame exactly as Tiler::GenerateTiles (src/fj_tiler.cc:56-113). */
+int fjgpu_tile_count(const fj_render_desc *render);
+int fjgpu_tile_rect(const fj_render_desc *render, int tile_id, int32_t rect[4]);
+
+/* Render the listed tiles (NULL = all tiles of the render region) into a
+ * DEVICE framebuffer `d_framebuffer` of xres*yres*4 float32 (RGBA, row-major,
+ * the layout of FrameBuffer, src/fj_framebuffer.cc:130-133); pixels of tiles
+ * not listed are left untouched.  Work is enqueued on `hip_stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and the call returns
+ * after the stream has been synchronised. */
+int fjgpu_render_tiles(fjgpu_scene *scene, const fj_render_desc *render,
+    const int32_t *tile_ids, int n_tiles,
+    float *d_framebuffer, void *hip_stream, fjgpu_stats *stats);
+
+/* Convenience: all tiles, result copied to a HOST buffer (xres*yres*4 floats). */
+int fjgpu_render_frame(fjgpu_scene *scene, const fj_render_desc *render,
+    float *h_framebuffer, fjgpu_stats *stats);
+
+/* Closest hit of n rays against group `group` (HOST arrays; copied in/out).
+ * rays [n][8] = orig xyz, dir xyz, tmin, tmax.  out_t [n] (DBL_MAX on miss),
+ * out_ids [n][2] = instance, primitive (-1 on miss), out_uv [n][2] = barycentric
+ * u, v of the hit (may be NULL). */
+int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
+    double *out_t, int32_t *out_ids, double *out_uv, fjgpu_stats *stats);
+
+/* Tunables (all have defaults): "batch_tiles" tiles per wavefront batch,
+ * "count_nodes" 0/1 enable traversal event counters. Returns 0 or FJGPU_EINVAL. */
+int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
+
+/* Human-readable message for the last error on this thread. */
+const char *fjgpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FJGPU_H */
