@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X ray-intersection/integrator core.
+
+Metric (BASELINE.json): Mray/s, primary + secondary rays, and ms/frame at
+1920x1080, 64 spp.  One "step" = one pass of the hot path over one frame of
+the dragon-class workload (configs[2]: xyzrgb_dragon-class dense mesh of
+7.22 M triangles, plastic + constant shaders, 32 point lights): sample
+generation -> camera rays -> traversal -> shading / shadow / reflection rays ->
+gaussian pixel filter -> framebuffer in HOST memory (D2H included; with N > 1
+also the RCCL tile gather to rank 0).  Scene parse, BLAS build and upload are
+outside the timed region, like the reference's build_accelerators()
+(reference src/fj_scene_interface.cc:264-270).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: "roofline" (dominant kernel = the trace kernels, algorithmic bytes per
+launch / HIP-event duration against the 8 TB/s HBM3E peak) and "cpu_baseline"
+(the compiled reference -- or the CPU restatement -- timed on the host cores on
+a bounded tile sample of the same workload).
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from fujiyama_renderer_amd import distributed as fjdist  # noqa: E402
+from fujiyama_renderer_amd import gpu, host, workloads  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per traversal event (SURVEY.md 8d / DESIGN.md 7)
+S_NODE, S_PRIM, S_INST, S_RAY_IN, S_HIT_OUT = 64, 72, 192, 64, 40
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dragon", choices=sorted(workloads.BUILDERS))
+    ap.add_argument("--mesh", default=None, help="mesh class override (smaller = quicker; not a valid headline run)")
+    ap.add_argument("--res", type=int, nargs=2, default=None)
+    ap.add_argument("--spp", type=int, nargs=2, default=None)
+    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample (0 disables)")
+    ap.add_argument("--batch-tiles", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st):
+    return (st.nodes_visited * S_NODE + st.prims_tested * S_PRIM + st.insts_tested * S_INST +
+            st.rays_traced * (S_RAY_IN + S_HIT_OUT))
+
+
+def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays):
+    """Time the CPU path on `sample_ids` (a block of tiles around the image centre).
+
+    kind "reference": the unmodified reference compiled from /root/reference by
+    oracle/Makefile (oracle/_ref/ref_render), restricted to the sample with its own
+    `render_region` property; its frame time is taken with steady_clock between the
+    frame start / done callbacks.  kind "port": the CPU restatement
+    (oracle/liboracle.so) on the same tiles.  Rays = the rays the device counted
+    for exactly these tiles (per-context counts are identical at parity).
+    """
+    cores = min(os.cpu_count() or 1, 64)
+    rects = [gpu.tile_rect(render, t) for t in sample_ids]
+    region = (min(r[0] for r in rects), min(r[1] for r in rects), max(r[2] for r in rects), max(r[3] for r in rects))
+    desc = "%d tiles (%dx%d px block at %d,%d) of the %dx%d frame, %dx%d spp" % (
+        len(sample_ids), region[2] - region[0], region[3] - region[1], region[0], region[1],
+        render.xres, render.yres, render.rate_x, render.rate_y)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+    if os.path.exists(ref_bin):
+        try:
+            text = scene_text_fn(extra=(("render_region", region),))
+            tmp = os.path.join(workloads.default_asset_dir(), "bench_cpu_baseline")
+            with open(tmp + ".scn", "w") as f:
+                f.write(text)
+            env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"))
+            subprocess.run([ref_bin, tmp + ".scn", tmp + ".fjfb"], env=env, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+            with open(tmp + ".fjfb", "rb") as f:
+                head = f.read(24)
+            seconds = struct.unpack("<d", head[16:24])[0]
+            return {"value": sample_rays / seconds / 1e6, "unit": "Mray/s", "cores": os.cpu_count() or 1,
+                    "kind": "reference", "sample": desc, "seconds": seconds, "rays": int(sample_rays)}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write("cpu_baseline: reference run failed (%s); using the CPU restatement\n" % e)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi  # test infrastructure, used here only as the timed CPU baseline
+    osc = oracle_ffi.OracleScene(scene_ptr)
+    t0 = time.perf_counter()
+    _, rc = osc.render(render, tile_ids=sample_ids, threads=cores)
+    seconds = time.perf_counter() - t0
+    osc.close()
+    return {"value": rc.total() / seconds / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": desc, "seconds": seconds, "rays": int(rc.total())}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    # ---------------- untimed: assets, scene, BLAS build, upload
+    kw = {}
+    if args.mesh:
+        kw["mesh"] = args.mesh
+    if args.res:
+        kw["res"] = tuple(args.res)
+    if args.spp:
+        kw["spp"] = tuple(args.spp)
+    builder = workloads.BUILDERS[args.workload]
+    asset_dir = workloads.default_asset_dir()
+    if world > 1:
+        if rank == 0:
+            builder(asset_dir, **kw)          # generate assets once
+        dist.barrier()
+
+    def scene_text(extra=()):
+        return builder(asset_dir, extra=extra, **kw)
+
+    t_prep = time.perf_counter()
+    host.run_scene_text(scene_text(), deferred=True)
+    scene_ptr, render = host.get_desc()
+    gs = gpu.Scene(scene_ptr, device=local_rank)
+    if args.batch_tiles:
+        gs.set_option("batch_tiles", args.batch_tiles)
+    prep_seconds = time.perf_counter() - t_prep
+
+    n_tiles = gpu.tile_count(render)
+    my_tiles = fjdist.tiles_of_rank(n_tiles, rank, world)
+    fb = torch.zeros((render.yres, render.xres, 4), dtype=torch.float32, device=device)
+    host_fb = torch.empty((render.yres, render.xres, 4), dtype=torch.float32).pin_memory()
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def step():
+        st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
+        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world)
+        if rank == 0:
+            host_fb.copy_(frame, non_blocking=False)       # framebuffer resident in host memory
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    # ---------------- aggregate over ranks
+    rays_local = float(sum(s.rays.total() for s in stats))
+    trace_ms_local = float(sum(s.trace_ms for s in stats))
+    alg_bytes_local = float(sum(algorithmic_bytes(s) for s in stats))
+    launches_local = float(sum(s.trace_launches for s in stats))
+    agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
+    mx = agg.clone()
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    total_rays = float(agg[0])
+    elapsed_max = float(mx[3])
+
+    if rank == 0:
+        s0 = stats[-1]
+        per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
+        # roofline of the dominant kernels (k_trace_closest + k_shadow) on rank 0:
+        # algorithmic bytes of all their launches / summed HIP-event durations
+        alg = float(sum(algorithmic_bytes(s) for s in stats))
+        tms = float(sum(s.trace_ms for s in stats))
+        nl = float(sum(s.trace_launches for s in stats))
+        achieved = alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "k_trace_closest+k_shadow", "launches": int(nl),
+                "avg_launch_ms": tms / nl if nl else None,
+                "algorithmic_bytes_per_launch": alg / nl if nl else None,
+                "bytes_per_ray": alg / max(1.0, float(sum(s.rays_traced for s in stats)))}
+        out = {
+            "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
+            "value": total_rays / elapsed_max / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s-class scene, %dx%d, %dx%d spp, tile %dx%d, %d tiles, 32 point lights"
+                                   % (args.workload, render.xres, render.yres, render.rate_x, render.rate_y,
+                                      render.tile_w, render.tile_h, n_tiles),
+                       "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot"}[args.workload],
+                       "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
+                       "prepare_seconds": prep_seconds},
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_tiles > 0:
+            # bounded CPU sample: a block of tiles in the middle of the frame
+            nx = -(-render.xres // render.tile_w)
+            ny = -(-render.yres // render.tile_h)
+            bw = max(1, min(nx, 4))
+            bh = max(1, min(ny, -(-args.cpu_tiles // bw)))
+            x0, y0 = (nx - bw) // 2, (ny - bh) // 2
+            sample = [(y0 + j) * nx + (x0 + i) for j in range(bh) for i in range(bw)]
+            sfb = torch.zeros_like(fb)
+            sst = gs.render_tiles(render, sample, sfb.data_ptr(), stream)
+            out["cpu_baseline"] = cpu_baseline(args, scene_text, render, scene_ptr, sample, float(sst.rays.total()))
+            out["cpu_baseline"]["gpu_ms_same_sample"] = sst.total_ms
+        print(json.dumps(out))
+    gs.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,33 @@ struct Best { double t, u, v; int inst, prim; };
 
 struct LocalCounters { uint32_t nodes, prims, insts; };
 
+// sum over the 64 lanes of the wave (butterfly; every lane gets the total)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned) (v & 0xffffffffull), off);
+    const unsigned hi = __shfl_xor((unsigned) (v >> 32), off);
+    v += ((unsigned long long) hi << 32) | lo;
+  }
+  return v;
+}
+
+// one global atomic per counter per WAVE, issued once at the end of a
+// persistent kernel (a per-thread atomic on one address serialises in L2)
+__device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long long nodes, unsigned long long prims,
+    unsigned long long insts, unsigned long long traced, unsigned long long shadow)
+{
+  nodes = wave_sum(nodes); prims = wave_sum(prims); insts = wave_sum(insts);
+  traced = wave_sum(traced); shadow = wave_sum(shadow);
+  if (__lane_id() == 0) {
+    if (nodes) atomicAdd(&cnt->nodes, nodes);
+    if (prims) atomicAdd(&cnt->prims, prims);
+    if (insts) atomicAdd(&cnt->insts, insts);
+    if (traced) atomicAdd(&cnt->traced, traced);
+    if (shadow) atomicAdd(&cnt->rays[CXT_SHADOW_RAY], shadow);
+  }
+}
+
 // Closest (ANYHIT == false) or first (ANYHIT == true) hit of one ray against
 // one group.  `stack` points at this lane's column of the LDS stack
 // (entries are BLOCK apart: lane-consecutive addresses, conflict free).
@@ -198,23 +225,21 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *r
     DHit *hits, uint32_t n, DCounters *cnt, int count_events)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const DRay r = rays[i];
-  const int group = paths ? paths[i].group : S.target_group;
-  Best b;
-  LocalCounters lc = {0, 0, 0};
-  trace_group<false>(S, group, mk(r.o[0], r.o[1], r.o[2]), mk(r.d[0], r.d[1], r.d[2]), r.tmin, r.tmax,
-      s_stack + threadIdx.x, &b, &lc);
-  DHit h;
-  h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
-  hits[i] = h;
-  if (count_events) {
-    atomicAdd(&cnt->nodes, (unsigned long long) lc.nodes);
-    atomicAdd(&cnt->prims, (unsigned long long) lc.prims);
-    atomicAdd(&cnt->insts, (unsigned long long) lc.insts);
-    atomicAdd(&cnt->traced, 1ull);
+  unsigned long long c_nodes = 0, c_prims = 0, c_insts = 0, c_traced = 0;
+  // persistent threads: the grid is sized to the machine and strides over the queue
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+    const DRay r = rays[i];
+    const int group = paths ? paths[i].group : S.target_group;
+    Best b;
+    LocalCounters lc = {0, 0, 0};
+    trace_group<false>(S, group, mk(r.o[0], r.o[1], r.o[2]), mk(r.d[0], r.d[1], r.d[2]), r.tmin, r.tmax,
+        s_stack + threadIdx.x, &b, &lc);
+    DHit h;
+    h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
+    hits[i] = h;
+    c_nodes += lc.nodes; c_prims += lc.prims; c_insts += lc.insts; c_traced += 1;
   }
+  if (count_events) flush_counters(cnt, c_nodes, c_prims, c_insts, c_traced, 0);
 }
 
 // --------------------------------------------------------------- k_gen_camera
@@ -350,15 +375,19 @@ __device__ V3 bump_mapping(const DTexture &bump, V3 dPdu, V3 dPdv, float tu, flo
   return normalize(nb);
 }
 
-// wave-aggregated append: one atomic per wave, slots by ballot prefix count
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter)
+// wave-aggregated append: one atomic per wave, slots by ballot prefix count.
+// `tally` (optional) receives the number of appended entries, also once per wave.
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter, unsigned long long *tally)
 {
   const unsigned long long mask = __ballot(want);
   if (!want) return 0xffffffffu;
   const unsigned lane = __lane_id();
   const unsigned leader = (unsigned) __ffsll((long long) mask) - 1;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
+  if (lane == leader) {
+    base = atomicAdd(counter, (uint32_t) __popcll(mask));
+    if (tally) atomicAdd(tally, (unsigned long long) __popcll(mask));
+  }
   base = __shfl(base, leader);
   return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -368,16 +397,18 @@ struct ChildRay {
   V3 o, d;
   double tmin, tmax;
   float T[3];
-  uint8_t cxt, dd, rd, td;
+  uint8_t dd, rd, td;
   int group;
   float fc[3];
   uint32_t flags;
 };
 
-__device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t sample, uint32_t rng,
+// `cxt` is uniform per call site (reflect / refract / diffuse children are
+// emitted by separate calls), so the per-context ray count is one atomic per wave
+__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t rng,
     DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity)
 {
-  const uint32_t slot = wave_append(c.want, &cnt->next_count);
+  const uint32_t slot = wave_append(c.want, &cnt->next_count, &cnt->rays[cxt]);
   if (!c.want) return;
   if (slot >= capacity) { cnt->overflow = 1; return; }
   DRay r;
@@ -388,12 +419,11 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t sample, u
   DPath p;
   p.sample = sample;
   p.T[0] = c.T[0]; p.T[1] = c.T[1]; p.T[2] = c.T[2];
-  p.cxt = c.cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
+  p.cxt = (uint8_t) cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
   p.group = c.group;
   p.fc[0] = c.fc[0]; p.fc[1] = c.fc[1]; p.fc[2] = c.fc[2];
   p.flags = c.flags; p.rng = rng; p.pad = 0;
   next_paths[slot] = p;
-  atomicAdd(&cnt->rays[c.cxt], 1ull);
 }
 
 // trace_surface's SurfaceInput setup + Shader::Evaluate for the device shaders.
@@ -527,7 +557,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           c0.T[0] = (float) (Kr * sh->reflect[0]) * p.T[0];
           c0.T[1] = (float) (Kr * sh->reflect[1]) * p.T[1];
           c0.T[2] = (float) (Kr * sh->reflect[2]) * p.T[2];
-          c0.cxt = CXT_REFLECT_RAY; c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
+          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
           c0.group = I->reflect_target;
           c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
         }
@@ -542,7 +572,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           c0.want = true;
           c0.o = Pw; c0.d = normalize(reflect(Iw, N)); c0.tmin = .0001; c0.tmax = 1000;
           c0.T[0] = (float) Kr * p.T[0]; c0.T[1] = (float) Kr * p.T[1]; c0.T[2] = (float) Kr * p.T[2];
-          c0.cxt = CXT_REFLECT_RAY; c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
+          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
           c0.group = I->reflect_target;
           c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
         }
@@ -550,7 +580,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           c1.want = true;
           c1.o = Pw; c1.d = normalize(refract(Iw, N, (double) (1.f / sh->ior))); c1.tmin = .0001; c1.tmax = 1000;
           c1.T[0] = (float) Kt * p.T[0]; c1.T[1] = (float) Kt * p.T[1]; c1.T[2] = (float) Kt * p.T[2];
-          c1.cxt = CXT_REFRACT_RAY; c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
+          c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
           c1.group = I->refract_target;
           const bool filt = sh->do_color_filter && dot(Iw, N) < 0;
           c1.fc[0] = sh->filter_color[0]; c1.fc[1] = sh->filter_color[1]; c1.fc[2] = sh->filter_color[2];
@@ -577,13 +607,13 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
   }
 
   // ---- compaction: ballot + prefix count, one atomic per wave and queue
-  const uint32_t lslot = wave_append(want_light, &cnt->light_count);
+  const uint32_t lslot = wave_append(want_light, &cnt->light_count, nullptr);
   if (want_light) {
     if (lslot < sp.light_capacity) lrecs[lslot] = lr;
     else cnt->overflow = 1;
   }
-  emit_child(c0, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
-  emit_child(c1, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c0, CXT_REFLECT_RAY, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c1, CXT_REFRACT_RAY, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
 }
 
 // ------------------------------------------------------------------- k_shadow
@@ -596,83 +626,91 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DScene S, ShadowParams sp, con
     float *s_accum, DCounters *cnt, int count_events)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
-  const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-  const uint32_t rec = gtid / sp.lanes;
-  const uint32_t sub = gtid % sp.lanes;
-  const bool active = rec < n;
+  unsigned long long c_nodes = 0, c_prims = 0, c_insts = 0, c_shadow = 0;
+  const unsigned long long total = (unsigned long long) n * sp.lanes;
+  // all lanes of a wave run the same number of iterations (total is a multiple
+  // of the lane-segment size and the stride a multiple of 64), so the segment
+  // shuffles below always see their partners
+  const unsigned long long total_pad = (total + 63ull) & ~63ull;
+  for (unsigned long long gtid = (unsigned long long) blockIdx.x * BLOCK + threadIdx.x; gtid < total_pad;
+       gtid += (unsigned long long) gridDim.x * BLOCK) {
+    const uint32_t rec = (uint32_t) (gtid / sp.lanes);
+    const uint32_t sub = (uint32_t) (gtid % sp.lanes);
+    const bool active = rec < n;
 
-  float sum[3] = {0.f, 0.f, 0.f};
-  uint32_t nshadow = 0;
-  LocalCounters lc = {0, 0, 0};
-  DLightRec R;
-  if (active) {
-    R = lrecs[rec];
-    const V3 Ps = mk(R.P[0], R.P[1], R.P[2]);
-    const V3 axis = mk(R.N[0], R.N[1], R.N[2]);
-    const V3 nml_axis = normalize(axis);
-    const double cos_limit = R.kind == 0 ? sp.cos_half_pi : sp.cos_pi;
-    const bool anyhit = S.groups[R.group].all_opaque != 0;
-    for (uint32_t l = sub; l < (uint32_t) S.n_light_samples; l += sp.lanes) {
-      const DLightSample LS = S.light_samples[l];
-      V3 Ln = mk(LS.P[0] - Ps.x, LS.P[1] - Ps.y, LS.P[2] - Ps.z);
-      const double distance = sqrt(dot(Ln, Ln));
-      if (distance > 0) {
-        const double inv = 1. / distance;
-        Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
-      }
-      const double cosangle = dot(nml_axis, Ln);
-      if (cosangle < cos_limit) continue;
-      float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
-      if (Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001) continue;
-      if (sp.cast_shadow) {
-        nshadow++;
-        Best b;
-        bool hit;
-        if (anyhit) hit = trace_group<true>(S, R.group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
-        else hit = trace_group<false>(S, R.group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
-        if (hit) {
-          // the occluder's shader runs in shadow context and only its Os is used
-          // (src/fj_shading.cc:338-355,548-569): opacity for plastic, 1 otherwise
-          float Os = 1.f;
-          const DInstance *I = &S.instances[b.inst];
-          const DPrimSet *P = &S.primsets[I->primset];
-          const int sg = (P->face_group && b.prim >= 0) ? P->face_group[b.prim] : 0;
-          int sid;
-          if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
-          else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
-          if (sid >= 0 && S.shaders[sid].type == FJ_SHADER_PLASTIC) Os = S.shaders[sid].opacity;
-          Os = (float) clampd(Os, 0, 1);
-          const float ac = 1 - Os;
-          Cl[0] *= ac; Cl[1] *= ac; Cl[2] *= ac;
+    float sum[3] = {0.f, 0.f, 0.f};
+    LocalCounters lc = {0, 0, 0};
+    uint32_t nshadow = 0;
+    uint32_t r_sample = 0;
+    float W[3] = {0.f, 0.f, 0.f};
+    if (active) {
+      const DLightRec *R = &lrecs[rec];
+      const V3 Ps = mk(R->P[0], R->P[1], R->P[2]);
+      const V3 axis = mk(R->N[0], R->N[1], R->N[2]);
+      const V3 nml_axis = normalize(axis);
+      const int kind = R->kind, group = R->group;
+      r_sample = R->sample;
+      W[0] = R->W[0]; W[1] = R->W[1]; W[2] = R->W[2];
+      const double cos_limit = kind == 0 ? sp.cos_half_pi : sp.cos_pi;
+      const bool anyhit = S.groups[group].all_opaque != 0;
+      for (uint32_t l = sub; l < (uint32_t) S.n_light_samples; l += sp.lanes) {
+        const DLightSample LS = S.light_samples[l];
+        V3 Ln = mk(LS.P[0] - Ps.x, LS.P[1] - Ps.y, LS.P[2] - Ps.z);
+        const double distance = sqrt(dot(Ln, Ln));
+        if (distance > 0) {
+          const double inv = 1. / distance;
+          Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
+        }
+        const double cosangle = dot(nml_axis, Ln);
+        if (cosangle < cos_limit) continue;
+        float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
+        if (Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001) continue;
+        if (sp.cast_shadow) {
+          nshadow++;
+          Best b;
+          bool hit;
+          if (anyhit) hit = trace_group<true>(S, group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
+          else hit = trace_group<false>(S, group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
+          if (hit) {
+            // the occluder's shader runs in shadow context and only its Os is used
+            // (src/fj_shading.cc:338-355,548-569): opacity for plastic, 1 otherwise
+            float Os = 1.f;
+            const DInstance *I = &S.instances[b.inst];
+            const DPrimSet *P = &S.primsets[I->primset];
+            const int sg = (P->face_group && b.prim >= 0) ? P->face_group[b.prim] : 0;
+            int sid;
+            if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
+            else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
+            if (sid >= 0 && S.shaders[sid].type == FJ_SHADER_PLASTIC) Os = S.shaders[sid].opacity;
+            Os = (float) clampd(Os, 0, 1);
+            const float ac = 1 - Os;
+            Cl[0] *= ac; Cl[1] *= ac; Cl[2] *= ac;
+          }
+        }
+        if (kind == 0) {             // plastic_shader.cc:131-137
+          float Kd = (float) dot(axis, Ln);
+          Kd = (float) (Kd > 0 ? (double) Kd : 0.);
+          sum[0] += Kd * Cl[0]; sum[1] += Kd * Cl[1]; sum[2] += Kd * Cl[2];
         }
       }
-      if (R.kind == 0) {             // plastic_shader.cc:131-137
-        float Kd = (float) dot(axis, Ln);
-        Kd = (float) (Kd > 0 ? (double) Kd : 0.);
-        sum[0] += Kd * Cl[0]; sum[1] += Kd * Cl[1]; sum[2] += Kd * Cl[2];
-      }
     }
+    // butterfly reduction inside the lane segment (all 64 lanes participate)
+    for (uint32_t off = sp.lanes >> 1; off > 0; off >>= 1) {
+      sum[0] += __shfl_xor(sum[0], (int) off);
+      sum[1] += __shfl_xor(sum[1], (int) off);
+      sum[2] += __shfl_xor(sum[2], (int) off);
+    }
+    if (active && sub == 0) {
+      float *acc = s_accum + 4 * (size_t) r_sample;
+      const float r0 = W[0] * sum[0], r1 = W[1] * sum[1], r2 = W[2] * sum[2];
+      if (r0 != 0.f) atomicAdd(acc + 0, r0);
+      if (r1 != 0.f) atomicAdd(acc + 1, r1);
+      if (r2 != 0.f) atomicAdd(acc + 2, r2);
+    }
+    c_nodes += lc.nodes; c_prims += lc.prims; c_insts += lc.insts; c_shadow += nshadow;
   }
-  // butterfly reduction inside the lane segment (all 64 lanes participate)
-  for (uint32_t off = sp.lanes >> 1; off > 0; off >>= 1) {
-    sum[0] += __shfl_xor(sum[0], (int) off);
-    sum[1] += __shfl_xor(sum[1], (int) off);
-    sum[2] += __shfl_xor(sum[2], (int) off);
-  }
-  if (active && sub == 0) {
-    float *acc = s_accum + 4 * (size_t) R.sample;
-    const float r0 = R.W[0] * sum[0], r1 = R.W[1] * sum[1], r2 = R.W[2] * sum[2];
-    if (r0 != 0.f) atomicAdd(acc + 0, r0);
-    if (r1 != 0.f) atomicAdd(acc + 1, r1);
-    if (r2 != 0.f) atomicAdd(acc + 2, r2);
-  }
-  if (nshadow) atomicAdd(&cnt->rays[CXT_SHADOW_RAY], (unsigned long long) nshadow);
-  if (count_events && (lc.nodes | lc.prims | lc.insts | nshadow)) {
-    atomicAdd(&cnt->nodes, (unsigned long long) lc.nodes);
-    atomicAdd(&cnt->prims, (unsigned long long) lc.prims);
-    atomicAdd(&cnt->insts, (unsigned long long) lc.insts);
-    atomicAdd(&cnt->traced, (unsigned long long) nshadow);
-  }
+  flush_counters(cnt, count_events ? c_nodes : 0, count_events ? c_prims : 0, count_events ? c_insts : 0,
+      count_events ? c_shadow : 0, c_shadow);
 }
 
 // ------------------------------------------------------------------ k_resolve
@@ -713,6 +751,21 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileD
 }
 
 // ----------------------------------------------------------- host launchers
+// persistent launches: at most PERSIST_BLOCKS_PER_CU resident blocks per CU
+#define PERSIST_BLOCKS_PER_CU 4
+static unsigned persistent_grid(unsigned long long blocks_needed)
+{
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const unsigned long long cap = (unsigned long long) cus * PERSIST_BLOCKS_PER_CU;
+  return (unsigned) (blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap);
+}
+
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
 
 int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, const TileDesc *d_tiles, int n_tiles,
@@ -728,7 +781,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_trace_closest, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events);
+  hipLaunchKernelGGL(k_trace_closest, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events);
   LAUNCH_CHECK();
   return 0;
 }
@@ -748,7 +801,7 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
 {
   if (n == 0) return 0;
   const unsigned long long threads = (unsigned long long) n * sp.lanes;
-  hipLaunchKernelGGL(k_shadow, dim3((unsigned) ((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, n,
+  hipLaunchKernelGGL(k_shadow, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, n,
       s_accum, cnt, count_events);
   LAUNCH_CHECK();
   return 0;

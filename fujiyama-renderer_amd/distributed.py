@@ -1,0 +1,73 @@
+"""Tile sharding across the GPUs of one node.
+
+Tiles are independent units (the pixel-sample RNG restarts per tile and tiles
+write disjoint framebuffer rectangles, reference src/fj_fixed_grid_sampler.cc:41-42,
+src/fj_renderer.cc:976-995), so the frame is sharded with no data-path
+collective: tile t belongs to rank t % G (row-major interleave for static load
+balance between sky and object regions), the scene + BLAS are replicated, and
+the only exchange is ONE gather of the finished RGBA tiles to rank 0
+(torch.distributed over RCCL/xGMI: equal-size slabs, `dist.gather`).
+
+Everything here works on CPU tensors with the gloo backend too (tests).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def tiles_of_rank(n_tiles, rank, world):
+    """Interleaved deal: tile ids owned by `rank`."""
+    return list(range(rank, n_tiles, world))
+
+
+def _grid(xres, yres, tile_w, tile_h):
+    return int(math.ceil(xres / float(tile_w))), int(math.ceil(yres / float(tile_h)))
+
+
+def pack_tiles(fb, tile_ids, tile_w, tile_h):
+    """fb [H, W, 4] -> slab [len(tile_ids), tile_h, tile_w, 4] (edge tiles zero padded).
+
+    Assumes the render region is the full frame (tile id = row-major grid index).
+    """
+    H, W, C = fb.shape
+    nx, ny = _grid(W, H, tile_w, tile_h)
+    padded = torch.zeros((ny * tile_h, nx * tile_w, C), dtype=fb.dtype, device=fb.device)
+    padded[:H, :W] = fb
+    tiles = padded.view(ny, tile_h, nx, tile_w, C).permute(0, 2, 1, 3, 4).reshape(ny * nx, tile_h, tile_w, C)
+    idx = torch.as_tensor(tile_ids, dtype=torch.long, device=fb.device)
+    return tiles.index_select(0, idx).contiguous()
+
+
+def unpack_tiles(slabs, tile_id_lists, xres, yres, tile_w, tile_h):
+    """Inverse of pack_tiles for the slabs of all ranks -> fb [H, W, 4]."""
+    C = slabs[0].shape[-1]
+    nx, ny = _grid(xres, yres, tile_w, tile_h)
+    tiles = torch.zeros((ny * nx, tile_h, tile_w, C), dtype=slabs[0].dtype, device=slabs[0].device)
+    for slab, ids in zip(slabs, tile_id_lists):
+        n = len(ids)
+        if n:
+            idx = torch.as_tensor(ids, dtype=torch.long, device=slab.device)
+            tiles.index_copy_(0, idx, slab[:n])
+    padded = tiles.view(ny, nx, tile_h, tile_w, C).permute(0, 2, 1, 3, 4).reshape(ny * tile_h, nx * tile_w, C)
+    return padded[:yres, :xres].contiguous()
+
+
+def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world):
+    """Gather every rank's finished tiles to rank 0; returns the assembled
+    framebuffer on rank 0 and None elsewhere.  One collective per frame:
+    33.2 MB total at 1080p, <= 4.1 MB per peer."""
+    H, W, _ = fb.shape
+    if world == 1:
+        return fb
+    per_rank = int(math.ceil(n_tiles / float(world)))
+    mine = tiles_of_rank(n_tiles, rank, world)
+    slab = torch.zeros((per_rank, tile_h, tile_w, fb.shape[-1]), dtype=fb.dtype, device=fb.device)
+    if mine:
+        slab[:len(mine)] = pack_tiles(fb, mine, tile_w, tile_h)
+    if rank == 0:
+        out = [torch.empty_like(slab) for _ in range(world)]
+        dist.gather(slab, gather_list=out, dst=0)
+        return unpack_tiles(out, [tiles_of_rank(n_tiles, r, world) for r in range(world)], W, H, tile_w, tile_h)
+    dist.gather(slab, gather_list=None, dst=0)
+    return None
