@@ -223,3 +223,36 @@ double CameraUvSizeY(double fov)   // src/fj_camera.cc:98-102
 }
 
 }  // namespace fjgpu
+
+// ---- diagnostics (include/fjgpu.h): let the CPU test-suite pin the host math
+// against the reference's golden vectors without a GPU
+extern "C" {
+
+void fjgpu_host_make_transform(int transform_order, int rotate_order, const double *trs, double *M, double *Minv)
+{
+  fj_xform_desc x;
+  std::memset(&x, 0, sizeof(x));
+  x.transform_order = transform_order;
+  x.rotate_order = rotate_order;
+  x.n_translate = x.n_rotate = x.n_scale = 1;
+  for (int k = 0; k < 3; k++) { x.translate[0].v[k] = trs[k]; x.rotate[0].v[k] = trs[3 + k]; x.scale[0].v[k] = trs[6 + k]; }
+  fjgpu::MakeTransform(x, 0, M, Minv);
+}
+
+void fjgpu_host_xorshift_f01(int n, double *out)
+{
+  std::vector<double> t;
+  fjgpu::XorShiftTable((size_t) (n > 0 ? n : 0), &t);
+  for (int i = 0; i < n; i++) out[i] = t[i];
+}
+
+void fjgpu_host_sampler_margin(const fj_render_desc *r, int32_t *margin)
+{
+  int m[2];
+  fjgpu::SamplerMargin(*r, m);
+  margin[0] = m[0]; margin[1] = m[1];
+}
+
+double fjgpu_host_camera_uv_size_y(double fov) { return fjgpu::CameraUvSizeY(fov); }
+
+}  // extern "C"

@@ -98,6 +98,14 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
  * "count_nodes" 0/1 enable traversal event counters. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
+/* Diagnostics: the host-side math that feeds geometry to the device (matrices,
+ * RNG tables, sampler margins), exported so it can be pinned against the
+ * reference's golden vectors on a machine without a GPU. */
+void fjgpu_host_make_transform(int transform_order, int rotate_order, const double *trs9, double *M16, double *Minv16);
+void fjgpu_host_xorshift_f01(int n, double *out);
+void fjgpu_host_sampler_margin(const fj_render_desc *render, int32_t *margin2);
+double fjgpu_host_camera_uv_size_y(double fov);
+
 /* Human-readable message for the last error on this thread. */
 const char *fjgpu_last_error(void);
 

@@ -1,0 +1,227 @@
+"""GPU suite (-m gpu): the HIP core, called through the C ABI (lib/libfjgpu.so,
+lib/libfjscene.so), against
+  * the CPU oracle on the same seeded inputs,
+  * the golden frames / vectors produced by the compiled reference,
+  * size-independent properties at BASELINE.json's full size.
+
+Tolerances: traversal results (t, instance, primitive, barycentrics) and ray
+counts are BIT-EXACT / equal; per-pixel RGBA is within 1e-4 relative (north_star),
+denominator floored at 1e-3 for near-black pixels.  The residual (~4e-7) comes
+from f32 accumulation order only: light sums are reduced as a tree and terms are
+added to a sample in queue order, where the reference adds them sequentially.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_io
+import oracle_ffi
+from fujiyama_renderer_amd import gpu, host, synth, workloads
+from fujiyama_renderer_amd.fujiyama import SceneInterface
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def rel_err(a, ref):
+    return np.abs(a - ref) / np.maximum(np.abs(ref), 1e-3)
+
+
+def prepare(text):
+    host.run_scene_text(text, deferred=True)
+    return host.get_desc()
+
+
+def render_both(text, threads=None):
+    sp, rd = prepare(text)
+    gs = gpu.Scene(sp)
+    fb, st = gs.render_frame(rd)
+    gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd, threads=threads)
+    osc.close()
+    return fb, st, ref, rc
+
+
+CASES = {
+    "c1_teapot_256_1spp": ("teapot", dict(res=(256, 256), spp=(1, 1))),
+    "teapot_64_2spp": ("teapot", dict(res=(64, 64), spp=(2, 2))),
+    "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
+    "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
+    "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
+                                  extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
+                                         ("filterwidth", (3, 2.5))))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_frames_match_oracle_and_reference_golden(name, asset_dir, golden_dir):
+    builder, kw = CASES[name]
+    fb, st, ref, rc = render_both(workloads.BUILDERS[builder](asset_dir, **kw))
+    assert st.rays.as_dict() == rc.as_dict()                 # same SlTrace events per context
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+    golden = np.load(os.path.join(golden_dir, "frames.npz"))[name]   # rendered by the compiled reference
+    assert fb.shape == golden.shape
+    assert float(rel_err(fb, golden).max()) <= REL_TOL
+    assert st.nodes_visited > 0 and st.prims_tested > 0 and st.rays_traced == st.rays.total()
+
+
+def test_trace_bit_exact_against_reference_grid_vectors(asset_dir, golden_dir):
+    """fjgpu_trace on the golden ray set: t / primitive ids produced by the REFERENCE's
+    GridAccelerator + Mesh::ray_intersect are reproduced bit-exactly by the BVH path."""
+    import test_oracle_golden as tg
+    vec = golden_io.read_vectors(os.path.join(golden_dir, "ref_vectors.bin"))
+    sp, _ = prepare(tg._mesh_scene(asset_dir))
+    rays = np.load(os.path.join(golden_dir, "mesh_trace_rays.npy"))
+    gs = gpu.Scene(sp)
+    t, ids, uv, st = gs.trace(0, rays)
+    gs.close()
+    assert np.array_equal(t, vec["grid_t"])
+    assert np.array_equal(ids[:, 1], vec["grid_prim"])
+    assert st.rays_traced == rays.shape[0]
+
+
+@pytest.mark.parametrize("builder,kw", [("teapot", dict(res=(64, 64), spp=(1, 1))),
+                                        ("buddhas", dict(res=(64, 36), spp=(1, 1), mesh="bunny"))])
+def test_trace_groups_bit_exact_against_oracle(builder, kw, asset_dir):
+    """every group of the scene (shadow group + all-objects group), random ray soup incl.
+    short tmax, origins inside geometry and axis-aligned directions"""
+    sp, _ = prepare(workloads.BUILDERS[builder](asset_dir, **kw))
+    rng = np.random.RandomState(5)
+    n = 30000
+    o = rng.normal(size=(n, 3)) * [4, 2, 4] + [0, 1.5, 0]
+    tgt = rng.normal(size=(n, 3)) * [2, 1, 2] + [-1, 1, -1]
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::97] = [0, -1, 0]
+    d[1::97] = [1, 0, 0]
+    tmax = np.where(rng.uniform(size=n) < .3, rng.uniform(.1, 6, size=n), 1000.)
+    rays = np.concatenate([o, d, np.full((n, 1), 1e-4), tmax[:, None]], axis=1)
+    gs = gpu.Scene(sp)
+    osc = oracle_ffi.OracleScene(sp)
+    for group in (0, 1):
+        t, ids, uv, _ = gs.trace(group, rays)
+        to, io, _ = osc.trace(group, rays)
+        assert np.array_equal(t, to), group
+        assert np.array_equal(ids, io), group
+        assert (io[:, 0] >= 0).mean() > 0.02
+    gs.close()
+    osc.close()
+
+
+def test_tile_subsets_and_batching_are_consistent(asset_dir):
+    """tiles are independent units: any subset / batch split gives the same pixels, and
+    pixels of tiles that were not listed stay untouched"""
+    import torch
+    sp, rd = prepare(workloads.dragon(asset_dir, res=(160, 90), spp=(2, 2), mesh="small"))
+    gs = gpu.Scene(sp)
+    full, st_full = gs.render_frame(rd)
+    n = gpu.tile_count(rd)
+    assert n == 15
+    sub = [1, 7, 14, 3]
+    fb = torch.full((rd.yres, rd.xres, 4), -1.0, dtype=torch.float32, device="cuda")
+    gs.set_option("batch_tiles", 3)
+    st = gs.render_tiles(rd, sub, fb.data_ptr())
+    out = fb.cpu().numpy()
+    touched = np.zeros((rd.yres, rd.xres), dtype=bool)
+    for t in sub:
+        x0, y0, x1, y1 = gpu.tile_rect(rd, t)
+        touched[y0:y1, x0:x1] = True
+        assert float(rel_err(out[y0:y1, x0:x1], full[y0:y1, x0:x1]).max()) <= 1e-6
+    assert (out[~touched] == -1.0).all()
+    assert st.batches == 2 and st.rays.camera < st_full.rays.camera
+    gs.set_option("batch_tiles", 1)
+    one_by_one, st1 = gs.render_frame(rd)
+    assert float(rel_err(one_by_one, full).max()) <= 1e-6
+    assert st1.rays.as_dict() == st_full.rays.as_dict() and st1.batches == 15
+    gs.close()
+
+
+from edge_scenes import EDGE_CASES, custom_scene as _custom_scene  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_CASES))
+def test_edge_cases_match_oracle(name, asset_dir):
+    fb, st, ref, rc = render_both(_custom_scene(asset_dir, **EDGE_CASES[name]))
+    assert st.rays.as_dict() == rc.as_dict(), name
+    assert float(rel_err(fb, ref).max()) <= REL_TOL, name
+    if name == "no_shadows":
+        assert st.rays.shadow == 0
+    if name == "zero_depth":
+        assert st.rays.reflect == 0 and st.rays.refract == 0
+    if name == "no_lights":
+        assert st.rays.shadow == 0 and ref.max() > 0      # dome / reflections still contribute
+
+
+def test_si_render_scene_end_to_end(asset_dir):
+    """the drop-in path: scene text -> Si* API -> SiRenderScene -> HIP core -> FrameBuffer"""
+    text = workloads.teapot(asset_dir, res=(64, 64), spp=(2, 2))
+    host.run_scene_text(text, deferred=False)
+    fb = host.framebuffer(0)
+    st = host.last_stats()
+    sp, rd = host.get_desc()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+    assert st.rays.as_dict() == rc.as_dict() and st.render_seconds > 0
+
+
+def test_unsupported_features_fail_loudly(asset_dir):
+    a = synth.ensure_assets(asset_dir, ("tiny",))
+    base = _custom_scene(asset_dir, lights=1)
+    # time-sampled transform (motion blur) is a "next" row: explicit error, no silent static render
+    moving = base.replace("RenderScene ren1", "SetSampleProperty3 obj1 translate 1 0 0 1\nRenderScene ren1")
+    sp, rd = prepare(moving)
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.Scene(sp)
+    assert "motion blur" in str(e.value)
+    grid = base.replace("NewLight light0 PointLight", "NewLight light0 GridLight")
+    sp, rd = prepare(grid)
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.Scene(sp)
+    assert "GridLight" in str(e.value)
+
+
+def test_full_size_headline_properties(asset_dir):
+    """BASELINE.json configs[2] at full size (7.22 M triangles, 1920x1080, 8x8 spp):
+    size-independent properties + oracle parity on two whole tiles."""
+    import torch
+    sp, rd = prepare(workloads.dragon(asset_dir))
+    assert (rd.xres, rd.yres, rd.rate_x, rd.rate_y) == (1920, 1080, 8, 8)
+    n = gpu.tile_count(rd)
+    assert n == 2040
+    gs = gpu.Scene(sp)
+    # a band of tiles through the dragon, rendered in two different batch splits
+    nx = 60
+    band = [17 * nx + x for x in range(20, 40)]
+    fb = torch.zeros((rd.yres, rd.xres, 4), dtype=torch.float32, device="cuda")
+    st = gs.render_tiles(rd, band, fb.data_ptr())
+    a = fb.cpu().numpy()
+    assert st.rays.camera == len(band) * 264 * 264          # (8*32 + 2*4)^2 samples per full tile
+    assert st.rays.shadow > 10 * st.rays.camera and st.rays.reflect > 0 and st.rays.refract == 0
+    gs.set_option("batch_tiles", 7)
+    fb.zero_()
+    st2 = gs.render_tiles(rd, band[::-1], fb.data_ptr())
+    b = fb.cpu().numpy()
+    assert st2.rays.as_dict() == st.rays.as_dict()
+    assert float(rel_err(b, a).max()) <= 1e-6
+    assert np.isfinite(a).all() and a.min() >= 0
+    y0 = 17 * 32
+    assert (a[y0:y0 + 32, 20 * 32:40 * 32, 3] == 1.0).all()   # every camera ray hits (dome) -> alpha 1
+    assert not a[:y0].any() and not a[y0 + 32:].any()
+    # oracle (reference grid accelerator) on two of those tiles
+    pick = [band[3], band[11]]
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd, tile_ids=pick)
+    osc.close()
+    fb.zero_()
+    st3 = gs.render_tiles(rd, pick, fb.data_ptr())
+    c = fb.cpu().numpy()
+    gs.close()
+    assert st3.rays.as_dict() == rc.as_dict()
+    for t in pick:
+        x0, yy0, x1, y1 = gpu.tile_rect(rd, t)
+        assert float(rel_err(c[yy0:y1, x0:x1], ref[yy0:y1, x0:x1]).max()) <= REL_TOL

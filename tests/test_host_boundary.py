@@ -1,0 +1,150 @@
+"""CPU suite, part 2: the drop-in boundary -- C-ABI export lists, the Si* scene
+API / command parser semantics, the Py3 emitter, and loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from fujiyama_renderer_amd import ffi, fujiyama, gpu, host, workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_GPU = gpu.device_count() > 0
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def _exported(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ffi.LIB_DIR, lib)],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    return set(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_libfjgpu_exports_every_declared_symbol():
+    names = _declared("fjgpu.h", "fjgpu_")
+    assert len(names) >= 13
+    exp = _exported("libfjgpu.so")
+    assert [n for n in names if n not in exp] == []
+
+
+def test_libfjscene_exports_c_and_cxx_api():
+    names = _declared("fj_scene_interface.h", "fj_")
+    assert len([n for n in names if n.startswith("fj_Si")]) == 38
+    exp = _exported("libfjscene.so")
+    assert [n for n in names if n not in exp] == []
+    # the C++ spelling (namespace fj, Itanium mangling) of the 41-function interface
+    cxx = [s for s in exp if s.startswith("_ZN2fj2Si") or s.startswith("_ZN2fj")]
+    for fn in ("SiOpenScene", "SiRenderScene", "SiNewMesh", "SiSetProperty3", "SiAssignShader",
+               "SiSetSampleProperty3", "SiSetTileReportCallback", "SiGetPropertyList"):
+        assert any(fn in s for s in cxx), fn
+
+
+def test_libraries_load_and_report_no_device_loudly(asset_dir):
+    assert isinstance(gpu.device_count(), int)
+    if HAVE_GPU:
+        pytest.skip("GPU present: the no-device failure path cannot be exercised")
+    host.run_scene_text(workloads.teapot(asset_dir, res=(32, 32), spp=(1, 1), mesh="tiny"), deferred=True)
+    sp, rd = host.get_desc()
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.Scene(sp)
+    assert "no CPU fallback" in str(e.value)
+    # and through the host API: RenderScene fails, the parser reports the line
+    with pytest.raises(host.SceneError) as e2:
+        host.run_scene_text(workloads.teapot(asset_dir, res=(32, 32), spp=(1, 1), mesh="tiny"), deferred=False)
+    assert "RenderScene" in str(e2.value) and "no CPU fallback" in str(e2.value)
+
+
+def test_parser_grammar_and_errors(asset_dir):
+    ok = "# comment\n\nNewCamera cam1 PerspectiveCamera\nSetProperty3 cam1 translate 0 1 7\nSetProperty1 cam1 rotate_order ORDER_XYZ\n"
+    assert host.run_scene_text(ok, deferred=True) == 0
+    cases = {
+        "Frobnicate x\n": "unknown command",
+        "NewCamera cam1\n": "too few arguments",
+        "NewCamera cam1 a b\n": "too many arguments",
+        "NewCamera c x\nNewCamera c x\n": "already exists",
+        "SetProperty1 nosuch fov 30\n": "not found",
+        "NewCamera c x\nSetProperty1 c fov abc\n": "bad number",
+        "NewCamera c x\nSetProperty3 c fov 1 2 3\n": "command failed",     # arity must match the property
+        "NewLight l LaserLight\n": "bad light type",
+        "OpenPlugin p /x/UnknownShader.so\n": "no device implementation",
+        "NewTexture t /nonexistent/file.mip\n": "cannot load texture",
+        "NewVolume v\n": "outside the device path",
+    }
+    for text, msg in cases.items():
+        with pytest.raises(host.SceneError) as e:
+            host.run_scene_text(text, deferred=True)
+        assert msg in str(e.value), (text, str(e.value))
+    with pytest.raises(host.SceneError) as e:
+        host.run_scene_text("NewCamera a x\n\nBogus\n", deferred=True)
+    assert ": 3: Bogus" in str(e.value)            # 1-based line number + the line, like bin/scene
+
+
+def test_renderer_defaults_and_property_semantics():
+    text = ("NewCamera cam1 PerspectiveCamera\nNewFrameBuffer fb1 rgba\nNewRenderer ren1\n"
+            "AssignCamera ren1 cam1\nAssignFrameBuffer ren1 fb1\n%sRenderScene ren1\n")
+    host.run_scene_text(text % "", deferred=True)
+    _, rd = host.get_desc()
+    # defaults of src/internal/fj_property_list_include.cc:451-473
+    assert (rd.xres, rd.yres, rd.tile_w, rd.tile_h, rd.rate_x, rd.rate_y) == (320, 240, 32, 32, 3, 3)
+    assert (rd.filter_w, rd.filter_h, rd.jitter, rd.cast_shadow) == (2.0, 2.0, 1.0, 1)
+    assert (rd.max_diffuse_depth, rd.max_reflect_depth, rd.max_refract_depth) == (3, 3, 3)
+    assert tuple(rd.region) == (0, 0, 320, 240) and (rd.time_start, rd.time_end) == (0.0, 1.0)
+    # resolution resets the render region; a later render_region sticks
+    host.run_scene_text(text % "SetProperty4 ren1 render_region 1 2 3 4\nSetProperty2 ren1 resolution 64 48\n", deferred=True)
+    _, rd = host.get_desc()
+    assert tuple(rd.region) == (0, 0, 64, 48)
+    host.run_scene_text(text % "SetProperty2 ren1 resolution 64 48\nSetProperty4 ren1 render_region 8 8 40 32\n", deferred=True)
+    _, rd = host.get_desc()
+    assert tuple(rd.region) == (8, 8, 40, 32)
+    fb = host.framebuffer(0)
+    assert fb.shape == (48, 64, 4) and not fb.any()      # Resize(x, y, 4) at RenderScene
+
+
+def test_python_emitter_matches_command_language(asset_dir):
+    si = fujiyama.SceneInterface(argv=["-R", "80", "60", "-S", "2", "2"])
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 0, 1.5, 7)
+    si.NewFrameBuffer("fb1", "rgba")
+    si.NewRenderer("ren1")
+    si.AssignCamera("ren1", "cam1")
+    si.AssignFrameBuffer("ren1", "fb1")
+    si.RenderScene("ren1")
+    lines = si.text().splitlines()
+    assert lines[0] == "OpenPlugin plastic_shader PlasticShader.so"      # DSO extension appended
+    assert lines[2] == "SetProperty3 cam1 translate 0 1.5 7"
+    assert lines[-3:] == ["SetProperty2 ren1 resolution 80 60", "SetProperty2 ren1 pixelsamples 2 2", "RenderScene ren1"]
+    with pytest.raises(TypeError):
+        si.SetProperty3("cam1", "translate", 1, 2)
+    host.run_scene_text(si.text(), deferred=True)
+    _, rd = host.get_desc()
+    assert (rd.xres, rd.yres, rd.rate_x) == (80, 60, 2)
+
+
+def test_workload_scene_structure(asset_dir):
+    """C2: 16 instances of one mesh + floor + dome, shadow group of the 16, all-objects target"""
+    host.run_scene_text(workloads.buddhas(asset_dir, res=(64, 36), spp=(1, 1), mesh="tiny"), deferred=True)
+    sp, rd = host.get_desc()
+
+    class SD(C.Structure):
+        _fields_ = [("n", C.c_int32 * 7), ("target_group", C.c_int32)]
+    d = C.cast(sp, C.POINTER(SD)).contents
+    n_meshes, n_curves, n_tex, n_shaders, n_lights, n_inst, n_groups = list(d.n)
+    assert (n_meshes, n_curves, n_tex, n_shaders, n_lights, n_inst) == (3, 0, 1, 18, 32, 18)
+    assert n_groups == 2 and d.target_group == 1
+
+
+def test_save_framebuffer_text_format(tmp_path):
+    out = tmp_path / "x.fb"
+    text = ("NewCamera cam1 PerspectiveCamera\nNewFrameBuffer fb1 rgba\nNewRenderer ren1\nAssignCamera ren1 cam1\n"
+            "AssignFrameBuffer ren1 fb1\nSetProperty2 ren1 resolution 4 2\nRenderScene ren1\nSaveFrameBuffer fb1 %s\n" % out)
+    host.run_scene_text(text, deferred=True)
+    lines = out.read_text().splitlines()
+    assert lines[0] == "#PTO Plain Text Object" and lines[2] == "resolution 4 2" and lines[3] == "channel_count 4"
+    assert lines[4] == "begin pixels" and lines[-1] == "end pixels" and len(lines) == 4 * 2 + 6

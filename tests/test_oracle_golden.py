@@ -1,0 +1,287 @@
+"""CPU suite, part 1: the oracle (oracle/liboracle.so, the CPU restatement of the
+reference's hot path) against golden vectors produced by the COMPILED REFERENCE
+(tests/golden/make_golden.py -> oracle/ref_vectors.cc, oracle/ref_render.cc).
+
+Bit-exact everywhere: the restatement keeps the reference's FP64/FP32 operation
+order and is built with -ffp-contract=off.  The same vectors also pin the
+product's HOST-side math (matrices, RNG tables, tiler, sampler margin) through
+the diagnostic exports of lib/libfjgpu.so -- no GPU needed.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import golden_io
+import oracle_ffi
+from fujiyama_renderer_amd import ffi, gpu, host, workloads
+
+pytestmark = pytest.mark.timeout(600) if hasattr(pytest.mark, "timeout") else []
+
+
+@pytest.fixture(scope="module")
+def vec(golden_dir):
+    return golden_io.read_vectors(os.path.join(golden_dir, "ref_vectors.bin"))
+
+
+@pytest.fixture(scope="module")
+def O():
+    L = oracle_ffi.lib()
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_xorshift_stream(vec, O):
+    n = vec["xorshift_u32"].size
+    out = np.empty(n, dtype=np.uint32)
+    O.fjo_xorshift_u32(n, _p(out))
+    assert np.array_equal(out, vec["xorshift_u32"])
+    # first values of Marsaglia's xorshift128 with the reference's seed
+    assert out[0] == 3701687786 and out[1] == 458299110
+    f = np.empty(vec["xorshift_f01"].size)
+    O.fjo_xorshift_f01(f.size, _p(f))
+    assert np.array_equal(f, vec["xorshift_f01"])
+
+
+def test_product_host_xorshift_table(vec):
+    L = gpu.lib()
+    f = np.empty(vec["xorshift_f01"].size)
+    L.fjgpu_host_xorshift_f01(f.size, _p(f))
+    assert np.array_equal(f, vec["xorshift_f01"])
+
+
+def test_box_ray_intersect(vec, O):
+    x = np.ascontiguousarray(vec["box_in"])
+    n = x.shape[0]
+    hit = np.empty(n, dtype=np.int32)
+    t = np.empty((n, 2))
+    O.fjo_box_ray(n, _p(x), _p(hit), _p(t))
+    assert np.array_equal(hit, vec["box_hit"])
+    assert np.array_equal(t, vec["box_t"])
+    # the six hand-built cases (inside, in front, tmax-clipped = still a hit because the
+    # test is tmin < ray_tmax && tmax > ray_tmin, behind, short ray, reversed-infinite box)
+    assert list(vec["box_hit"][:6]) == [1, 1, 1, 0, 0, 0]
+    assert 0.2 < vec["box_hit"].mean() < 0.9
+
+
+def test_tri_ray_intersect(vec, O):
+    x = np.ascontiguousarray(vec["tri_in"])
+    n = x.shape[0]
+    hit = np.empty(n, dtype=np.int32)
+    tuv = np.empty((n, 3))
+    O.fjo_tri_ray(n, _p(x), _p(hit), _p(tuv))
+    assert np.array_equal(hit, vec["tri_hit"])
+    assert np.array_equal(tuv, vec["tri_tuv"])
+    assert 0.3 < hit.mean() < 0.95
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_transform_matrices_all_orders(vec, O, which):
+    orders, trs = vec["xfm_orders"], vec["xfm_trs"]
+    for i in range(orders.shape[0]):
+        M = np.empty(16)
+        Minv = np.empty(16)
+        t = np.ascontiguousarray(trs[i])
+        if which == "oracle":
+            O.fjo_make_transform(int(orders[i, 0]), int(orders[i, 1]), _p(t), _p(M), _p(Minv))
+        else:
+            gpu.lib().fjgpu_host_make_transform(int(orders[i, 0]), int(orders[i, 1]), _p(t), _p(M), _p(Minv))
+        assert np.array_equal(M, vec["xfm_M"][i]), (which, i)
+        assert np.array_equal(Minv, vec["xfm_Minv"][i]), (which, i)
+    assert orders.shape[0] == 108   # 6 transform orders x 6 rotate orders x 3
+
+
+class _Xf(C.Structure):
+    _fields_ = [("transform_order", C.c_int32), ("rotate_order", C.c_int32),
+                ("n", C.c_int32 * 3), ("_pad", C.c_int32),
+                ("translate", (C.c_double * 4) * 8), ("rotate", (C.c_double * 4) * 8), ("scale", (C.c_double * 4) * 8)]
+
+
+class _Cam(C.Structure):
+    _fields_ = [("xform", _Xf), ("fov", C.c_double), ("znear", C.c_double), ("zfar", C.c_double)]
+
+
+def test_camera_get_ray(vec, O):
+    for c in range(vec["cam_params"].shape[0]):
+        p = vec["cam_params"][c]
+        cam = _Cam()
+        cam.xform.transform_order = 0
+        cam.xform.rotate_order = 10
+        cam.xform.n[0] = cam.xform.n[1] = cam.xform.n[2] = 1
+        for k in range(3):
+            cam.xform.translate[0][k] = p[k]
+            cam.xform.rotate[0][k] = p[3 + k]
+            cam.xform.scale[0][k] = 1.0
+        cam.fov, cam.znear, cam.zfar = p[6], .01, 1000
+        uvt = np.ascontiguousarray(vec["cam_uvt"][c])
+        out = np.empty((uvt.shape[0], 8))
+        O.fjo_camera_rays(C.byref(cam), int(p[7]), int(p[8]), uvt.shape[0], _p(uvt), _p(out))
+        assert np.array_equal(out, vec["cam_rays"][c]), c
+
+
+def _render_desc(cfg):
+    r = ffi.RenderDesc()
+    r.xres, r.yres, r.rate_x, r.rate_y = int(cfg[0]), int(cfg[1]), int(cfg[2]), int(cfg[3])
+    r.filter_w, r.filter_h, r.jitter = cfg[4], cfg[5], cfg[6]
+    r.tile_w = r.tile_h = 32
+    r.region[0], r.region[1], r.region[2], r.region[3] = 0, 0, r.xres, r.yres
+    r.time_start, r.time_end = cfg[11], cfg[12]
+    return r
+
+
+def test_fixed_grid_sampler(vec, O):
+    i = 0
+    while "sampler%d_cfg" % i in vec:
+        cfg = vec["sampler%d_cfg" % i]
+        ref = vec["sampler%d_uvt" % i]
+        r = _render_desc(cfg)
+        rect = (C.c_int32 * 4)(int(cfg[7]), int(cfg[8]), int(cfg[9]), int(cfg[10]))
+        out = np.empty((ref.shape[0] + 8, 3))
+        nxy = (C.c_int32 * 2)()
+        n = O.fjo_tile_samples(C.byref(r), rect, _p(out), out.shape[0], nxy)
+        assert n == ref.shape[0], (i, n, ref.shape)
+        assert np.array_equal(out[:n], ref), i
+        # product margin = the reference's count_samples_in_margin
+        m = (C.c_int32 * 2)()
+        gpu.lib().fjgpu_host_sampler_margin(C.byref(r), m)
+        assert nxy[0] == int(cfg[2]) * (int(cfg[9]) - int(cfg[7])) + 2 * m[0]
+        assert nxy[1] == int(cfg[3]) * (int(cfg[10]) - int(cfg[8])) + 2 * m[1]
+        i += 1
+    assert i == 7
+
+
+def test_gaussian_filter(vec, O):
+    xy = np.ascontiguousarray(vec["gauss_xy"])
+    for key, (wx, wy) in (("gauss_w_2_2", (2.0, 2.0)), ("gauss_w_3_2p5", (3.0, 2.5))):
+        out = np.empty(xy.shape[0])
+        O.fjo_gaussian.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        O.fjo_gaussian(xy.shape[0], wx, wy, _p(xy), _p(out))
+        assert np.array_equal(out, vec[key])
+
+
+def test_tiler_oracle_and_product(vec, O):
+    i = 0
+    while "tiler%d_cfg" % i in vec:
+        cfg = vec["tiler%d_cfg" % i]
+        ref = vec["tiler%d_tiles" % i]
+        r = ffi.RenderDesc()
+        r.xres, r.yres, r.tile_w, r.tile_h = int(cfg[0]), int(cfg[1]), int(cfg[2]), int(cfg[3])
+        for k in range(4):
+            r.region[k] = int(cfg[4 + k])
+        out = np.empty((ref.shape[0] + 4, 5), dtype=np.int32)
+        n = O.fjo_tiles(C.byref(r), _p(out), out.shape[0])
+        assert n == ref.shape[0]
+        assert np.array_equal(out[:n], ref)
+        assert gpu.tile_count(r) == n
+        for t in range(n):
+            assert gpu.tile_rect(r, t) == tuple(ref[t, 1:]), (i, t)
+        i += 1
+    assert i == 5
+    # C3: 60 x 34 = 2040 tiles, last row 24 px high
+    t3 = vec["tiler2_tiles"]
+    assert t3.shape[0] == 2040 and t3[-1, 4] - t3[-1, 2] == 24
+
+
+def _mesh_scene(asset_dir):
+    """small mesh as a single-instance scene: group 0 = the all-objects group"""
+    from fujiyama_renderer_amd import synth
+    from fujiyama_renderer_amd.fujiyama import SceneInterface
+    a = synth.ensure_assets(asset_dir, ("small",))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("ply", "StanfordPlyProcedure")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.NewMesh("m")
+    si.NewProcedure("p", "ply")
+    si.AssignMesh("p", "mesh", "m")
+    si.SetStringProperty("p", "filepath", a["small"])
+    si.RunProcedure("p")
+    si.NewShader("s", "constant_shader")
+    si.NewObjectInstance("o", "m")
+    si.AssignShader("o", "DEFAULT_SHADING_GROUP", "s")
+    si.NewFrameBuffer("fb1", "rgba")
+    si.NewRenderer("ren1")
+    si.AssignCamera("ren1", "cam1")
+    si.AssignFrameBuffer("ren1", "fb1")
+    si.SetProperty2("ren1", "resolution", 32, 32)
+    si.RenderScene("ren1")
+    return si.text()
+
+
+def test_grid_accelerator_mesh_trace(vec, golden_dir, asset_dir):
+    """GridAccelerator + Mesh::ray_intersect + ComputeNormals, via the host's own PLY
+    loader (so it also pins libfjscene's StanfordPlyProcedure + normals)."""
+    host.run_scene_text(_mesh_scene(asset_dir), deferred=True)
+    sp, _ = host.get_desc()
+    osc = oracle_ffi.OracleScene(sp)
+    rays = np.load(os.path.join(golden_dir, "mesh_trace_rays.npy"))
+    t, ids, attr = osc.trace(0, rays)
+    osc.close()
+    assert np.array_equal(t, vec["grid_t"])
+    assert np.array_equal(ids[:, 1], vec["grid_prim"])
+    hit = vec["grid_prim"] >= 0
+    assert 0.3 < hit.mean() < 0.95
+    # identity instance transform: N is normalised by ObjectInstance::RayIntersect
+    n_ref = vec["grid_attr"][hit, :3]
+    n_ref = n_ref * (1. / np.sqrt((n_ref * n_ref).sum(1)))[:, None]
+    assert np.allclose(attr[hit, :3], n_ref, rtol=0, atol=1e-15)
+    assert np.array_equal(attr[hit, 5:8], vec["grid_attr"][hit, 3:6])
+
+
+FRAME_CASES = {
+    "c1_teapot_256_1spp": ("teapot", dict(res=(256, 256), spp=(1, 1))),
+    "teapot_64_2spp": ("teapot", dict(res=(64, 64), spp=(2, 2))),
+    "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
+    "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
+    "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
+                                  extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
+                                         ("filterwidth", (3, 2.5))))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_CASES))
+def test_oracle_frames_match_reference_renders(name, golden_dir, asset_dir):
+    """Whole path: sampler -> camera -> BVH over instances -> grid -> triangles -> glass /
+    plastic / constant shaders -> shadow + reflection + refraction recursion -> gaussian
+    filter.  Reference pixels (captured as raw f32 through the frame-done callback) are
+    reproduced BIT-EXACTLY by the restatement."""
+    builder, kw = FRAME_CASES[name]
+    frames = np.load(os.path.join(golden_dir, "frames.npz"))
+    host.run_scene_text(workloads.BUILDERS[builder](asset_dir, **kw), deferred=True)
+    sp, rd = host.get_desc()
+    osc = oracle_ffi.OracleScene(sp)
+    fb, rc = osc.render(rd, threads=4)
+    osc.close()
+    ref = frames[name]
+    assert fb.shape == ref.shape
+    assert np.array_equal(fb, ref), float(np.abs(fb - ref).max())
+    assert rc.camera > 0 and rc.shadow > rc.camera
+
+
+def test_oracle_edge_case_frames_match_reference_renders(golden_dir, asset_dir):
+    """translucent occluders, no shadows, depth limits, colour filter, 0 / 5 / 70 lights,
+    diffuse + bump maps, ragged frame + region, no jitter + wide filter, empty scene"""
+    import edge_scenes
+    frames = np.load(os.path.join(golden_dir, "frames.npz"))
+    for name, kw in sorted(edge_scenes.EDGE_CASES.items()):
+        host.run_scene_text(edge_scenes.custom_scene(asset_dir, **kw), deferred=True)
+        sp, rd = host.get_desc()
+        osc = oracle_ffi.OracleScene(sp)
+        fb, _ = osc.render(rd, threads=4)
+        osc.close()
+        assert np.array_equal(fb, frames["edge_" + name]), (name, float(np.abs(fb - frames["edge_" + name]).max()))
+
+
+def test_oracle_thread_count_invariance(asset_dir):
+    """image is independent of the worker count (per-tile RNG restart)"""
+    host.run_scene_text(workloads.teapot(asset_dir, res=(64, 64), spp=(2, 2)), deferred=True)
+    sp, rd = host.get_desc()
+    osc = oracle_ffi.OracleScene(sp)
+    a, ra = osc.render(rd, threads=1)
+    b, rb = osc.render(rd, threads=7)
+    osc.close()
+    assert np.array_equal(a, b) and ra.as_dict() == rb.as_dict()
