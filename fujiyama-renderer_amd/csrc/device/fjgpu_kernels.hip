@@ -78,6 +78,17 @@ __device__ __forceinline__ bool slab_f32box(const float *bmin, const float *bmax
   return slab(mn, mx, o, inv, tmin, tmax, tnear);
 }
 
+// Reference quirk kept for identical results: BoxRayIntersect (src/fj_box.cc:73-138)
+// branches on `dir >= 0`, which is true for -0.0, and then divides by -0.0: the
+// slab interval comes out reversed (+inf, -inf) and EVERY box test on that ray
+// fails -- the group's bounds test in world space, an instance's accelerator
+// bounds test in object space.  A ray with a negative-zero direction component
+// therefore hits nothing there.  (+0.0 behaves normally.)
+__device__ __forceinline__ bool has_negative_zero(V3 d)
+{
+  return (d.x == 0 && signbit(d.x)) || (d.y == 0 && signbit(d.y)) || (d.z == 0 && signbit(d.z));
+}
+
 // ------------------------------------------------------- triangle test (a21)
 // TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
 // EPSILON 1e-6 (:12); no t-sign test here -- the range test is the caller's
@@ -152,6 +163,7 @@ __device__ bool trace_group(const DScene &S, int group, V3 o, V3 d, double tmin,
   best->prim = -1;
   best->u = best->v = 0;
   const V3 winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+  if (has_negative_zero(d)) return false;
 
   for (int gi = 0; gi < G.count; gi++) {
     const int ii = S.group_instances[G.first + gi];
@@ -166,6 +178,7 @@ __device__ bool trace_group(const DScene &S, int group, V3 o, V3 d, double tmin,
     const V3 oo = xpoint(I->Minv, o);
     const V3 od = xvector(I->Minv, d);
     const V3 inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+    if (has_negative_zero(od)) continue;
     const DPrimSet *P = &S.primsets[I->primset];
     if (P->n_prims == 0) continue;
     if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;

@@ -210,7 +210,7 @@ def test_full_size_headline_properties(asset_dir):
     assert float(rel_err(b, a).max()) <= 1e-6
     assert np.isfinite(a).all() and a.min() >= 0
     y0 = 17 * 32
-    assert (a[y0:y0 + 32, 20 * 32:40 * 32, 3] == 1.0).all()   # every camera ray hits (dome) -> alpha 1
+    assert np.abs(a[y0:y0 + 32, 20 * 32:40 * 32, 3] - 1.0).max() < 1e-6   # every camera ray hits (dome) -> alpha 1
     assert not a[:y0].any() and not a[y0 + 32:].any()
     # oracle (reference grid accelerator) on two of those tiles
     pick = [band[3], band[11]]
