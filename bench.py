@@ -215,7 +215,12 @@ def main():
                                       render.tile_w, render.tile_h, n_tiles),
                        "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot"}[args.workload],
                        "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
-                       "prepare_seconds": prep_seconds},
+                       "prepare_seconds": prep_seconds,
+                       "counters_last_frame_rank0": {"nodes": int(s0.nodes_visited), "prims": int(s0.prims_tested),
+                                                     "insts": int(s0.insts_tested), "traced": int(s0.rays_traced),
+                                                     "shadow_traversed": int(s0.shadow_traversed)},
+                       "ms_last_frame_rank0": {"trace": s0.trace_ms, "shade": s0.shade_ms, "gen": s0.gen_ms,
+                                               "resolve": s0.resolve_ms, "total": s0.total_ms}},
             "roofline": roof,
         }
         if world == 1 and args.cpu_tiles > 0:

@@ -73,6 +73,8 @@ struct fjgpu_scene {
   DPath *d_paths[2];
   DHit *d_hits;
   DLightRec *d_lrecs;
+  DShadowRay *d_squeue;
+  size_t squeue_cap;
   DCounters *d_cnt;
   TileDesc *d_tiles;
   double *d_jit, *d_tim;
@@ -235,6 +237,8 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     for (int k = 0; k < 2; k++) { e |= W.alloc(rays, &sc->d_rays[k]); e |= W.alloc(rays, &sc->d_paths[k]); }
     e |= W.alloc(rays, &sc->d_hits);
     e |= W.alloc(rays, &sc->d_lrecs);
+    sc->squeue_cap = std::min<size_t>(rays * 8, (size_t) 24 << 20);
+    e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
     if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }
@@ -310,6 +314,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   swp.cos_pi = std::cos(3.14159265358979323846);
   swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, sc->n_light_samples)));
   swp.cast_shadow = r->cast_shadow;
+  swp.queue_capacity = (uint32_t) sc->squeue_cap;
   ResolveParams rp;
   rp.xres = r->xres; rp.yres = r->yres; rp.rate_x = r->rate_x; rp.rate_y = r->rate_y;
   rp.npx_x = r->rate_x + 2 * margin[0]; rp.npx_y = r->rate_y + 2 * margin[1];
@@ -382,7 +387,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
       if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); break; }
       if (hc.light_count) {
         rc = timed(&acc.trace_ms, [&]() {
-          return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_cnt, (int) sc->count_events);
+          return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
         });
         if (rc) break;
         acc.trace_launches++;
@@ -400,6 +405,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     if (rc) break;
     DCounters hc;
     if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
+    if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "wavefront queue overflow: lower the batch_tiles option"); break; }
     acc.rays.shadow += hc.rays[CXT_SHADOW_RAY];
     acc.rays.diffuse += hc.rays[CXT_DIFFUSE_RAY];
     acc.rays.reflect += hc.rays[CXT_REFLECT_RAY];
@@ -408,6 +414,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     acc.prims_tested += hc.prims;
     acc.insts_tested += hc.insts;
     acc.rays_traced += hc.traced;
+    acc.shadow_traversed += hc.squeued;
     acc.batches++;
   }
   (void) hipEventRecord(ev_all[1], st);

@@ -27,6 +27,7 @@ struct ShadeParams {
 struct ShadowParams {
   double cos_half_pi, cos_pi;  // cos(PI/2.), cos(PI) evaluated by the host libm
   uint32_t lanes;              // lanes per light record: power of two <= 64
+  uint32_t queue_capacity;     // entries of the shadow-ray queue
   int32_t cast_shadow;
 };
 
@@ -42,7 +43,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
 int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const DRay *rays, const DPath *paths,
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt);
 int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
-    float *s_accum, DCounters *cnt, int count_events);
+    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
     const double *s_uv, const float *s_accum, float *fb);
 

@@ -145,114 +145,184 @@ __device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long lon
   }
 }
 
-// Closest (ANYHIT == false) or first (ANYHIT == true) hit of one ray against
-// one group.  `stack` points at this lane's column of the LDS stack
-// (entries are BLOCK apart: lane-consecutive addresses, conflict free).
+// ----------------------------------------------------- persistent traversal
+// One traversal engine for closest-hit and any-hit rays, written as a per-lane
+// state machine so that a lane that finishes its ray is refilled from the
+// wave's slice of the queue instead of idling until the slowest lane of the
+// wave is done (ray costs are heavy tailed: most shadow rays leave the BLAS
+// after a few nodes, a few walk hundreds).  Each wave owns a contiguous slice
+// of the ray queue (static split, no global work counter) and hands indices to
+// its idle lanes with ballot + prefix popcount.
+//
 // Semantics reproduced: a hit counts iff tmin <= t <= tmax with
 // the ORIGINAL ray range (RayInRange, src/fj_ray.h:29-32); the closest one wins
 // with strict '<' (src/fj_bvh_accelerator.cc:183, src/fj_grid_accelerator.cc:263);
 // at exactly equal t inside one mesh the larger primitive id wins (the grid's
-// LIFO cell lists test it first).
-template <bool ANYHIT>
-__device__ bool trace_group(const DScene &S, int group, V3 o, V3 d, double tmin, double tmax,
-    uint32_t *stack, Best *best, LocalCounters *lc)
+// LIFO cell lists test it first).  Instances of the group are visited in group
+// order (ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: the ray
+// goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
+#define TRAV_DONE 0xffffffffu
+#define TRAV_REFILL 20        // refill when at least this many lanes are idle
+#define TRAV_STEPS 6          // inner-node steps between leaf / refill checks
+
+struct RayIn { V3 o, d; double tmin, tmax; int group; bool anyhit; };
+
+template <class Policy>
+__device__ void traverse_persistent(const DScene &S, Policy &pol, uint32_t n, uint32_t *stack, LocalCounters *lc)
 {
-  const DGroup G = S.groups[group];
-  best->t = DBL_MAX;
-  best->inst = -1;
-  best->prim = -1;
-  best->u = best->v = 0;
-  const V3 winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
-  if (has_negative_zero(d)) return false;
+  const unsigned lane = __lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // this wave's slice of the queue
+  const unsigned long long wave = ((unsigned long long) blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const unsigned long long n_waves = ((unsigned long long) gridDim.x * BLOCK) >> 6;
+  uint32_t next = (uint32_t) ((unsigned long long) n * wave / n_waves);
+  const uint32_t range_end = (uint32_t) ((unsigned long long) n * (wave + 1) / n_waves);
 
-  for (int gi = 0; gi < G.count; gi++) {
-    const int ii = S.group_instances[G.first + gi];
-    const DInstance *I = &S.instances[ii];
-    lc->insts++;
-    double tn;
-    const double tfar = ANYHIT ? tmax : fmin(tmax, best->t);
-    if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
+  bool have = false;
+  uint32_t idx = 0;
+  V3 o = mk(0, 0, 0), winv = o, oo = o, od = o, inv = o, d = o;
+  double tmin = 0, tmax = 0;
+  Best best;
+  best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+  int gfirst = 0, gcount = 0, gi = 0, ii = -1;
+  bool anyhit = false, dead_ray = false;
+  const DPrimSet *P = nullptr;
+  uint32_t cur = TRAV_DONE;
+  int sp = 0;
 
-    // ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: ray to
-    // object space with M^-1; dir is NOT renormalised so t is preserved
-    const V3 oo = xpoint(I->Minv, o);
-    const V3 od = xvector(I->Minv, d);
-    const V3 inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
-    if (has_negative_zero(od)) continue;
-    const DPrimSet *P = &S.primsets[I->primset];
-    if (P->n_prims == 0) continue;
-    if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-
-    int sp = 0;
-    uint32_t cur = P->root;
-    for (;;) {
-      if (cur & FJ_LEAF_FLAG) {
-        const uint32_t first = (cur & 0x7fffffffu) >> 3;
-        const uint32_t cnt = (cur & 7u) + 1;
-        for (uint32_t k = 0; k < cnt; k++) {
-          const double *vp = P->tri_verts + (size_t) (first + k) * 9;
-          double t, u, v;
-          lc->prims++;
-          if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
-          if (!(tmin <= t && t <= tmax)) continue;
-          const int pid = (int) P->prim_ids[first + k];
-          if (t < best->t || (t == best->t && best->inst == ii && pid > best->prim)) {
-            best->t = t; best->u = u; best->v = v; best->inst = ii; best->prim = pid;
-            if (ANYHIT) return true;
-          }
+  for (;;) {
+    // ---- refill idle lanes from the wave's slice
+    const unsigned long long idle = __ballot(!have);
+    if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
+      if (!have) {
+        const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
+        if (my < range_end) {
+          RayIn r;
+          pol.fetch(my, &r);
+          have = true; idx = my;
+          o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+          const DGroup G = S.groups[r.group];
+          gfirst = G.first; gcount = G.count; gi = 0;
+          best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+          cur = TRAV_DONE; sp = 0;
+          dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
         }
-        if (sp == 0) break;
-        cur = stack[(--sp) * BLOCK];
-        continue;
       }
-      const DNode *nd = &P->nodes[cur];
-      lc->nodes++;
-      // 64-byte node: four 16-byte loads
-      const float4 a = reinterpret_cast<const float4 *>(nd)[0];
-      const float4 b = reinterpret_cast<const float4 *>(nd)[1];
-      const float4 c = reinterpret_cast<const float4 *>(nd)[2];
-      const uint4 e = reinterpret_cast<const uint4 *>(nd)[3];
-      const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-      const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
-      const double tf2 = ANYHIT ? tmax : fmin(tmax, best->t);
-      double tl, tr;
-      const bool hl = slab_f32box(lmin, lmax, oo, inv, tmin, tf2, &tl);
-      const bool hr = slab_f32box(rmin, rmax, oo, inv, tmin, tf2, &tr);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        stack[(sp++) * BLOCK] = left_first ? e.y : e.x;
-        cur = left_first ? e.x : e.y;
-      } else if (hl) cur = e.x;
-      else if (hr) cur = e.y;
-      else {
-        if (sp == 0) break;
-        cur = stack[(--sp) * BLOCK];
+      next += (uint32_t) __popcll(idle);
+      if (__ballot(have) == 0ull) break;
+    }
+
+    // ---- lanes between instances: enter the next instance or retire the ray
+    if (have && cur == TRAV_DONE) {
+      bool found = false;
+      while (!dead_ray && gi < gcount) {
+        ii = S.group_instances[gfirst + gi];
+        gi++;
+        const DInstance *I = &S.instances[ii];
+        lc->insts++;
+        double tn;
+        const double tfar = anyhit ? tmax : fmin(tmax, best.t);
+        if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
+        oo = xpoint(I->Minv, o);
+        od = xvector(I->Minv, d);
+        if (has_negative_zero(od)) continue;
+        inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+        P = &S.primsets[I->primset];
+        if (P->n_prims == 0) continue;
+        if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+        found = true;
+        break;
+      }
+      if (found) { cur = P->root; sp = 0; }
+      else { pol.finish(idx, best); have = false; }
+    }
+
+    // ---- inner nodes: a few steps for every lane that holds one
+    for (int step = 0; step < TRAV_STEPS; step++) {
+      const bool inner = have && !(cur & FJ_LEAF_FLAG);
+      if (__ballot(inner) == 0ull) break;
+      if (inner) {
+        const DNode *nd = &P->nodes[cur];
+        lc->nodes++;
+        // 64-byte node: four 16-byte loads
+        const float4 a = reinterpret_cast<const float4 *>(nd)[0];
+        const float4 b = reinterpret_cast<const float4 *>(nd)[1];
+        const float4 c = reinterpret_cast<const float4 *>(nd)[2];
+        const uint4 e = reinterpret_cast<const uint4 *>(nd)[3];
+        const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+        const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+        const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
+        double tl, tr;
+        const bool hl = slab_f32box(lmin, lmax, oo, inv, tmin, tf2, &tl);
+        const bool hr = slab_f32box(rmin, rmax, oo, inv, tmin, tf2, &tr);
+        if (hl && hr) {
+          const bool left_first = tl <= tr;
+          stack[(sp++) * BLOCK] = left_first ? e.y : e.x;
+          cur = left_first ? e.x : e.y;
+        } else if (hl) cur = e.x;
+        else if (hr) cur = e.y;
+        else cur = (sp == 0) ? TRAV_DONE : stack[(--sp) * BLOCK];
       }
     }
+
+    // ---- leaves: FP64 Moller-Trumbore on the pre-gathered triangles
+    if (have && (cur & FJ_LEAF_FLAG) && cur != TRAV_DONE) {
+      const uint32_t first = (cur & 0x7fffffffu) >> 3;
+      const uint32_t cnt = (cur & 7u) + 1;
+      bool stop = false;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const double *vp = P->tri_verts + (size_t) (first + k) * 9;
+        double t, u, v;
+        lc->prims++;
+        if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+        if (!(tmin <= t && t <= tmax)) continue;
+        const int pid = (int) P->prim_ids[first + k];
+        if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+          best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
+          if (anyhit) { stop = true; break; }
+        }
+      }
+      if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
+      else cur = (sp == 0) ? TRAV_DONE : stack[(--sp) * BLOCK];
+    }
   }
-  return best->inst >= 0;
 }
 
 // ------------------------------------------------------------------ k_trace
+struct ClosestPolicy {
+  const DRay *rays;
+  const DPath *paths;
+  DHit *hits;
+  int default_group;
+  __device__ void fetch(uint32_t i, RayIn *r) const
+  {
+    const DRay q = rays[i];
+    r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
+    r->tmin = q.tmin; r->tmax = q.tmax;
+    r->group = paths ? paths[i].group : default_group;
+    r->anyhit = false;
+  }
+  __device__ void finish(uint32_t i, const Best &b) const
+  {
+    DHit h;
+    h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
+    hits[i] = h;
+  }
+};
+
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, int count_events)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
-  unsigned long long c_nodes = 0, c_prims = 0, c_insts = 0, c_traced = 0;
-  // persistent threads: the grid is sized to the machine and strides over the queue
-  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-    const DRay r = rays[i];
-    const int group = paths ? paths[i].group : S.target_group;
-    Best b;
-    LocalCounters lc = {0, 0, 0};
-    trace_group<false>(S, group, mk(r.o[0], r.o[1], r.o[2]), mk(r.d[0], r.d[1], r.d[2]), r.tmin, r.tmax,
-        s_stack + threadIdx.x, &b, &lc);
-    DHit h;
-    h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
-    hits[i] = h;
-    c_nodes += lc.nodes; c_prims += lc.prims; c_insts += lc.insts; c_traced += 1;
+  ClosestPolicy pol;
+  pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
+  LocalCounters lc = {0, 0, 0};
+  traverse_persistent(S, pol, n, s_stack + threadIdx.x, &lc);
+  if (count_events) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
   }
-  if (count_events) flush_counters(cnt, c_nodes, c_prims, c_insts, c_traced, 0);
 }
 
 // --------------------------------------------------------------- k_gen_camera
@@ -630,43 +700,58 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
 }
 
 // ------------------------------------------------------------------- k_shadow
-// SlIlluminance (src/fj_shading.cc:296-359) for every (light record, light
-// sample) pair.  `lanes` consecutive lanes (a power of two <= 64) serve one
-// record and stride over the light samples; the per-record sum is formed with
-// a butterfly reduction inside the lane segment, and one lane adds
-// W * sum_i Kd_i * Cl_i * (1 - alpha_i) to the sample.
-__global__ void __launch_bounds__(BLOCK) k_shadow(DScene S, ShadowParams sp, const DLightRec *lrecs, uint32_t n,
-    float *s_accum, DCounters *cnt, int count_events)
+// SlIlluminance (src/fj_shading.cc:296-359) in two wavefront stages.
+//
+// k_shadow_cull: every (light record, light sample) pair.  `lanes` consecutive
+// lanes (a power of two <= 64) serve one record and stride over the light
+// samples.  A pair is tested against the world AABBs of the shadow group's
+// instances: if it misses all of them the light is unoccluded and Kd * Cl goes
+// into the per-record sum (butterfly reduction inside the lane segment, one
+// lane adds W * sum to the sample); otherwise the ray is appended -- ballot +
+// prefix count, one atomic per wave -- to the compact shadow-ray queue.
+//
+// k_shadow_trace: the compact queue only, so every lane of a wave is
+// traversing (no lanes idling while a neighbour walks the BLAS).  Adds
+// c * (1 - Os_occluder) to the sample, or c when the ray reaches the light.
+__global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
+    uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
-  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
-  unsigned long long c_nodes = 0, c_prims = 0, c_insts = 0, c_shadow = 0;
+  unsigned long long c_insts = 0, c_shadow = 0;
+  const uint32_t n = rec_end - rec_begin;
   const unsigned long long total = (unsigned long long) n * sp.lanes;
-  // all lanes of a wave run the same number of iterations (total is a multiple
-  // of the lane-segment size and the stride a multiple of 64), so the segment
-  // shuffles below always see their partners
+  // every lane of a wave runs the same number of iterations (see k_shadow_trace note)
   const unsigned long long total_pad = (total + 63ull) & ~63ull;
   for (unsigned long long gtid = (unsigned long long) blockIdx.x * BLOCK + threadIdx.x; gtid < total_pad;
        gtid += (unsigned long long) gridDim.x * BLOCK) {
-    const uint32_t rec = (uint32_t) (gtid / sp.lanes);
+    const uint32_t rec = rec_begin + (uint32_t) (gtid / sp.lanes);
     const uint32_t sub = (uint32_t) (gtid % sp.lanes);
-    const bool active = rec < n;
+    const bool active = rec < rec_end;
 
     float sum[3] = {0.f, 0.f, 0.f};
-    LocalCounters lc = {0, 0, 0};
-    uint32_t nshadow = 0;
     uint32_t r_sample = 0;
     float W[3] = {0.f, 0.f, 0.f};
+    const uint32_t nl = (uint32_t) S.n_light_samples;
+    const uint32_t iters = (nl + sp.lanes - 1) / sp.lanes;     // uniform trip count: ballots stay convergent
+    DLightRec R;
+    V3 Ps = mk(0, 0, 0), axis = Ps, nml_axis = Ps;
+    DGroup G;
+    G.first = 0; G.count = 0; G.all_opaque = 1; G.pad = 0;
+    double cos_limit = 0;
     if (active) {
-      const DLightRec *R = &lrecs[rec];
-      const V3 Ps = mk(R->P[0], R->P[1], R->P[2]);
-      const V3 axis = mk(R->N[0], R->N[1], R->N[2]);
-      const V3 nml_axis = normalize(axis);
-      const int kind = R->kind, group = R->group;
-      r_sample = R->sample;
-      W[0] = R->W[0]; W[1] = R->W[1]; W[2] = R->W[2];
-      const double cos_limit = kind == 0 ? sp.cos_half_pi : sp.cos_pi;
-      const bool anyhit = S.groups[group].all_opaque != 0;
-      for (uint32_t l = sub; l < (uint32_t) S.n_light_samples; l += sp.lanes) {
+      R = lrecs[rec];
+      Ps = mk(R.P[0], R.P[1], R.P[2]);
+      axis = mk(R.N[0], R.N[1], R.N[2]);
+      nml_axis = normalize(axis);
+      r_sample = R.sample;
+      W[0] = R.W[0]; W[1] = R.W[1]; W[2] = R.W[2];
+      cos_limit = R.kind == 0 ? sp.cos_half_pi : sp.cos_pi;
+      G = S.groups[R.group];
+    }
+    for (uint32_t it = 0; it < iters; it++) {
+      const uint32_t l = sub + it * sp.lanes;
+      bool emit = false;
+      DShadowRay q;
+      if (active && l < nl) {
         const DLightSample LS = S.light_samples[l];
         V3 Ln = mk(LS.P[0] - Ps.x, LS.P[1] - Ps.y, LS.P[2] - Ps.z);
         const double distance = sqrt(dot(Ln, Ln));
@@ -675,36 +760,45 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DScene S, ShadowParams sp, con
           Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
         }
         const double cosangle = dot(nml_axis, Ln);
-        if (cosangle < cos_limit) continue;
         float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
-        if (Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001) continue;
-        if (sp.cast_shadow) {
-          nshadow++;
-          Best b;
-          bool hit;
-          if (anyhit) hit = trace_group<true>(S, group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
-          else hit = trace_group<false>(S, group, Ps, Ln, .0001, distance, s_stack + threadIdx.x, &b, &lc);
-          if (hit) {
-            // the occluder's shader runs in shadow context and only its Os is used
-            // (src/fj_shading.cc:338-355,548-569): opacity for plastic, 1 otherwise
-            float Os = 1.f;
-            const DInstance *I = &S.instances[b.inst];
-            const DPrimSet *P = &S.primsets[I->primset];
-            const int sg = (P->face_group && b.prim >= 0) ? P->face_group[b.prim] : 0;
-            int sid;
-            if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
-            else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
-            if (sid >= 0 && S.shaders[sid].type == FJ_SHADER_PLASTIC) Os = S.shaders[sid].opacity;
-            Os = (float) clampd(Os, 0, 1);
-            const float ac = 1 - Os;
-            Cl[0] *= ac; Cl[1] *= ac; Cl[2] *= ac;
+        const bool lit = !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
+        if (lit) {
+          float k[3] = {0.f, 0.f, 0.f};
+          if (R.kind == 0) {             // plastic_shader.cc:131-137
+            float Kd = (float) dot(axis, Ln);
+            Kd = (float) (Kd > 0 ? (double) Kd : 0.);
+            k[0] = Kd * Cl[0]; k[1] = Kd * Cl[1]; k[2] = Kd * Cl[2];
+          }
+          bool maybe_occluded = false;
+          if (sp.cast_shadow) {
+            c_shadow++;
+            // group bounds test + leaf bounds of the instance BVH, as culling
+            if (!has_negative_zero(Ln)) {
+              const V3 winv = mk(1. / Ln.x, 1. / Ln.y, 1. / Ln.z);
+              for (int gi = 0; gi < G.count; gi++) {
+                const DInstance *I = &S.instances[S.group_instances[G.first + gi]];
+                double tn;
+                if (slab(I->wbounds, I->wbounds + 3, Ps, winv, .0001, distance, &tn)) { maybe_occluded = true; break; }
+                c_insts++;
+              }
+            }
+          }
+          if (maybe_occluded) {
+            emit = true;
+            q.o[0] = Ps.x; q.o[1] = Ps.y; q.o[2] = Ps.z;
+            q.d[0] = Ln.x; q.d[1] = Ln.y; q.d[2] = Ln.z;
+            q.tmax = distance;
+            q.c[0] = W[0] * k[0]; q.c[1] = W[1] * k[1]; q.c[2] = W[2] * k[2];
+            q.sample = r_sample; q.group = R.group; q.pad = 0;
+          } else {
+            sum[0] += k[0]; sum[1] += k[1]; sum[2] += k[2];
           }
         }
-        if (kind == 0) {             // plastic_shader.cc:131-137
-          float Kd = (float) dot(axis, Ln);
-          Kd = (float) (Kd > 0 ? (double) Kd : 0.);
-          sum[0] += Kd * Cl[0]; sum[1] += Kd * Cl[1]; sum[2] += Kd * Cl[2];
-        }
+      }
+      const uint32_t slot = wave_append(emit, &cnt->shadow_count, nullptr);
+      if (emit) {
+        if (slot < sp.queue_capacity) squeue[slot] = q;
+        else cnt->overflow = 1;
       }
     }
     // butterfly reduction inside the lane segment (all 64 lanes participate)
@@ -720,10 +814,62 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DScene S, ShadowParams sp, con
       if (r1 != 0.f) atomicAdd(acc + 1, r1);
       if (r2 != 0.f) atomicAdd(acc + 2, r2);
     }
-    c_nodes += lc.nodes; c_prims += lc.prims; c_insts += lc.insts; c_shadow += nshadow;
   }
-  flush_counters(cnt, count_events ? c_nodes : 0, count_events ? c_prims : 0, count_events ? c_insts : 0,
-      count_events ? c_shadow : 0, c_shadow);
+  flush_counters(cnt, 0, 0, count_events ? c_insts : 0, count_events ? c_shadow : 0, c_shadow);
+}
+
+struct ShadowPolicy {
+  const DScene *S;
+  const DShadowRay *squeue;
+  float *s_accum;
+  __device__ void fetch(uint32_t i, RayIn *r) const
+  {
+    const DShadowRay q = squeue[i];
+    r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
+    r->tmin = .0001; r->tmax = q.tmax;
+    r->group = q.group;
+    r->anyhit = S->groups[q.group].all_opaque != 0;
+  }
+  __device__ void finish(uint32_t i, const Best &b) const
+  {
+    float ac = 1.f;
+    if (b.inst >= 0) {
+      // the occluder's shader runs in shadow context and only its Os is used
+      // (src/fj_shading.cc:338-355,548-569): opacity for plastic, 1 otherwise
+      float Os = 1.f;
+      const DInstance *I = &S->instances[b.inst];
+      const DPrimSet *P = &S->primsets[I->primset];
+      const int sg = (P->face_group && b.prim >= 0) ? P->face_group[b.prim] : 0;
+      int sid;
+      if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
+      else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
+      if (sid >= 0 && S->shaders[sid].type == FJ_SHADER_PLASTIC) Os = S->shaders[sid].opacity;
+      Os = (float) clampd(Os, 0, 1);
+      ac = 1 - Os;
+    }
+    if (ac == 0.f) return;
+    const DShadowRay *q = &squeue[i];
+    const float r0 = q->c[0] * ac, r1 = q->c[1] * ac, r2 = q->c[2] * ac;
+    float *acc = s_accum + 4 * (size_t) q->sample;
+    if (r0 != 0.f) atomicAdd(acc + 0, r0);
+    if (r1 != 0.f) atomicAdd(acc + 1, r1);
+    if (r2 != 0.f) atomicAdd(acc + 2, r2);
+  }
+};
+
+__global__ void __launch_bounds__(BLOCK) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
+    DCounters *cnt, int count_events)
+{
+  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
+  const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
+  ShadowPolicy pol;
+  pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
+  LocalCounters lc = {0, 0, 0};
+  traverse_persistent(S, pol, n, s_stack + threadIdx.x, &lc);
+  if (count_events) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
+  }
 }
 
 // ------------------------------------------------------------------ k_resolve
@@ -810,13 +956,25 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
 }
 
 int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
-    float *s_accum, DCounters *cnt, int count_events)
+    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  const unsigned long long threads = (unsigned long long) n * sp.lanes;
-  hipLaunchKernelGGL(k_shadow, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, n,
-      s_accum, cnt, count_events);
-  LAUNCH_CHECK();
+  // records are processed in chunks whose worst case (every pair survives the cull)
+  // fits the shadow-ray queue; the trace stage reads the queue length on the device
+  const uint32_t nl = (uint32_t) (S.n_light_samples > 0 ? S.n_light_samples : 1);
+  uint32_t chunk = sp.queue_capacity / nl;
+  if (chunk == 0) chunk = 1;
+  for (uint32_t b = 0; b < n; b += chunk) {
+    const uint32_t e = (n - b < chunk) ? n : b + chunk;
+    (void) hipMemsetAsync(&cnt->shadow_count, 0, sizeof(uint32_t), st);
+    const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
+    hipLaunchKernelGGL(k_shadow_cull, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
+        S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_shadow_trace, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+        S, (const DShadowRay *) squeue, s_accum, cnt, count_events);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -129,13 +129,21 @@ struct DLightRec {             // one shading event that gathers direct light
   int32_t cxt;                 // context of the shading ray (shadow contexts never light)
 };
 
+struct DShadowRay {            // 80 B: a shadow ray that survived the instance-box cull
+  double o[3], d[3], tmax;
+  float c[3];                  // W * Kd * Cl: added to the sample, scaled by (1 - occluder Os)
+  uint32_t sample;
+  int32_t group;
+  int32_t pad;
+};
+
 struct DCounters {
   unsigned long long rays[5];  // per context (fj_ray_counts order: camera shadow diffuse reflect refract)
-  unsigned long long nodes, prims, insts, traced;
+  unsigned long long nodes, prims, insts, traced, squeued;
   uint32_t next_count;         // entries appended to the next ray queue
   uint32_t light_count;        // entries appended to the light-record queue
   uint32_t overflow;
-  uint32_t work_head;          // persistent-thread work counter
+  uint32_t shadow_count;       // entries appended to the shadow-ray queue (was: work head)
 };
 
 #endif

@@ -39,7 +39,7 @@ class GpuStats(C.Structure):           # fjgpu_stats
     _fields_ = [
         ("rays", RayCounts),
         ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("insts_tested", C.c_uint64),
-        ("rays_traced", C.c_uint64),
+        ("rays_traced", C.c_uint64), ("shadow_traversed", C.c_uint64),
         ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("gen_ms", C.c_double),
         ("resolve_ms", C.c_double), ("total_ms", C.c_double),
         ("trace_launches", C.c_uint32), ("batches", C.c_uint32),

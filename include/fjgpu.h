@@ -51,6 +51,7 @@ typedef struct fjgpu_stats {
   uint64_t prims_tested;       /* triangle / curve tests (72 B each) */
   uint64_t insts_tested;       /* instance records fetched (192 B each) */
   uint64_t rays_traced;        /* rays entering a trace kernel (closest + shadow) */
+  uint64_t shadow_traversed;   /* shadow rays that survived the instance-box cull and walked a BLAS */
   double   trace_ms;           /* HIP-event time of the trace kernels (closest + shadow) */
   double   shade_ms;           /* shading / queue kernels */
   double   gen_ms;             /* sample + camera-ray generation */
