@@ -237,7 +237,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     for (int k = 0; k < 2; k++) { e |= W.alloc(rays, &sc->d_rays[k]); e |= W.alloc(rays, &sc->d_paths[k]); }
     e |= W.alloc(rays, &sc->d_hits);
     e |= W.alloc(rays, &sc->d_lrecs);
-    sc->squeue_cap = std::min<size_t>(rays * 8, (size_t) 24 << 20);
+    sc->squeue_cap = std::min<size_t>(rays * 8, (size_t) 24 << 20) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);

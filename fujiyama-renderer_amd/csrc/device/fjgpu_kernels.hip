@@ -17,6 +17,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fjgpu_types.h"
 #include "fjgpu_kernels.h"
@@ -162,22 +163,25 @@ __device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long lon
 // order (ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: the ray
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
-#define TRAV_REFILL 20        // refill when at least this many lanes are idle
-#define TRAV_STEPS 6          // inner-node steps between leaf / refill checks
+// tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
+struct TravTune { uint32_t refill, steps, grab; };
+#define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
+#define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
+#define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
 
 struct RayIn { V3 o, d; double tmin, tmax; int group; bool anyhit; };
 
 template <class Policy>
-__device__ void traverse_persistent(const DScene &S, Policy &pol, uint32_t n, uint32_t *stack, LocalCounters *lc)
+__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, uint32_t *stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
+  bool head_live = true;                   // wave-uniform: the global head still has entries
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  // this wave's slice of the queue
-  const unsigned long long wave = ((unsigned long long) blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const unsigned long long n_waves = ((unsigned long long) gridDim.x * BLOCK) >> 6;
-  uint32_t next = (uint32_t) ((unsigned long long) n * wave / n_waves);
-  const uint32_t range_end = (uint32_t) ((unsigned long long) n * (wave + 1) / n_waves);
-
+  // work distribution: waves claim TRAV_GRAB consecutive queue entries at a time
+  // from a global head (one atomic per 1024 rays).  Static per-wave slices were
+  // measurably worse: neighbouring rays have correlated cost, so whole slices
+  // end up cheap or expensive and the slowest wave sets the kernel time.
+  uint32_t next = 0, range_end = 0;        // wave-uniform
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), winv = o, oo = o, od = o, inv = o, d = o;
@@ -193,13 +197,21 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, uint32_t n, ui
   for (;;) {
     // ---- refill idle lanes from the wave's slice
     const unsigned long long idle = __ballot(!have);
+    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
+      base = __shfl(base, 0);
+      if (base >= n) head_live = false;
+      else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
+    }
     if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
       if (!have) {
         const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
         if (my < range_end) {
           RayIn r;
-          pol.fetch(my, &r);
-          have = true; idx = my;
+          r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = 0; r.group = 0; r.anyhit = false;
+          have = pol.fetch(my, &r);
+          idx = my;
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
           const DGroup G = S.groups[r.group];
@@ -210,7 +222,10 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, uint32_t n, ui
         }
       }
       next += (uint32_t) __popcll(idle);
-      if (__ballot(have) == 0ull) break;
+      if (__ballot(have) == 0ull) {
+        if (next >= range_end && !head_live) break;
+        continue;               // only padding slots were fetched / slice exhausted: claim more
+      }
     }
 
     // ---- lanes between instances: enter the next instance or retire the ray
@@ -295,13 +310,14 @@ struct ClosestPolicy {
   const DPath *paths;
   DHit *hits;
   int default_group;
-  __device__ void fetch(uint32_t i, RayIn *r) const
+  __device__ bool fetch(uint32_t i, RayIn *r) const
   {
     const DRay q = rays[i];
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = q.tmin; r->tmax = q.tmax;
     r->group = paths ? paths[i].group : default_group;
     r->anyhit = false;
+    return true;
   }
   __device__ void finish(uint32_t i, const Best &b) const
   {
@@ -312,13 +328,13 @@ struct ClosestPolicy {
 };
 
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
-    DHit *hits, uint32_t n, DCounters *cnt, int count_events)
+    DHit *hits, uint32_t n, DCounters *cnt, int count_events, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
   ClosestPolicy pol;
   pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent(S, pol, n, s_stack + threadIdx.x, &lc);
+  traverse_persistent(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -713,19 +729,31 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
 // k_shadow_trace: the compact queue only, so every lane of a wave is
 // traversing (no lanes idling while a neighbour walks the BLAS).  Adds
 // c * (1 - Os_occluder) to the sample, or c when the ray reaches the light.
+#define SQ_CHUNK 256u          // shadow-queue slots a wave reserves per global atomic
+#define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
+
 __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   unsigned long long c_insts = 0, c_shadow = 0;
+  const unsigned lane = __lane_id();
   const uint32_t n = rec_end - rec_begin;
-  const unsigned long long total = (unsigned long long) n * sp.lanes;
-  // every lane of a wave runs the same number of iterations (see k_shadow_trace note)
-  const unsigned long long total_pad = (total + 63ull) & ~63ull;
-  for (unsigned long long gtid = (unsigned long long) blockIdx.x * BLOCK + threadIdx.x; gtid < total_pad;
-       gtid += (unsigned long long) gridDim.x * BLOCK) {
-    const uint32_t rec = rec_begin + (uint32_t) (gtid / sp.lanes);
-    const uint32_t sub = (uint32_t) (gtid % sp.lanes);
-    const bool active = rec < rec_end;
+  // each wave owns a contiguous slice of the records, so the rays it emits --
+  // and the shadow-queue chunks it fills -- stay spatially coherent
+  const unsigned long long wave = ((unsigned long long) blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const unsigned long long n_waves = ((unsigned long long) gridDim.x * BLOCK) >> 6;
+  const uint32_t recs_per_iter = 64u / sp.lanes;
+  const uint32_t slice_begin = (uint32_t) ((unsigned long long) n * wave / n_waves);
+  const uint32_t slice_end = (uint32_t) ((unsigned long long) n * (wave + 1) / n_waves);
+  // queue space is reserved SQ_CHUNK slots at a time: one atomic per 1024 rays
+  // instead of one per wave iteration (a single-address atomic per iteration
+  // serialised the whole kernel in L2)
+  uint32_t chunk_base = 0, chunk_used = SQ_CHUNK;   // wave-uniform; "used == CHUNK" = no chunk yet
+
+  for (uint32_t r0 = slice_begin; r0 < slice_end; r0 += recs_per_iter) {
+    const uint32_t rec = rec_begin + r0 + lane / sp.lanes;
+    const uint32_t sub = lane % sp.lanes;
+    const bool active = (r0 + lane / sp.lanes) < slice_end;
 
     float sum[3] = {0.f, 0.f, 0.f};
     uint32_t r_sample = 0;
@@ -795,10 +823,26 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
           }
         }
       }
-      const uint32_t slot = wave_append(emit, &cnt->shadow_count, nullptr);
-      if (emit) {
-        if (slot < sp.queue_capacity) squeue[slot] = q;
-        else cnt->overflow = 1;
+      // ---- compaction into the wave's current chunk (ballot + prefix popcount)
+      const unsigned long long mask = __ballot(emit);
+      const uint32_t need = (uint32_t) __popcll(mask);
+      if (need) {
+        if (chunk_used + need > SQ_CHUNK) {
+          // retire the chunk: mark its unused tail as padding, reserve a new one
+          if (chunk_used < SQ_CHUNK)
+            for (uint32_t k = chunk_used + lane; k < SQ_CHUNK; k += 64)
+              if (chunk_base + k < sp.queue_capacity) squeue[chunk_base + k].sample = SQ_INVALID;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&cnt->shadow_count, SQ_CHUNK);
+          chunk_base = __shfl(base, 0);
+          chunk_used = 0;
+        }
+        if (emit) {
+          const uint32_t slot = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+          if (slot < sp.queue_capacity) squeue[slot] = q;
+          else cnt->overflow = 1;
+        }
+        chunk_used += need;
       }
     }
     // butterfly reduction inside the lane segment (all 64 lanes participate)
@@ -809,12 +853,16 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     }
     if (active && sub == 0) {
       float *acc = s_accum + 4 * (size_t) r_sample;
-      const float r0 = W[0] * sum[0], r1 = W[1] * sum[1], r2 = W[2] * sum[2];
-      if (r0 != 0.f) atomicAdd(acc + 0, r0);
-      if (r1 != 0.f) atomicAdd(acc + 1, r1);
-      if (r2 != 0.f) atomicAdd(acc + 2, r2);
+      const float r0v = W[0] * sum[0], r1v = W[1] * sum[1], r2v = W[2] * sum[2];
+      if (r0v != 0.f) atomicAdd(acc + 0, r0v);
+      if (r1v != 0.f) atomicAdd(acc + 1, r1v);
+      if (r2v != 0.f) atomicAdd(acc + 2, r2v);
     }
   }
+  // pad the tail of the last chunk
+  if (chunk_used < SQ_CHUNK)
+    for (uint32_t k = chunk_used + lane; k < SQ_CHUNK; k += 64)
+      if (chunk_base + k < sp.queue_capacity) squeue[chunk_base + k].sample = SQ_INVALID;
   flush_counters(cnt, 0, 0, count_events ? c_insts : 0, count_events ? c_shadow : 0, c_shadow);
 }
 
@@ -822,13 +870,15 @@ struct ShadowPolicy {
   const DScene *S;
   const DShadowRay *squeue;
   float *s_accum;
-  __device__ void fetch(uint32_t i, RayIn *r) const
+  __device__ bool fetch(uint32_t i, RayIn *r) const
   {
     const DShadowRay q = squeue[i];
+    if (q.sample == SQ_INVALID) return false;      // padding slot of a partially filled chunk
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = .0001; r->tmax = q.tmax;
     r->group = q.group;
     r->anyhit = S->groups[q.group].all_opaque != 0;
+    return true;
   }
   __device__ void finish(uint32_t i, const Best &b) const
   {
@@ -858,14 +908,14 @@ struct ShadowPolicy {
 };
 
 __global__ void __launch_bounds__(BLOCK) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
-    DCounters *cnt, int count_events)
+    DCounters *cnt, int count_events, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent(S, pol, n, s_stack + threadIdx.x, &lc);
+  traverse_persistent(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -925,6 +975,22 @@ static unsigned persistent_grid(unsigned long long blocks_needed)
   return (unsigned) (blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap);
 }
 
+static TravTune trav_tune()
+{
+  static TravTune t = {0, 0, 0};
+  if (t.grab == 0) {
+    auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
+    t.refill = env("FJGPU_TRAV_REFILL", 16);
+    t.steps = env("FJGPU_TRAV_STEPS", 6);
+    t.grab = env("FJGPU_TRAV_GRAB", 128);
+    if (t.refill < 1) t.refill = 1;
+    if (t.refill > 64) t.refill = 64;
+    if (t.steps < 1) t.steps = 1;
+    if (t.grab < 64) t.grab = 64;
+  }
+  return t;
+}
+
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
 
 int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, const TileDesc *d_tiles, int n_tiles,
@@ -940,7 +1006,8 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_trace_closest, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events);
+  (void) hipMemsetAsync(&cnt->trace_head, 0, sizeof(uint32_t), st);
+  hipLaunchKernelGGL(k_trace_closest, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
   LAUNCH_CHECK();
   return 0;
 }
@@ -962,17 +1029,19 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
   // records are processed in chunks whose worst case (every pair survives the cull)
   // fits the shadow-ray queue; the trace stage reads the queue length on the device
   const uint32_t nl = (uint32_t) (S.n_light_samples > 0 ? S.n_light_samples : 1);
-  uint32_t chunk = sp.queue_capacity / nl;
+  // every resident wave may leave one partially filled (padded) chunk behind
+  const uint32_t pad = persistent_grid(1ull << 30) * (BLOCK / 64) * SQ_CHUNK;
+  uint32_t chunk = (sp.queue_capacity > pad ? sp.queue_capacity - pad : 0) / nl;
   if (chunk == 0) chunk = 1;
   for (uint32_t b = 0; b < n; b += chunk) {
     const uint32_t e = (n - b < chunk) ? n : b + chunk;
-    (void) hipMemsetAsync(&cnt->shadow_count, 0, sizeof(uint32_t), st);
+    (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + trace_head
     const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
     hipLaunchKernelGGL(k_shadow_cull, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
         S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_shadow_trace, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-        S, (const DShadowRay *) squeue, s_accum, cnt, count_events);
+        S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
     LAUNCH_CHECK();
   }
   return 0;

@@ -143,7 +143,9 @@ struct DCounters {
   uint32_t next_count;         // entries appended to the next ray queue
   uint32_t light_count;        // entries appended to the light-record queue
   uint32_t overflow;
-  uint32_t shadow_count;       // entries appended to the shadow-ray queue (was: work head)
+  uint32_t shadow_count;       // slots reserved in the shadow-ray queue
+  uint32_t trace_head;         // persistent traversal: next unclaimed queue index
+  uint32_t pad_[3];
 };
 
 #endif
