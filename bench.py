@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument("--mesh", default=None, help="mesh class override (smaller = quicker; not a valid headline run)")
     ap.add_argument("--res", type=int, nargs=2, default=None)
     ap.add_argument("--spp", type=int, nargs=2, default=None)
-    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-tiles", type=int, default=-1,
+                    help="tiles in the CPU-baseline sample (-1: two per host core so every core stays busy; 0 disables)")
     ap.add_argument("--batch-tiles", type=int, default=0)
     return ap.parse_args()
 
@@ -91,7 +92,8 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
             with open(tmp + ".fjfb", "rb") as f:
                 head = f.read(24)
             seconds = struct.unpack("<d", head[16:24])[0]
-            return {"value": sample_rays / seconds / 1e6, "unit": "Mray/s", "cores": os.cpu_count() or 1,
+            return {"value": sample_rays / seconds / 1e6, "unit": "Mray/s",
+                    "cores": min(os.cpu_count() or 1, len(sample_ids)), "host_cores": os.cpu_count() or 1,
                     "kind": "reference", "sample": desc, "seconds": seconds, "rays": int(sample_rays)}
         except Exception as e:  # fall through to the port
             sys.stderr.write("cpu_baseline: reference run failed (%s); using the CPU restatement\n" % e)
@@ -223,12 +225,17 @@ def main():
                                                "resolve": s0.resolve_ms, "total": s0.total_ms}},
             "roofline": roof,
         }
-        if world == 1 and args.cpu_tiles > 0:
-            # bounded CPU sample: a block of tiles in the middle of the frame
+        if world == 1 and args.cpu_tiles != 0:
+            # bounded CPU sample: a block of tiles in the middle of the frame, two tiles per
+            # host core (the reference hands whole tiles to its worker threads)
             nx = -(-render.xres // render.tile_w)
             ny = -(-render.yres // render.tile_h)
-            bw = max(1, min(nx, 4))
-            bh = max(1, min(ny, -(-args.cpu_tiles // bw)))
+            # (capped at 64 tiles: the reference's per-ray heap traffic makes it scale badly past
+            # that many threads -- 512 tiles took 142 s on the 256-core host of the GPU box)
+            want = args.cpu_tiles if args.cpu_tiles > 0 else min(2 * (os.cpu_count() or 1), 64)
+            want = max(1, min(want, nx * ny))
+            bw = max(1, min(nx, 32, want))
+            bh = max(1, min(ny, -(-want // bw)))
             x0, y0 = (nx - bw) // 2, (ny - bh) // 2
             sample = [(y0 + j) * nx + (x0 + i) for j in range(bh) for i in range(bw)]
             sfb = torch.zeros_like(fb)
