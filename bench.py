@@ -215,7 +215,8 @@ def main():
             "config": {"workload": "%s-class scene, %dx%d, %dx%d spp, tile %dx%d, %d tiles, 32 point lights"
                                    % (args.workload, render.xres, render.yres, render.rate_x, render.rate_y,
                                       render.tile_w, render.tile_h, n_tiles),
-                       "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot"}[args.workload],
+                       "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot",
+                                             "furry": "furbunny"}.get(args.workload, args.workload),
                        "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
                        "prepare_seconds": prep_seconds,
                        "counters_last_frame_rank0": {"nodes": int(s0.nodes_visited), "prims": int(s0.prims_tested),

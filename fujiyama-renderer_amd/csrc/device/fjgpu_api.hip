@@ -121,8 +121,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   if (be) return fail(be, err);
   for (int i = 0; i < desc->n_shaders; i++) {
     const int t = desc->shaders[i].type;
-    if (t == FJ_SHADER_HAIR || t == FJ_SHADER_PATHTRACING)
-      return fail(FJGPU_EUNSUPPORTED, "HairShader / PathtracingShader are not on the device path yet");
+    if (t == FJ_SHADER_PATHTRACING)
+      return fail(FJGPU_EUNSUPPORTED, "PathtracingShader is not on the device path yet");
   }
 
   int ndev = 0;
@@ -152,6 +152,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     d.root = h.root;
     d.n_prims = h.n_prims;
     std::memcpy(d.bounds, h.bounds, sizeof(d.bounds));
+    for (int k = 0; k < 3; k++) { d.grid_cell[k] = h.grid_cell[k]; d.grid_n[k] = h.grid_n[k]; }
     e |= M.upload(h.nodes.data(), h.nodes.size(), &d.nodes);
     e |= M.upload(h.prim_ids.data(), h.prim_ids.size(), &d.prim_ids);
     if (h.type == FJ_PRIMSET_MESH) {

@@ -26,8 +26,6 @@ namespace {
 
 const double ACC_PADDING = .0001;     // Accelerator PADDING, src/fj_accelerator.cc:13
 
-struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
-
 // f64 -> f32 rounded toward -inf / +inf, then one extra ulp outward
 inline float down2(double v)
 {
@@ -159,7 +157,12 @@ struct Builder {
   }
 };
 
-void build_blas(HostPrimSet *ps, std::vector<PrimRef> &refs)
+}  // namespace
+
+float RoundDown2(double v) { return down2(v); }
+float RoundUp2(double v) { return up2(v); }
+
+void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
 {
   Builder b;
   b.prims.swap(refs);
@@ -182,6 +185,8 @@ void build_blas(HostPrimSet *ps, std::vector<PrimRef> &refs)
   ps->n_prims = n;
 }
 
+namespace {
+
 int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
 {
   ps->type = FJ_PRIMSET_MESH;
@@ -202,7 +207,8 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
     for (int c = 0; c < 3; c++) { r.bmin[c] = down2(mn[c]); r.bmax[c] = up2(mx[c]); r.c[c] = (float) (.5 * (mn[c] + mx[c])); }
     r.id = (uint32_t) f;
   }
-  build_blas(ps, refs);
+  for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
+  BuildBlas(ps, refs);
   ps->tri_verts.resize((size_t) ps->n_prims * 9);
   for (int i = 0; i < ps->n_prims; i++) {
     const int f = (int) ps->prim_ids[i];

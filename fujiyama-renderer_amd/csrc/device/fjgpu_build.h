@@ -21,6 +21,8 @@ struct HostPrimSet {
   std::vector<int8_t> curve_depth;    // [n]
   uint32_t root;
   double bounds[6];
+  double grid_cell[3];
+  int grid_n[3];
   int n_prims;
   int max_depth;
   const fj_mesh_desc *mesh;
@@ -39,6 +41,12 @@ struct HostScene {
   double cam_M[12];
   double cam_fov, cam_znear, cam_zfar;
 };
+
+// BLAS build over arbitrary primitive boxes (meshes and curve sets share it)
+struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
+void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs);
+float RoundDown2(double v);   // f64 -> f32 toward -inf, one more ulp outward
+float RoundUp2(double v);
 
 // returns 0 or a negative FJGPU_E* code with *err set
 int BuildHostScene(const fj_scene_desc *desc, HostScene *out, std::string *err);

@@ -56,6 +56,8 @@ __device__ __forceinline__ V3 xvector(const double *m, V3 v)
             m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
 
+__device__ __forceinline__ double clampd(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
+
 // ------------------------------------------------------------ culling tests
 // Conservative slab test (culling only).  NaN from 0 * inf is ignored by
 // fmin/fmax, which return the non-NaN operand.
@@ -144,6 +146,190 @@ __device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long lon
     if (traced) atomicAdd(&cnt->traced, traced);
     if (shadow) atomicAdd(&cnt->rays[CXT_SHADOW_RAY], shadow);
   }
+}
+
+// --------------------------------------------------------- curve test (a23)
+// Curve::ray_intersect + converge_bezier3, reference src/fj_curve.cc:187-232,300-390
+// (Nakamaru-Ono subdivision in ray space).  The reference recurses with a
+// Bezier3 per level; here every leaf segment is re-derived from the root by
+// the same sequence of split_bezier3 calls (identical arithmetic, no per-lane
+// stack of control points), and subtrees whose ancestor fails the reference's
+// bounds test are skipped.  Children of a node start from a fresh "no hit"
+// (t = REAL_MAX) in the reference, so nothing is pruned by depth; the combine
+// rule `t_left < t_right ? left : right` selects the RIGHTMOST leaf among those
+// with the smallest z, which is what `z <= best` in a left-to-right sweep does.
+struct Bz { V3 c0, c1, c2, c3; double w0, w1; };
+
+__device__ __forceinline__ V3 bez_eval(const Bz &b, double t)       // eval_bezier3, :464-472
+{
+  const double u = 1 - t;
+  const double a = u * u * u;
+  const double bb = 3 * u * u * t;
+  const double c = 3 * u * t * t;
+  const double d = t * t * t;
+  return a * b.c0 + bb * b.c1 + c * b.c2 + d * b.c3;
+}
+__device__ __forceinline__ V3 mid_point(V3 a, V3 b) { return (a + b) * .5; }
+__device__ __forceinline__ double dmax(double x, double y) { return x > y ? x : y; }   // Max, src/fj_numeric.h
+__device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : y; }
+__device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
+
+__device__ bool curve_ray(const double *cpw, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+{
+  // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
+  const double ray_scale = sqrt(dot(od, od));
+  const double sinv = 1. / ray_scale;
+  const V3 nd = od * sinv;
+  // compute_world_to_ray_matrix, :268-295: dst = rotate * translate
+  const double lx = nd.x, ly = nd.y, lz = nd.z;
+  const double d = sqrt(lx * lx + lz * lz);
+  const double d_inv = 1. / d;
+  const V3 r0 = mk(lz * d_inv, 0, -lx * d_inv);
+  const V3 r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
+  const V3 r2 = mk(lx, ly, lz);
+  const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
+  const double m03 = r0.x * nox + r0.y * noy + r0.z * noz;
+  const double m13 = r1.x * nox + r1.y * noy + r1.z * noz;
+  const double m23 = r2.x * nox + r2.y * noy + r2.z * noz;
+  Bz root;
+  {
+    V3 p[4];
+    for (int k = 0; k < 4; k++) {
+      const V3 q = ld3(cpw + 3 * k);
+      p[k] = mk(r0.x * q.x + r0.y * q.y + r0.z * q.z + m03,
+                r1.x * q.x + r1.y * q.y + r1.z * q.z + m13,
+                r2.x * q.x + r2.y * q.y + r2.z * q.z + m23);
+    }
+    root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
+    root.w0 = w0; root.w1 = w1;
+  }
+  double best_z = DBL_MAX, best_v = DBL_MAX;
+  bool any = false;
+  const uint32_t nleaf = 1u << depth;
+  uint32_t j = 0;
+  while (j < nleaf) {
+    Bz b = root;
+    double v0 = 0, vn = 1;
+    bool pruned = false;
+    for (int L = 0;; L++) {
+      // converge_bezier3 entry test: get_bezier3_bounds (cp bounds +- max radius)
+      const double radius = .5 * dmax(b.w0, b.w1);
+      const double mnx = dmin(dmin(dmin(b.c0.x, b.c1.x), b.c2.x), b.c3.x) - radius;
+      const double mxx = dmax(dmax(dmax(b.c0.x, b.c1.x), b.c2.x), b.c3.x) + radius;
+      const double mny = dmin(dmin(dmin(b.c0.y, b.c1.y), b.c2.y), b.c3.y) - radius;
+      const double mxy = dmax(dmax(dmax(b.c0.y, b.c1.y), b.c2.y), b.c3.y) + radius;
+      const double mxz = dmax(dmax(dmax(b.c0.z, b.c1.z), b.c2.z), b.c3.z) + radius;
+      if (mnx >= radius || mxx <= -radius || mny >= radius || mxy <= -radius || mxz <= 1e-6) {
+        const uint32_t span = 1u << (depth - L);
+        j = ((j / span) + 1) * span;
+        pruned = true;
+        break;
+      }
+      if (L == depth) break;
+      // split_bezier3, :488-508, keeping the half selected by bit (depth-L-1) of j
+      const V3 midP = bez_eval(b, .5);
+      const V3 midCP = mid_point(b.c1, b.c2);
+      const double vm = (v0 + vn) * .5;
+      const double wm = (b.w0 + b.w1) * .5;
+      if (((j >> (depth - L - 1)) & 1u) == 0) {
+        const V3 l1 = mid_point(b.c0, b.c1);
+        const V3 l2 = mid_point(l1, midCP);
+        b.c1 = l1; b.c2 = l2; b.c3 = midP;
+        b.w1 = wm;
+        vn = vm;
+      } else {
+        const V3 q2 = mid_point(b.c3, b.c2);
+        const V3 q1 = mid_point(q2, midCP);
+        b.c0 = midP; b.c1 = q1; b.c2 = q2;
+        b.w0 = wm;
+        v0 = vm;
+      }
+    }
+    if (pruned) continue;
+    j++;
+    // depth == 0 block of converge_bezier3
+    const V3 dir = b.c3 - b.c0;
+    V3 dP0 = b.c1 - b.c0;
+    if (dot_xy(dir, dP0) < 0) dP0 = dP0 * -1;
+    if (-1 * dot_xy(dP0, b.c0) < 0) continue;
+    V3 dPn = b.c3 - b.c2;
+    if (dot_xy(dir, dPn) < 0) dPn = dPn * -1;
+    if (dot_xy(dPn, b.c3) < 0) continue;
+    double w = dir.x * dir.x + dir.y * dir.y;
+    if (fabs(w) < 1e-6) continue;
+    w = -(b.c0.x * dir.x + b.c0.y * dir.y) / w;
+    w = clampd(w, 0, 1);
+    const double v = v0 * (1 - w) + vn * w;
+    const double radius_w = .5 * ((1 - w) * b.w0 + w * b.w1);
+    const V3 vP = bez_eval(b, w);
+    if (vP.x * vP.x + vP.y * vP.y >= radius_w * radius_w) continue;
+    if (vP.z <= 1e-6) continue;
+    if (vP.z <= best_z) { best_z = vP.z; best_v = v; any = true; }
+  }
+  if (!any) return false;
+  *t_out = best_z / ray_scale;
+  *v_out = best_v;
+  return true;
+}
+
+// The reference's GridAccelerator accepts a primitive hit only when the hit point
+// lies inside the cell being walked (src/fj_grid_accelerator.cc:253-260), and a curve
+// is listed in a cell only if one of its 32 depth-5 sub-segments' control-point boxes
+// overlaps the cell (Curve::box_intersect, src/fj_curve.cc:234-242,399-462) -- WITHOUT
+// the ribbon radius.  A ribbon hit whose ray point falls in a neighbouring cell that
+// does not list the curve is therefore rejected by the reference.  The same rule is
+// applied here so the two renderers see the same fur.
+__device__ bool curve_listed_in_cell_of(const DPrimSet *P, const double *cpw, V3 hitp)
+{
+  int ci[3];
+  double cmin[3], cmax[3];
+  const double hp[3] = {hitp.x, hitp.y, hitp.z};
+  for (int a = 0; a < 3; a++) {
+    int c = (int) floor((hp[a] - P->bounds[a]) / P->grid_cell[a]);
+    c = c < 0 ? 0 : (c > P->grid_n[a] - 1 ? P->grid_n[a] - 1 : c);
+    ci[a] = c;
+    cmin[a] = P->bounds[a] + (double) c * P->grid_cell[a];       // get_grid_cell, :334-343
+    cmax[a] = cmin[a] + P->grid_cell[a];
+    if (hp[a] < cmin[a] || cmax[a] < hp[a]) return false;        // Box::ContainsPoint (inclusive)
+  }
+  (void) ci;
+  // box_bezier3_intersect_recursive(cell, bezier, 5) with zero velocity
+  const V3 r0 = ld3(cpw), r1 = ld3(cpw + 3), r2 = ld3(cpw + 6), r3 = ld3(cpw + 9);
+  const uint32_t depth = 5, nleaf = 32;
+  uint32_t j = 0;
+  while (j < nleaf) {
+    V3 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+    bool pruned = false;
+    for (uint32_t L = 0;; L++) {
+      // AABB of the control polygon vs the cell (BoxBoxIntersect, inclusive).  Inner
+      // levels are tested too: a sub-segment's control points stay inside the parent's hull
+      const double mn[3] = {dmin(dmin(dmin(c0.x, c1.x), c2.x), c3.x), dmin(dmin(dmin(c0.y, c1.y), c2.y), c3.y), dmin(dmin(dmin(c0.z, c1.z), c2.z), c3.z)};
+      const double mx[3] = {dmax(dmax(dmax(c0.x, c1.x), c2.x), c3.x), dmax(dmax(dmax(c0.y, c1.y), c2.y), c3.y), dmax(dmax(dmax(c0.z, c1.z), c2.z), c3.z)};
+      const bool overlap = !(mx[0] < cmin[0] || mn[0] > cmax[0] || mx[1] < cmin[1] || mn[1] > cmax[1] || mx[2] < cmin[2] || mn[2] > cmax[2]);
+      if (!overlap) {
+        const uint32_t span = 1u << (depth - L);
+        j = ((j / span) + 1) * span;
+        pruned = true;
+        break;
+      }
+      if (L == depth) return true;
+      Bz b;
+      b.c0 = c0; b.c1 = c1; b.c2 = c2; b.c3 = c3; b.w0 = b.w1 = 0;
+      const V3 midP = bez_eval(b, .5);
+      const V3 midCP = mid_point(c1, c2);
+      if (((j >> (depth - L - 1)) & 1u) == 0) {
+        const V3 l1 = mid_point(c0, c1);
+        const V3 l2 = mid_point(l1, midCP);
+        c1 = l1; c2 = l2; c3 = midP;
+      } else {
+        const V3 q2 = mid_point(c3, c2);
+        const V3 q1 = mid_point(q2, midCP);
+        c0 = midP; c1 = q1; c2 = q2;
+      }
+    }
+    if (!pruned) j++;
+  }
+  return false;
 }
 
 // ----------------------------------------------------- persistent traversal
@@ -286,11 +472,21 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const uint32_t first = (cur & 0x7fffffffu) >> 3;
       const uint32_t cnt = (cur & 7u) + 1;
       bool stop = false;
+      const bool is_curve = P->type == FJ_PRIMSET_CURVE;
       for (uint32_t k = 0; k < cnt; k++) {
-        const double *vp = P->tri_verts + (size_t) (first + k) * 9;
-        double t, u, v;
+        double t, u = 0, v = 0;
         lc->prims++;
-        if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+        if (is_curve) {
+          // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
+          const size_t sl = first + k;
+          if (!curve_ray(P->curve_cp + sl * 12, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
+                         (int) P->curve_depth[sl], oo, od, &t, &u)) continue;
+          if (!curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
+          v = (double) sl;
+        } else {
+          const double *vp = P->tri_verts + (size_t) (first + k) * 9;
+          if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+        }
         if (!(tmin <= t && t <= tmax)) continue;
         const int pid = (int) P->prim_ids[first + k];
         if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
@@ -391,7 +587,6 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
 }
 
 // -------------------------------------------------------------------- shading
-__device__ __forceinline__ double clampd(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
 
 // Texture::Lookup, src/fj_texture.cc:51-78 + MipInput::ReadTile clamp (src/fj_mipmap.cc:153-170)
 __device__ void tex_lookup(const DTexture &tex, float u, float v, float out[4])
@@ -556,33 +751,56 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     const DPrimSet *P = &S.primsets[I->primset];
     const V3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = mk(r.d[0], r.d[1], r.d[2]);
 
-    // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
     const V3 oo = xpoint(I->Minv, ro);
     const V3 od = xvector(I->Minv, rd);
-    const int32_t *ix = P->indices + 3 * (size_t) h.prim;
-    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
-    V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
-    if (P->N) { n0 = ld3(P->N + 3 * (size_t) i0); n1 = ld3(P->N + 3 * (size_t) i1); n2 = ld3(P->N + 3 * (size_t) i2); }
-    V3 N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;          // TriComputeNormal, src/fj_triangle.cc:44-49
+    V3 N = mk(0, 0, 0);
     float tu = 0.f, tv = 0.f;
     V3 dPdu = mk(0, 0, 0), dPdv = mk(0, 0, 0);
-    const bool has_uv = P->uv != nullptr;
+    float Cd[3] = {1.f, 1.f, 1.f};                                // Intersection default
+    bool has_uv = false;
     float t0u = 0, t0v = 0, t1u = 0, t1v = 0, t2u = 0, t2v = 0;
-    if (has_uv) {
-      t0u = P->uv[2 * (size_t) i0]; t0v = P->uv[2 * (size_t) i0 + 1];
-      t1u = P->uv[2 * (size_t) i1]; t1v = P->uv[2 * (size_t) i1 + 1];
-      t2u = P->uv[2 * (size_t) i2]; t2v = P->uv[2 * (size_t) i2 + 1];
-      const float tt = (float) (1 - h.u - h.v);                  // f32 barycentric, src/fj_mesh.cc:285
-      tu = (float) (tt * t0u + h.u * t1u + h.v * t2u);
-      tv = (float) (tt * t0v + h.u * t1v + h.v * t2v);
+    int i0 = 0, i1 = 0, i2 = 0;
+    int sg = 0;
+    if (P->type == FJ_PRIMSET_CURVE) {
+      // --- Curve::ray_intersect attribute part (src/fj_curve.cc:211-229): dPdv = curve
+      // derivative at v_hit, Cd = lerp of the end colours; N / uv / dPdu stay zero
+      const size_t sl = (size_t) h.v;
+      const double vhit = h.u;
+      const double *cp = P->curve_cp + sl * 12;
+      const V3 c0 = ld3(cp), c1 = ld3(cp + 3), c2 = ld3(cp + 6), c3 = ld3(cp + 9);
+      const double uu = 1 - vhit;
+      const double da = 2 * uu * uu, db = 4 * uu * vhit, dc = 2 * vhit * vhit;
+      dPdv = da * (c1 - c0) + db * (c2 - c1) + dc * (c3 - c2);   // derivative_bezier3, :474-486
+      const float tl = (float) vhit;
+      const float *cd = P->curve_Cd + sl * 6;
+      Cd[0] = (1 - tl) * cd[0] + tl * cd[3];
+      Cd[1] = (1 - tl) * cd[1] + tl * cd[4];
+      Cd[2] = (1 - tl) * cd[2] + tl * cd[5];
+    } else {
+      // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
+      const int32_t *ix = P->indices + 3 * (size_t) h.prim;
+      i0 = ix[0]; i1 = ix[1]; i2 = ix[2];
+      V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
+      if (P->N) { n0 = ld3(P->N + 3 * (size_t) i0); n1 = ld3(P->N + 3 * (size_t) i1); n2 = ld3(P->N + 3 * (size_t) i2); }
+      N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;            // TriComputeNormal, src/fj_triangle.cc:44-49
+      has_uv = P->uv != nullptr;
+      if (has_uv) {
+        t0u = P->uv[2 * (size_t) i0]; t0v = P->uv[2 * (size_t) i0 + 1];
+        t1u = P->uv[2 * (size_t) i1]; t1v = P->uv[2 * (size_t) i1 + 1];
+        t2u = P->uv[2 * (size_t) i2]; t2v = P->uv[2 * (size_t) i2 + 1];
+        const float tt = (float) (1 - h.u - h.v);                  // f32 barycentric, src/fj_mesh.cc:285
+        tu = (float) (tt * t0u + h.u * t1u + h.v * t2u);
+        tv = (float) (tt * t0v + h.u * t1v + h.v * t2v);
+      }
+      sg = P->face_group ? P->face_group[h.prim] : 0;
     }
     V3 Pw = oo + h.t * od;                                        // RayPointAt in object space
     // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)
     Pw = xpoint(I->M, Pw);
     N = normalize(xvector(I->M, N));
+    dPdv = xvector(I->M, dPdv);
 
     // --- shader lookup: ObjectInstance::GetShader (src/fj_object_instance.cc:177-191)
-    const int sg = P->face_group ? P->face_group[h.prim] : 0;
     int sid;
     if (sg < 0 || sg >= I->n_shaders) sid = I->shaders[0];
     else { sid = I->shaders[sg]; if (sid < 0) sid = I->shaders[0]; }
@@ -626,7 +844,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
               dPdv = ((double) (-du2) * dP1 + (double) du1 * dP2) * (double) invdet;
             }
             dPdu = xvector(I->M, dPdu);
-            dPdv = xvector(I->M, dPdv);
+            dPdv = xvector(I->M, dPdv);   // (mesh dPdv is zero until here)
           }
           Nf = bump_mapping(S.textures[sh->bump_map], dPdu, dPdv, tu, tv, (double) sh->bump_amplitude, Nf);
         }
@@ -688,8 +906,27 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
         Os = 1.f;
         break;
       }
+      case FJ_SHADER_HAIR: {       // hair_shader.cc:87-117: Kajiya-Kay over all light samples
+        add_cs = false;
+        if (S.n_light_samples > 0) {
+          const V3 tangent = normalize(dPdv);
+          want_light = true;
+          lr.P[0] = Pw.x; lr.P[1] = Pw.y; lr.P[2] = Pw.z;
+          lr.N[0] = N.x; lr.N[1] = N.y; lr.N[2] = N.z;     // illuminance axis = in.N (zero for curves)
+          lr.aux[0] = tangent.x; lr.aux[1] = tangent.y; lr.aux[2] = tangent.z;
+          lr.aux[3] = Iw.x; lr.aux[4] = Iw.y; lr.aux[5] = Iw.z;
+          lr.W[0] = p.T[0]; lr.W[1] = p.T[1]; lr.W[2] = p.T[2];
+          lr.Cd[0] = Cd[0] * sh->diffuse[0]; lr.Cd[1] = Cd[1] * sh->diffuse[1]; lr.Cd[2] = Cd[2] * sh->diffuse[2];
+          lr.sample = sample;
+          lr.group = I->shadow_target;
+          lr.kind = 1;
+          lr.cxt = p.cxt;
+        }
+        Os = 1.f;
+        break;
+      }
       default:
-        // hair / pathtracing need curve primitives / per-path RNG: rejected at scene creation
+        // pathtracing needs the per-path RNG contract: rejected at scene creation
         add_cs = false;
         break;
       }
@@ -796,6 +1033,19 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             float Kd = (float) dot(axis, Ln);
             Kd = (float) (Kd > 0 ? (double) Kd : 0.);
             k[0] = Kd * Cl[0]; k[1] = Kd * Cl[1]; k[2] = Kd * Cl[2];
+          } else {                       // hair_shader.cc:184-206 (the plugin's sqrt / pow are the C
+                                         // library's double versions on float arguments)
+            const V3 tangent = mk(R.aux[0], R.aux[1], R.aux[2]);
+            const V3 Iv = mk(R.aux[3], R.aux[4], R.aux[5]);
+            const float TL = (float) dot(tangent, Ln);
+            const float diff = (float) sqrt((double) (1 - TL * TL));
+            const float roughness = .05f;
+            const float TI = (float) dot(tangent, Iv);
+            float spec = (float) (sqrt((double) (1 - TL * TL)) * sqrt((double) (1 - TI * TI)) + (double) (TL * TI));
+            spec = (float) pow((double) spec, (double) (1 / roughness));
+            k[0] = (R.Cd[0] * diff + spec) * Cl[0];
+            k[1] = (R.Cd[1] * diff + spec) * Cl[1];
+            k[2] = (R.Cd[2] * diff + spec) * Cl[2];
           }
           bool maybe_occluded = false;
           if (sp.cast_shadow) {

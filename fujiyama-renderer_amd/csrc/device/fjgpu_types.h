@@ -40,6 +40,12 @@ struct DPrimSet {
   const float *curve_Cd;       // [n_curves][6]  end colours (BLAS order)
   const int8_t *curve_depth;   // [n_curves]     cached split depth (BLAS order)
   double bounds[6];            // Accelerator::bounds_ = primset bounds + 1e-4 (object space)
+  // curves only: geometry of the reference's uniform grid (origin = bounds min, cell size,
+  // cell counts); needed to reproduce its "hit point must lie in a cell that lists the
+  // primitive" acceptance rule for ribbons
+  double grid_cell[3];
+  int32_t grid_n[3];
+  int32_t pad2;
   uint32_t root;               // child ref of the root
   int32_t type;                // FJ_PRIMSET_*
   int32_t n_prims;

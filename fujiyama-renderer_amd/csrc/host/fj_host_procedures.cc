@@ -202,13 +202,6 @@ int RunProcedure(Scene *sc, Procedure *proc, std::string *err)
   return -1;
 }
 
-// CurveGeneratorProcedure is restated with the curve primitives (config 5)
-int RunCurveGenerator(Scene *, Procedure *, std::string *err)
-{
-  *err = "CurveGeneratorProcedure: not available yet";
-  return -1;
-}
-
 // Dome light importance sampling (Light::Preprocess for DomeLight,
 // reference src/fj_dome_light.cc:58-97) -- restated with config 6 (IBL).
 int PreprocessDomeLight(Scene *, Light *)

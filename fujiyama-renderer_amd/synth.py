@@ -60,7 +60,7 @@ def write_ply(path, verts, faces_quads=None, faces_tris=None, uv=None):
             rec.tofile(f)
 
 
-def bumpy_sphere(nu, nv, seed=SEED, bumps=12, amp=0.18):
+def bumpy_sphere(nu, nv, seed=SEED, bumps=12, amp=0.18, radius=1.0):
     """Closed genus-0 surface r(theta,phi) = 1 + sum a_k sin(f_k theta + p_k) sin(g_k phi)^2...
 
     nu segments around (periodic), nv segments pole to pole; poles are single
@@ -87,6 +87,8 @@ def bumpy_sphere(nu, nv, seed=SEED, bumps=12, amp=0.18):
     ring = np.stack([x, y, z], axis=-1).reshape(-1, 3)
     verts = np.concatenate([[[0.0, 1.0, 0.0]], ring, [[0.0, -1.0, 0.0]]], axis=0)
     verts[:, 1] -= verts[:, 1].min()
+    if radius != 1.0:
+        verts *= radius
 
     nr = nv - 1
     idx = 1 + np.arange(nr * nu).reshape(nr, nu)
@@ -176,6 +178,10 @@ MESH_CLASSES = {
     "teapot": (56, 57),        # 6 272
     "tiny": (12, 9),           # 192 (unit tests)
     "small": (100, 101),       # 20 000 (golden traversal vectors)
+    # furred meshes (config 5): CurveGeneratorProcedure grows int(1e5 * area) curves per face,
+    # so the curve count is set by the surface area, i.e. by the radius
+    "furbunny": (186, 188, 0.5),   # 69 564 tris, area ~3.3  -> ~330 k curves
+    "furball": (24, 17, 0.12),     # 768 tris,    area ~0.19 -> ~19 k curves (tests)
 }
 
 
@@ -186,8 +192,8 @@ def ensure_assets(root, meshes=("teapot",), textures=True):
     for name in meshes:
         path = os.path.join(root, "%s.ply" % name)
         if not os.path.exists(path):
-            nu, nv = MESH_CLASSES[name]
-            v, q, t = bumpy_sphere(nu, nv, seed=SEED + len(name))
+            cls = MESH_CLASSES[name]
+            v, q, t = bumpy_sphere(cls[0], cls[1], seed=SEED + len(name), radius=cls[2] if len(cls) > 2 else 1.0)
             write_ply(path + ".tmp", v, faces_quads=q, faces_tris=t)
             os.replace(path + ".tmp", path)
         out[name] = path

@@ -158,7 +158,47 @@ def dragon(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="dragon", nlights=32, e
     return si.text()
 
 
-BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon}
+def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=()):
+    """C5: fur (cubic Bezier curves + HairShader) grown on a mesh by
+    CurveGeneratorProcedure; plastic mesh and floor without reflection (furry_bunny.scn)."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("hair_shader", "HairShader")
+    si.OpenPlugin("curve_generator_procedure", "CurveGeneratorProcedure")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 1.6, .8, 1.8)
+    si.SetProperty3("cam1", "rotate", -8.0494669755283983, 45, 0)
+    point_lights(si, nlights)
+    si.NewShader("curve_shader", "hair_shader")
+    si.NewShader("bunny_shader", "plastic_shader")
+    si.SetProperty3("bunny_shader", "diffuse", .8, .5, .3)
+    si.SetProperty3("bunny_shader", "reflect", 0, 0, 0)
+    si.NewCurve("curve_data")
+    _ply(si, "bunny_mesh", a[mesh])
+    si.NewProcedure("bunny_hair_gen", "curve_generator_procedure")
+    si.AssignMesh("bunny_hair_gen", "mesh", "bunny_mesh")
+    si.AssignCurve("bunny_hair_gen", "curve", "curve_data")
+    si.RunProcedure("bunny_hair_gen")
+    si.NewObjectInstance("bunny1", "bunny_mesh")
+    si.AssignShader("bunny1", "DEFAULT_SHADING_GROUP", "bunny_shader")
+    _stage(si, a, floor_translate=(3, 0, 3))
+    si.SetProperty3("floor_shader", "diffuse", .3, .35, .4)
+    si.SetProperty3("floor_shader", "reflect", 0, 0, 0)
+    si.NewObjectInstance("curve1", "curve_data")
+    si.AssignShader("curve1", "DEFAULT_SHADING_GROUP", "curve_shader")
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "bunny1")
+    si.AddObjectToGroup("group1", "curve1")
+    for o in ("bunny1", "curve1", "floor1"):
+        si.AssignObjectGroup(o, "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry}
 
 
 def default_asset_dir():

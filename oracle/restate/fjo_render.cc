@@ -456,8 +456,35 @@ static int SlTrace(RenderState *rs, const Cxt &cxt, const V3 &orig, const V3 &di
   return 1;
 }
 
-// TODO(round 1, later today): hair + pathtracing shaders (a28, a29)
-static void HairEvaluate(RenderState *, const fj_shader_desc &, const Cxt &, const SurfIn &, SurfOut *out) { out->Cs = Col(); out->Os = 1; }
+// shaders/hair_shader/hair_shader.cc:87-117,184-206 (Kajiya-Kay; tangent = dPdv;
+// the illuminance axis is in.N, which Curve::ray_intersect leaves at zero, so the
+// cone test against cos(PI) always passes)
+static void HairEvaluate(RenderState *rs, const fj_shader_desc &sh, const Cxt &cxt, const SurfIn &in, SurfOut *out)
+{
+  out->Cs = Col();
+  const std::vector<LightSample> &samples = rs->sc->light_samples;
+  for (size_t i = 0; i < samples.size(); i++) {
+    LightOut L;
+    L.Cl = Col(); L.Ln = V3(); L.distance = 0;
+    Illuminance(rs, cxt, samples[i], in.P, in.N, rs->cos_pi, in, &L);
+    const V3 tangent = Normalize(in.dPdv);
+    // kajiya_diffuse / kajiya_specular
+    const float TL = Dot(tangent, L.Ln);
+    // the plugin calls the C library's double sqrt / pow on float arguments
+    // (hair_shader.cc includes no <cmath>): products and the sum are formed in f64
+    const float diff = ::sqrt((double) (1 - TL * TL));
+    const float roughness = .05;
+    const float TI = Dot(tangent, in.I);
+    float spec = ::sqrt((double) (1 - TL * TL)) * ::sqrt((double) (1 - TI * TI)) + TL * TI;
+    spec = ::pow((double) spec, (double) (1 / roughness));
+    out->Cs.r += (in.Cd.r * sh.diffuse[0] * diff + spec) * L.Cl.r;
+    out->Cs.g += (in.Cd.g * sh.diffuse[1] * diff + spec) * L.Cl.g;
+    out->Cs.b += (in.Cd.b * sh.diffuse[2] * diff + spec) * L.Cl.b;
+  }
+  out->Os = 1;
+}
+
+// TODO: PathtracingShader (a29) needs the counter-based RNG contract
 static void PathtracingEvaluate(RenderState *, const fj_shader_desc &, const Cxt &, const SurfIn &, SurfOut *out) { out->Cs = Col(); out->Os = 1; }
 
 // =============================================================== light samples

@@ -42,7 +42,12 @@ def check(which, res, spp, **kw):
 
 if __name__ == "__main__":
     print("devices:", gpu.device_count())
+    if len(sys.argv) > 1 and sys.argv[1] == "furry":
+        check("furry", (64, 48), (2, 2), mesh="furball", nlights=4); check("furry", (160, 120), (3, 3), mesh="furball"); sys.exit(0)
     check("teapot", (64, 64), (2, 2))
     check("teapot", (256, 256), (1, 1))
     check("buddhas", (160, 90), (2, 2), mesh="bunny")
     check("dragon", (160, 90), (3, 3), mesh="small")
+
+def check_furry():
+    check("furry", (64, 48), (2, 2), mesh="furball", nlights=4)

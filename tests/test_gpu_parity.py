@@ -50,6 +50,7 @@ CASES = {
     "teapot_64_2spp": ("teapot", dict(res=(64, 64), spp=(2, 2))),
     "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
     "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
+    "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
     "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
                                   extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
                                          ("filterwidth", (3, 2.5))))),
@@ -107,6 +108,34 @@ def test_trace_groups_bit_exact_against_oracle(builder, kw, asset_dir):
         assert np.array_equal(t, to), group
         assert np.array_equal(ids, io), group
         assert (io[:, 0] >= 0).mean() > 0.02
+    gs.close()
+    osc.close()
+
+
+def test_curve_trace_bit_exact_against_oracle(asset_dir):
+    """C5 primitives: Bezier ribbons (Nakamaru-Ono subdivision) incl. the reference grid's
+    cell-listing acceptance rule; t and instance bit-exact (the reference leaves prim_id of a
+    curve hit at 0, so primitive ids are compared for mesh hits only)"""
+    sp, _ = prepare(workloads.furry(asset_dir, res=(32, 24), spp=(1, 1), mesh="furball", nlights=1))
+    rng = np.random.RandomState(9)
+    n = 40000
+    o = rng.normal(size=(n, 3)) * .4 + [0.3, .25, .3]
+    tgt = rng.normal(size=(n, 3)) * .07 + [0, .12, 0]
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d, np.full((n, 1), 1e-4), np.full((n, 1), 1000.)], axis=1)
+    gs = gpu.Scene(sp)
+    osc = oracle_ffi.OracleScene(sp)
+    for group in (0, 1):
+        t, ids, uv, _ = gs.trace(group, rays)
+        to, io, _ = osc.trace(group, rays)
+        assert np.array_equal(t, to), group
+        assert np.array_equal(ids[:, 0], io[:, 0]), group
+    curve_inst = 3                                   # bunny1, floor1, dome1, curve1
+    hits_curve = (io[:, 0] == curve_inst)
+    assert hits_curve.sum() > 500
+    mesh_hit = (io[:, 0] >= 0) & ~hits_curve
+    assert np.array_equal(ids[mesh_hit, 1], io[mesh_hit, 1])
     gs.close()
     osc.close()
 
