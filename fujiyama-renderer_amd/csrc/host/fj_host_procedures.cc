@@ -202,14 +202,6 @@ int RunProcedure(Scene *sc, Procedure *proc, std::string *err)
   return -1;
 }
 
-// Dome light importance sampling (Light::Preprocess for DomeLight,
-// reference src/fj_dome_light.cc:58-97) -- restated with config 6 (IBL).
-int PreprocessDomeLight(Scene *, Light *)
-{
-  g_last_error = "DomeLight: importance sampling preprocess not available yet";
-  return -1;
-}
-
 // .fb writer: the reference's plain-text PTO format, src/fj_framebuffer_io.cc:46-68
 int WriteFrameBuffer(const std::string &filename, const fj::FrameBuffer &fb)
 {

@@ -198,7 +198,69 @@ def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, 
     return si.text()
 
 
-BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry}
+def ibl(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="buddha", sample_count=256, extra=()):
+    """Image-based lighting check (scenes/dome_light1.py): one DomeLight with an environment
+    map (stratified importance samples, deterministic), a plastic object, a mirror-like and a
+    diffuse ball, the dome mirrored by a negative scale, an EMPTY shadow group for the balls
+    and per-object reflect groups."""
+    a = synth.ensure_assets(asset_dir, (mesh, "tiny"))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetSampleProperty3("cam1", "translate", 0, 1, 8.5, 0)
+    rot = 110
+    si.NewLight("light1", "DomeLight")
+    si.SetProperty3("light1", "rotate", 0, rot, 0)
+    si.SetProperty1("light1", "sample_count", sample_count)
+    si.NewTexture("tex1", a["sky"])
+    si.AssignTexture("light1", "environment_map", "tex1")
+    si.NewShader("happy_shader", "plastic_shader")
+    si.SetProperty3("happy_shader", "diffuse", .8, .8, .8)
+    si.NewShader("dome_shader", "constant_shader")
+    si.AssignTexture("dome_shader", "texture", "tex1")
+    si.NewShader("sphere_shader1", "plastic_shader")
+    si.SetProperty3("sphere_shader1", "diffuse", 0, 0, 0)
+    si.SetProperty1("sphere_shader1", "ior", 40)
+    si.NewShader("sphere_shader2", "plastic_shader")
+    si.SetProperty3("sphere_shader2", "diffuse", .5, .5, .5)
+    si.SetProperty3("sphere_shader2", "reflect", 0, 0, 0)
+    _ply(si, "happy_mesh", a[mesh])
+    _ply(si, "dome_mesh", a["dome"])
+    _ply(si, "sphere_mesh", a["tiny"])
+    si.NewObjectInstance("happy1", "happy_mesh")
+    si.AssignShader("happy1", "DEFAULT_SHADING_GROUP", "happy_shader")
+    si.NewObjectInstance("dome1", "dome_mesh")
+    si.SetProperty3("dome1", "rotate", 0, rot, 0)
+    si.SetProperty3("dome1", "scale", -.5, .5, .5)
+    si.AssignShader("dome1", "DEFAULT_SHADING_GROUP", "dome_shader")
+    si.NewObjectInstance("sphere1", "sphere_mesh")
+    si.AssignShader("sphere1", "DEFAULT_SHADING_GROUP", "sphere_shader1")
+    si.SetProperty3("sphere1", "translate", -1.5, -.5, 0)
+    si.SetProperty3("sphere1", "scale", .5, .5, .5)
+    si.NewObjectInstance("sphere2", "sphere_mesh")
+    si.AssignShader("sphere2", "DEFAULT_SHADING_GROUP", "sphere_shader2")
+    si.SetProperty3("sphere2", "translate", 1.5, -.5, 0)
+    si.SetProperty3("sphere2", "scale", .5, .5, .5)
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "happy1")
+    si.AssignObjectGroup("happy1", "shadow_target", "group1")
+    si.NewObjectGroup("group2")
+    si.AssignObjectGroup("sphere1", "shadow_target", "group2")
+    si.AssignObjectGroup("sphere2", "shadow_target", "group2")
+    si.NewObjectGroup("group3")
+    si.AddObjectToGroup("group3", "dome1")
+    si.AssignObjectGroup("sphere1", "reflect_target", "group3")
+    si.NewObjectGroup("group4")
+    si.AddObjectToGroup("group4", "dome1")
+    si.AddObjectToGroup("group4", "happy1")
+    si.AssignObjectGroup("happy1", "reflect_target", "group4")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl}
 
 
 def default_asset_dir():

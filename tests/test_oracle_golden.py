@@ -238,6 +238,7 @@ FRAME_CASES = {
     "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
     "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
     "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
+    "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
     "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
                                   extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
                                          ("filterwidth", (3, 2.5))))),
