@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -69,8 +70,9 @@ struct fjgpu_scene {
   size_t work_samples, work_rays;
   double *d_suv;
   float *d_accum;
-  DRay *d_rays[2];
-  DPath *d_paths[2];
+  struct Level { DRay *rays; DPath *paths; size_t cap; };
+  std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
+  int max_children;                // most child rays one shading event can emit in this scene
   DHit *d_hits;
   DLightRec *d_lrecs;
   DShadowRay *d_squeue;
@@ -121,8 +123,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   if (be) return fail(be, err);
   for (int i = 0; i < desc->n_shaders; i++) {
     const int t = desc->shaders[i].type;
-    if (t == FJ_SHADER_PATHTRACING)
-      return fail(FJGPU_EUNSUPPORTED, "PathtracingShader is not on the device path yet");
+    (void) t;
   }
 
   int ndev = 0;
@@ -192,12 +193,24 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.n_instances = (int) hs.instances.size();
   S.n_groups = (int) hs.groups.size();
   S.n_primsets = (int) hs.primsets.size();
+  S.has_curves = 0;
+  for (const auto &ps : hs.primsets) if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) S.has_curves = 1;
   S.target_group = hs.target_group;
   std::memcpy(S.cam_M, hs.cam_M, sizeof(S.cam_M));
   S.cam_znear = hs.cam_znear;
   S.cam_zfar = hs.cam_zfar;
   sc->cam_fov = hs.cam_fov;
   sc->n_light_samples = S.n_light_samples;
+  sc->max_children = 0;
+  for (int i = 0; i < desc->n_shaders; i++) {
+    const fj_shader_desc &sh = desc->shaders[i];
+    auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
+    int k = 0;
+    if (sh.type == FJ_SHADER_PLASTIC) k = sh.do_reflect ? 1 : 0;
+    else if (sh.type == FJ_SHADER_GLASS) k = 2;
+    else if (sh.type == FJ_SHADER_PATHTRACING) k = (int) lum(sh.diffuse) + (int) lum(sh.reflect) + (int) lum(sh.refract);
+    sc->max_children = std::max(sc->max_children, k);
+  }
   HIP_TRY(hipDeviceSynchronize());
   *out = sc.release();
   return 0;
@@ -235,7 +248,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     int e = 0;
     e |= W.alloc(samples * 2, &sc->d_suv);
     e |= W.alloc(samples * 4, &sc->d_accum);
-    for (int k = 0; k < 2; k++) { e |= W.alloc(rays, &sc->d_rays[k]); e |= W.alloc(rays, &sc->d_paths[k]); }
+    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
     e |= W.alloc(rays, &sc->d_hits);
     e |= W.alloc(rays, &sc->d_lrecs);
     sc->squeue_cap = std::min<size_t>(rays * 8, (size_t) 24 << 20) + 4096 * 1024;   // + one chunk per resident wave
@@ -253,6 +266,16 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     if (sc->mem.upload(draws.data(), tab_len, const_cast<const double **>(&sc->d_tim))) return -1;
     sc->tab_len = tab_len;
   }
+  return 0;
+}
+
+int ensure_level(fjgpu_scene *sc, int level, size_t cap)
+{
+  fjgpu_scene::Level &L = sc->levels[level];
+  if (L.cap >= cap) return 0;
+  DeviceBuffers &W = *sc->work;
+  if (W.alloc(cap, &L.rays) || W.alloc(cap, &L.paths)) return -1;   // older, smaller buffers stay owned by `work`
+  L.cap = cap;
   return 0;
 }
 
@@ -290,7 +313,12 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   if (bt < 1) bt = 1;
   const size_t cap_samples = full_tile_samples * (size_t) bt;
   const size_t cap_rays = cap_samples * 2 + 1024;
-  if (ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples))
+  // one queue per recursion level: camera + every diffuse / reflect / refract bounce
+  {
+    const size_t nlev = 2 + (size_t) std::max(0, r->max_diffuse_depth) + std::max(0, r->max_reflect_depth) + std::max(0, r->max_refract_depth);
+    if (sc->levels.size() < nlev) sc->levels.resize(nlev, fjgpu_scene::Level{nullptr, nullptr, 0});
+  }
+  if (ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) || ensure_level(sc, 0, cap_rays))
     return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
 
   // camera (Renderer::preprocess_camera + Camera::compute_uv_size)
@@ -365,39 +393,55 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
 
     rc = timed(&acc.gen_ms, [&]() {
-      return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->d_rays[0], sc->d_paths[0]);
+      return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->levels[0].rays, sc->levels[0].paths);
     });
     if (rc) break;
     acc.rays.camera += n_samples;
 
-    uint32_t count = n_samples;
-    int cur = 0;
-    for (int level = 0; count > 0 && rc == 0 && level < 64; level++) {
-      rc = timed(&acc.trace_ms, [&]() {
-        return launch_trace_closest(st, S, sc->d_rays[cur], sc->d_paths[cur], sc->d_hits, count, sc->d_cnt, (int) sc->count_events);
-      });
-      if (rc) break;
-      acc.trace_launches++;
-      rc = timed(&acc.shade_ms, [&]() {
-        return launch_shade(st, S, shp, sc->d_rays[cur], sc->d_paths[cur], sc->d_hits, count, sc->d_accum,
-            sc->d_rays[1 - cur], sc->d_paths[1 - cur], sc->d_lrecs, sc->d_cnt);
-      });
-      if (rc) break;
-      DCounters hc;
-      if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
-      if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); break; }
-      if (hc.light_count) {
-        rc = timed(&acc.trace_ms, [&]() {
-          return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
+    // Depth-first wavefront schedule: the rays of one recursion level live in that
+    // level's queue; a level is consumed in chunks small enough that the children a
+    // chunk can emit (max_children per ray) fit the next level's queue, and that
+    // queue is drained completely before the next chunk is taken.  Memory is bounded
+    // by levels x capacity whatever the branching of the shaders (glass: 2 children,
+    // pathtracing: up to 3), while plastic-only scenes run whole levels at once.
+    std::function<int(int, uint32_t)> process = [&](int level, uint32_t count) -> int {
+      if (level + 1 >= (int) sc->levels.size()) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
+      if (ensure_level(sc, level + 1, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for a ray queue level");
+      const uint32_t kids = (uint32_t) std::max(1, sc->max_children);
+      const uint32_t chunk_max = kids <= 1 ? count : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
+      for (uint32_t off = 0; off < count; off += chunk_max) {
+        const uint32_t n = std::min(chunk_max, count - off);
+        const DRay *rays = sc->levels[level].rays + off;
+        const DPath *paths = sc->levels[level].paths + off;
+        (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
+        int e = timed(&acc.trace_ms, [&]() {
+          return launch_trace_closest(st, S, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
         });
-        if (rc) break;
+        if (e) return e;
         acc.trace_launches++;
+        e = timed(&acc.shade_ms, [&]() {
+          return launch_shade(st, S, shp, rays, paths, sc->d_hits, n, sc->d_accum,
+              sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_lrecs, sc->d_cnt);
+        });
+        if (e) return e;
+        DCounters hc;
+        if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (hc.overflow) return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option");
+        if (hc.light_count) {
+          e = timed(&acc.trace_ms, [&]() {
+            return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
+          });
+          if (e) return e;
+          acc.trace_launches++;
+        }
+        if (hc.next_count) {
+          e = process(level + 1, hc.next_count);
+          if (e) return e;
+        }
       }
-      count = hc.next_count;
-      // reset the queue heads for the next level
-      (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);
-      cur = 1 - cur;
-    }
+      return 0;
+    };
+    rc = process(0, n_samples);
     if (rc) break;
 
     rc = timed(&acc.resolve_ms, [&]() {

@@ -259,12 +259,17 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
       if (s.primset < 0 || s.primset >= d->n_curves) { *err = "instance curve index out of range"; return FJGPU_EINVAL; }
       o.primset = d->n_meshes + s.primset;
     } else { *err = "unknown primitive set type"; return FJGPU_EINVAL; }
-    TransformBounds(M, out->primsets[o.primset].bounds, o.wbounds);
-    // widen the culling box by a relative epsilon: it must contain every point
-    // M * (o' + t d') the object-space test can report
-    for (int k = 0; k < 3; k++) {
-      const double pad = 1e-9 * (std::fabs(o.wbounds[k]) + std::fabs(o.wbounds[3 + k]) + 1);
-      o.wbounds[k] -= pad; o.wbounds[3 + k] += pad;
+    // ObjectInstance::merge_sampled_bounds (reference src/fj_object_instance.cc:313-356): the
+    // world box is built from T, R and the ABSOLUTE scale.  With a negative scale it is
+    // mirrored and no longer encloses the geometry -- and the reference's instance BVH
+    // culls with it, so rays that miss this box miss the instance there.  The device tests
+    // the same box with the same BoxRayIntersect arithmetic.
+    {
+      fj_xform_desc ax = x;
+      for (int k = 0; k < 3; k++) ax.scale[0].v[k] = std::fabs(x.scale[0].v[k]);
+      double Ma[16], Mai[16];
+      MakeTransform(ax, 0, Ma, Mai);
+      TransformBounds(Ma, out->primsets[o.primset].bounds, o.wbounds);
     }
     o.n_shaders = s.n_shaders;
     for (int k = 0; k < FJ_MAX_SHADING_GROUPS; k++) {
@@ -290,6 +295,7 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
     G.count = d->groups[g].n_instances;
     G.all_opaque = 1;
     G.pad = 0;
+    for (int k = 0; k < 6; k++) G.sbounds[k] = 0;
     for (int k = 0; k < G.count; k++) {
       const int inst = d->groups[g].instances[k];
       if (inst < 0 || inst >= d->n_instances) { *err = "group instance index out of range"; return FJGPU_EINVAL; }
@@ -301,6 +307,15 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
         if (sid >= 0 && d->shaders[sid].type == FJ_SHADER_PLASTIC && d->shaders[sid].opacity < 1.f) G.all_opaque = 0;
       }
     }
+  }
+  // Accelerator::ComputeBounds of a group: ObjectSet bounds + PADDING.  Only needed for
+  // single-instance groups, where the instance BVH's root is the leaf and the group box is
+  // the only world-space test the reference makes.
+  for (int g = 0; g < d->n_groups; g++) {
+    DGroup &G = out->groups[g];
+    if (G.count != 1) continue;
+    const DInstance &I = out->instances[out->group_instances[G.first]];
+    for (int k = 0; k < 3; k++) { G.sbounds[k] = I.wbounds[k] - ACC_PADDING; G.sbounds[3 + k] = I.wbounds[3 + k] + ACC_PADDING; }
   }
   if (d->target_group < 0 || d->target_group >= d->n_groups) { *err = "renderer target group out of range"; return FJGPU_EINVAL; }
   out->target_group = d->target_group;

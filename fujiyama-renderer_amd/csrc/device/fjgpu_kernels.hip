@@ -92,6 +92,48 @@ __device__ __forceinline__ bool has_negative_zero(V3 d)
   return (d.x == 0 && signbit(d.x)) || (d.y == 0 && signbit(d.y)) || (d.z == 0 && signbit(d.z));
 }
 
+// BoxRayIntersect, reference src/fj_box.cc:73-138, operation for operation.  Used where
+// the reference's own box decides the RESULT (instance bounds, which are not always
+// conservative -- see fjgpu_build.cc), as opposed to pure culling.
+__device__ __noinline__ bool box_ray_ref(const double *b, V3 o, V3 d, double ray_tmin, double ray_tmax)
+{
+  double tmin, tmax, tymin, tymax, tzmin, tzmax;
+  if (d.x >= 0) { tmin = (b[0] - o.x) / d.x; tmax = (b[3] - o.x) / d.x; }
+  else          { tmin = (b[3] - o.x) / d.x; tmax = (b[0] - o.x) / d.x; }
+  if (d.y >= 0) { tymin = (b[1] - o.y) / d.y; tymax = (b[4] - o.y) / d.y; }
+  else          { tymin = (b[4] - o.y) / d.y; tymax = (b[1] - o.y) / d.y; }
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  if (d.z >= 0) { tzmin = (b[2] - o.z) / d.z; tzmax = (b[5] - o.z) / d.z; }
+  else          { tzmin = (b[5] - o.z) / d.z; tzmax = (b[2] - o.z) / d.z; }
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  return (tmin < ray_tmax) && (tmax > ray_tmin);
+}
+
+// Same decision as box_ray_ref at a fraction of the cost: the slab interval from the
+// per-ray reciprocal differs from the reference's divisions by a few ulp, so it settles
+// every case that is not within 1e-12 (relative) of a boundary; the rest -- and anything
+// involving NaN / inf -- takes the exact path.
+__device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3 inv, double ray_tmin, double ray_tmax)
+{
+  const double x0 = (b[0] - o.x) * inv.x, x1 = (b[3] - o.x) * inv.x;
+  const double y0 = (b[1] - o.y) * inv.y, y1 = (b[4] - o.y) * inv.y;
+  const double z0 = (b[2] - o.z) * inv.z, z1 = (b[5] - o.z) * inv.z;
+  const double lx = fmin(x0, x1), hx = fmax(x0, x1), ly = fmin(y0, y1), hy = fmax(y0, y1);
+  const double lz = fmin(z0, z1), hz = fmax(z0, z1);
+  const double lo = fmax(fmax(lx, ly), lz), hi = fmin(fmin(hx, hy), hz);
+  const double sum = ((x0 + x1) + (y0 + y1)) + (z0 + z1);        // NaN / inf detector
+  const double m = 1e-12 * fmax(fmax(fabs(lo), fabs(hi)), fmax(fabs(ray_tmin), fmin(fabs(ray_tmax), 1e300)));
+  if (sum - sum == 0. && m < 1e300) {
+    if (hi - lo > m && ray_tmax - lo > m && hi - ray_tmin > m) return true;
+    if (lo - hi > m || lo - ray_tmax > m || ray_tmin - hi > m) return false;
+  }
+  return box_ray_ref(b, o, d, ray_tmin, ray_tmax);
+}
+
 // ------------------------------------------------------- triangle test (a21)
 // TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
 // EPSILON 1e-6 (:12); no t-sign test here -- the range test is the caller's
@@ -357,7 +399,7 @@ struct TravTune { uint32_t refill, steps, grab; };
 
 struct RayIn { V3 o, d; double tmin, tmax; int group; bool anyhit; };
 
-template <class Policy>
+template <bool kCurves, class Policy>
 __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, uint32_t *stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
@@ -370,11 +412,12 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   uint32_t next = 0, range_end = 0;        // wave-uniform
   bool have = false;
   uint32_t idx = 0;
-  V3 o = mk(0, 0, 0), winv = o, oo = o, od = o, inv = o, d = o;
+  V3 o = mk(0, 0, 0), oo = o, od = o, inv = o, d = o, winv = o;
   double tmin = 0, tmax = 0;
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
   int gfirst = 0, gcount = 0, gi = 0, ii = -1;
+  const double *gsb = nullptr;
   bool anyhit = false, dead_ray = false;
   const DPrimSet *P = nullptr;
   uint32_t cur = TRAV_DONE;
@@ -399,12 +442,13 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           have = pol.fetch(my, &r);
           idx = my;
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
-          winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
           const DGroup G = S.groups[r.group];
           gfirst = G.first; gcount = G.count; gi = 0;
+          gsb = S.groups[r.group].sbounds;
           best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
           cur = TRAV_DONE; sp = 0;
           dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
+          winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
         }
       }
       next += (uint32_t) __popcll(idle);
@@ -424,7 +468,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         lc->insts++;
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
-        if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
+        // the reference's own (possibly non-enclosing) instance box, full ray range
+        if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, tmin, tmax)) continue;
         oo = xpoint(I->Minv, o);
         od = xvector(I->Minv, d);
         if (has_negative_zero(od)) continue;
@@ -472,11 +517,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const uint32_t first = (cur & 0x7fffffffu) >> 3;
       const uint32_t cnt = (cur & 7u) + 1;
       bool stop = false;
-      const bool is_curve = P->type == FJ_PRIMSET_CURVE;
+      const bool is_curve = kCurves && P->type == FJ_PRIMSET_CURVE;
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u = 0, v = 0;
         lc->prims++;
-        if (is_curve) {
+        if (kCurves && is_curve) {
           // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
           const size_t sl = first + k;
           if (!curve_ray(P->curve_cp + sl * 12, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
@@ -523,6 +568,7 @@ struct ClosestPolicy {
   }
 };
 
+template <bool kCurves>
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, int count_events, TravTune tune)
 {
@@ -530,7 +576,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *r
   ClosestPolicy pol;
   pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
+  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -582,7 +628,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
   p.group = S.target_group;
   p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
-  p.flags = 0; p.rng = 0; p.pad = 0;
+  p.flags = 0; p.rng = 0; p.uid = ((uint32_t) T.id << 20) + k;
   paths[slot] = p;
 }
 
@@ -647,6 +693,29 @@ __device__ V3 refract(V3 I, V3 N, double ior)        // SlRefract, :100-138
 
 __device__ __forceinline__ float luminance4(const float c[4]) { return (float) (.298912 * c[0] + .586611 * c[1] + .114478 * c[2]); }
 
+__device__ __forceinline__ float luminance3(const float c[3]) { return (float) (.298912 * c[0] + .586611 * c[1] + .114478 * c[2]); }
+
+// Counter-based RNG contract of the pathtracing path: the reference's
+// seeded XorShift (src/fj_random.cc:18-43) with seed = mix(sample uid, path key), four
+// warm-up draws, then the two numbers of the diffuse bounce.
+__device__ void pt_draw2(uint32_t uid, uint32_t key, double *x1, double *x2)
+{
+  uint32_t h = uid * 0x9E3779B1u ^ (key + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  uint32_t st[4];
+  uint32_t seed = h;
+  for (uint32_t i = 0; i < 4; i++) st[i] = seed = 1812433253U * (seed ^ (seed >> 30)) + i;
+  double out[2] = {0, 0};
+  for (int i = 0; i < 6; i++) {
+    const uint32_t t = st[0] ^ (st[0] << 11);
+    st[0] = st[1]; st[1] = st[2]; st[2] = st[3];
+    st[3] = (st[3] ^ (st[3] >> 19)) ^ (t ^ (t >> 8));
+    if (i >= 4) out[i - 4] = (double) st[3] / 4294967295u;
+  }
+  *x1 = out[0];
+  *x2 = out[1];
+}
+
 // SlBumpMapping, src/fj_shading.cc:418-464
 __device__ V3 bump_mapping(const DTexture &bump, V3 dPdu, V3 dPdv, float tu, float tv, double amplitude, V3 N)
 {
@@ -699,7 +768,7 @@ struct ChildRay {
 
 // `cxt` is uniform per call site (reflect / refract / diffuse children are
 // emitted by separate calls), so the per-context ray count is one atomic per wave
-__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t rng,
+__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t key,
     DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity)
 {
   const uint32_t slot = wave_append(c.want, &cnt->next_count, &cnt->rays[cxt]);
@@ -716,7 +785,7 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
   p.cxt = (uint8_t) cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
   p.group = c.group;
   p.fc[0] = c.fc[0]; p.fc[1] = c.fc[1]; p.fc[2] = c.fc[2];
-  p.flags = c.flags; p.rng = rng; p.pad = 0;
+  p.flags = c.flags; p.rng = key; p.uid = uid;
   next_paths[slot] = p;
 }
 
@@ -736,17 +805,18 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
   if (active) h = hits[i];
   const bool hit = active && h.inst >= 0;
 
-  ChildRay c0, c1;   // up to two children (glass); plastic uses c0
-  c0.want = c1.want = false;
+  ChildRay c0, c1, c2;   // reflect, refract, diffuse children (glass: c0 + c1, plastic: c0, pathtracing: any)
+  c0.want = c1.want = c2.want = false;
   bool want_light = false;
   DLightRec lr;
-  uint32_t sample = 0, rng = 0;
+  uint32_t sample = 0, rng = 0, uid = 0;
 
   if (hit) {
     const DRay r = rays[i];
     DPath p = paths[i];
     sample = p.sample;
     rng = p.rng;
+    uid = p.uid;
     const DInstance *I = &S.instances[h.inst];
     const DPrimSet *P = &S.primsets[I->primset];
     const V3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = mk(r.d[0], r.d[1], r.d[2]);
@@ -925,8 +995,77 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
         Os = 1.f;
         break;
       }
+      case FJ_SHADER_PATHTRACING: {   // pathtracing_shader.cc:125-257 with the counter-based RNG contract
+        float Cdm[3] = {Cd[0], Cd[1], Cd[2]};
+        V3 Np = N;
+        if (sh->diffuse_map >= 0) {
+          float dm[4];
+          tex_lookup(S.textures[sh->diffuse_map], tu, tv, dm);
+          Cdm[0] *= dm[0]; Cdm[1] *= dm[1]; Cdm[2] *= dm[2];
+        }
+        if (sh->bump_map >= 0) {
+          if (has_uv) {
+            const V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            const V3 dP1 = p1 - p0, dP2 = p2 - p0;
+            const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;
+            const float determinant = du1 * dv2 - dv1 * du2;
+            if (determinant != 0) {
+              const float invdet = (float) (1. / determinant);
+              dPdu = ((double) dv2 * dP1 - (double) dv1 * dP2) * (double) invdet;
+              dPdv = ((double) (-du2) * dP1 + (double) du1 * dP2) * (double) invdet;
+            }
+            dPdu = xvector(I->M, dPdu);
+            dPdv = xvector(I->M, dPdv);
+          }
+          Np = bump_mapping(S.textures[sh->bump_map], dPdu, dPdv, tu, tv, (double) sh->bump_amplitude, N);
+        }
+        Cs[0] = sh->emission[0]; Cs[1] = sh->emission[1]; Cs[2] = sh->emission[2];   // Le, added below
+        if (luminance3(sh->diffuse) > 0.f && (int) p.ddepth + 1 <= sp.max_diffuse_depth) {   // integrate_diffuse
+          const V3 w = Np;
+          V3 u = fabs(w.x) > .001 ? mk(0, 1, 0) : mk(1, 0, 0);
+          u = normalize(cross(u, w));
+          const V3 v = cross(w, u);
+          double x1, x2;
+          pt_draw2(uid, rng, &x1, &x2);
+          const double r1 = 2. * 3.14159265358979323846 * x1;
+          const double r2 = x2;
+          const double r2sqrt = sqrt(r2);
+          const V3 D = normalize(u * cos(r1) * r2sqrt + v * sin(r1) * r2sqrt + w * sqrt(1. - r2));
+          const float kd = (float) dot(Np, D);
+          c2.want = true;
+          c2.o = Pw; c2.d = D; c2.tmin = .001; c2.tmax = 1000;
+          c2.T[0] = p.T[0] * (Cdm[0] * kd * sh->diffuse[0]);
+          c2.T[1] = p.T[1] * (Cdm[1] * kd * sh->diffuse[1]);
+          c2.T[2] = p.T[2] * (Cdm[2] * kd * sh->diffuse[2]);
+          c2.dd = p.ddepth + 1; c2.rd = p.rdepth; c2.td = p.tdepth;
+          c2.group = I->reflect_target;                              // SlDiffuseContext uses the REFLECT target
+          c2.fc[0] = c2.fc[1] = c2.fc[2] = 1.f; c2.flags = 0;
+        }
+        if (luminance3(sh->reflect) > 0.f && (int) p.rdepth + 1 <= sp.max_reflect_depth) {   // integrate_reflect
+          const float kr = (float) fresnel(Iw, Np, 1. / (double) sh->ior);
+          c0.want = true;
+          c0.o = Pw; c0.d = normalize(reflect(Iw, Np)); c0.tmin = .001; c0.tmax = 1000;
+          c0.T[0] = p.T[0] * (kr * sh->reflect[0]); c0.T[1] = p.T[1] * (kr * sh->reflect[1]); c0.T[2] = p.T[2] * (kr * sh->reflect[2]);
+          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
+          c0.group = I->reflect_target;
+          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+        }
+        if (luminance3(sh->refract) > 0.f && (int) p.tdepth + 1 <= sp.max_refract_depth) {   // integrate_refract
+          const double Kr = fresnel(Iw, Np, (double) (1 / sh->ior));      // 1/ior in f32, as in the plugin
+          const float kt = (float) (1 - Kr);
+          c1.want = true;
+          c1.o = Pw; c1.d = normalize(refract(Iw, Np, 1. / (double) sh->ior)); c1.tmin = .0001; c1.tmax = 1000;
+          c1.T[0] = p.T[0] * (kt * sh->refract[0]); c1.T[1] = p.T[1] * (kt * sh->refract[1]); c1.T[2] = p.T[2] * (kt * sh->refract[2]);
+          c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
+          c1.group = I->refract_target;
+          const bool filt = sh->do_color_filter && dot(Iw, Np) < 0;
+          c1.fc[0] = sh->filter_color[0]; c1.fc[1] = sh->filter_color[1]; c1.fc[2] = sh->filter_color[2];
+          c1.flags = filt ? 1u : 0u;
+        }
+        Os = 1.f;
+        break;
+      }
       default:
-        // pathtracing needs the per-path RNG contract: rejected at scene creation
         add_cs = false;
         break;
       }
@@ -948,8 +1087,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     if (lslot < sp.light_capacity) lrecs[lslot] = lr;
     else cnt->overflow = 1;
   }
-  emit_child(c0, CXT_REFLECT_RAY, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
-  emit_child(c1, CXT_REFRACT_RAY, sample, rng, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c0, CXT_REFLECT_RAY, sample, uid, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c1, CXT_REFRACT_RAY, sample, uid, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity);
 }
 
 // ------------------------------------------------------------------- k_shadow
@@ -1052,11 +1192,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             c_shadow++;
             // group bounds test + leaf bounds of the instance BVH, as culling
             if (!has_negative_zero(Ln)) {
-              const V3 winv = mk(1. / Ln.x, 1. / Ln.y, 1. / Ln.z);
               for (int gi = 0; gi < G.count; gi++) {
                 const DInstance *I = &S.instances[S.group_instances[G.first + gi]];
-                double tn;
-                if (slab(I->wbounds, I->wbounds + 3, Ps, winv, .0001, distance, &tn)) { maybe_occluded = true; break; }
+                if (box_ray_ref(G.count == 1 ? G.sbounds : I->wbounds, Ps, Ln, .0001, distance)) { maybe_occluded = true; break; }
                 c_insts++;
               }
             }
@@ -1157,6 +1295,7 @@ struct ShadowPolicy {
   }
 };
 
+template <bool kCurves>
 __global__ void __launch_bounds__(BLOCK) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, int count_events, TravTune tune)
 {
@@ -1165,7 +1304,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_trace(DScene S, const DShadowR
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
+  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -1257,7 +1396,11 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
 {
   if (n == 0) return 0;
   (void) hipMemsetAsync(&cnt->trace_head, 0, sizeof(uint32_t), st);
-  hipLaunchKernelGGL(k_trace_closest, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
+  // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
+  if (S.has_curves)
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
+  else
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
   LAUNCH_CHECK();
   return 0;
 }
@@ -1290,8 +1433,12 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
     hipLaunchKernelGGL(k_shadow_cull, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
         S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_shadow_trace, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-        S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
+    if (S.has_curves)
+      hipLaunchKernelGGL(k_shadow_trace<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
+    else
+      hipLaunchKernelGGL(k_shadow_trace<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
     LAUNCH_CHECK();
   }
   return 0;

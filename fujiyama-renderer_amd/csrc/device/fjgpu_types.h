@@ -57,7 +57,7 @@ struct DPrimSet {
 struct DInstance {
   double M[12];                // rows 0..2 of the 4x4 (row 3 is 0 0 0 1)
   double Minv[12];
-  double wbounds[6];           // world AABB (merge_sampled_bounds)
+  double wbounds[6];           // the REFERENCE's instance bounds (merge_sampled_bounds: |scale|!), exact
   int32_t primset;             // index into DPrimSet table
   int32_t n_shaders;
   int32_t shaders[FJ_MAX_SHADING_GROUPS];
@@ -69,6 +69,7 @@ struct DGroup {
   int32_t first, count;        // slice of the group-instance index array
   int32_t all_opaque;          // every shader reachable in the group has Os == 1 -> any-hit shadows
   int32_t pad;
+  double sbounds[6];           // single-instance group: its instance's bounds + 1e-4 (the group accelerator's box)
 };
 
 struct DTexture {
@@ -92,6 +93,7 @@ struct DScene {
   const DLightSample *light_samples;
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
+  int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
   // camera (static): eye, matrix rows, uv_size
   double cam_M[12];
@@ -113,8 +115,8 @@ struct DPath {                 // 48 B per-ray path state
   int32_t group;               // trace target group
   float fc[3];                 // pending pow(filter, t_hit) colour (glass / pathtracing refraction)
   uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit
-  uint32_t rng;                // pathtracing: per-path counter
-  uint32_t pad;
+  uint32_t rng;                // pathtracing RNG contract: path key (child k of key p = 4 p + k)
+  uint32_t uid;                // pathtracing RNG contract: tile id * 2^20 + sample index in the tile
 };
 static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
 

@@ -260,7 +260,79 @@ def ibl(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="buddha", sample_count=256
     return si.text()
 
 
-BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl}
+def cornell(asset_dir, res=(1920, 1080), spp=(16, 16), mesh="bunny", extra=(), objects=("bunny", "sphere", "happy")):
+    """C4: closed box lit by an emissive blob, PathtracingShader everywhere
+    (scenes/pathtracing.py): diffuse walls, a glass object (reflect + refract + transmit
+    filter), a rock-textured bumpy ball, a glossy diffuse+reflect object.  No lights."""
+    a = synth.ensure_assets(asset_dir, (mesh, "tiny", "small"))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("pathtracing_shader", "PathtracingShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetSampleProperty3("cam1", "translate", 0, 0.5, 1.85, 0)
+    si.SetProperty1("cam1", "fov", 40)
+    si.NewTexture("rock_tex1", a["rock"])
+    diff = .8
+    for name, col in (("floor_shader1", (diff, diff, diff)), ("ceiling_shader1", (diff, diff, diff)),
+                      ("wall_shader1", (diff, 0, 0)), ("wall_shader2", (0, diff, 0)), ("wall_shader3", (diff, diff, diff))):
+        si.NewShader(name, "pathtracing_shader")
+        si.SetProperty3(name, "diffuse", *col)
+    si.NewShader("plastic_shader1", "pathtracing_shader")
+    si.SetProperty3("plastic_shader1", "diffuse", .2, .4, .8)
+    si.SetProperty3("plastic_shader1", "reflect", 1, 1, 1)
+    si.SetProperty3("plastic_shader1", "specular", .1, .1, .1)
+    si.NewShader("textured_shader1", "pathtracing_shader")
+    si.AssignTexture("textured_shader1", "diffuse_map", "rock_tex1")
+    si.AssignTexture("textured_shader1", "bump_map", "rock_tex1")
+    si.SetProperty1("textured_shader1", "bump_amplitude", 3)
+    si.NewShader("glass_shader1", "pathtracing_shader")
+    si.SetProperty3("glass_shader1", "diffuse", 0, 0, 0)
+    si.SetProperty3("glass_shader1", "reflect", 1, 1, 1)
+    si.SetProperty3("glass_shader1", "refract", 1, 1, 1)
+    si.SetProperty3("glass_shader1", "transmit", .2, .1, .0)
+    si.NewShader("light_shader1", "pathtracing_shader")
+    si.SetProperty3("light_shader1", "diffuse", 0, 0, 0)
+    si.SetProperty3("light_shader1", "emission", 1.2 * 20, 1.1 * 20, 0.9 * 20)
+    _ply(si, "happy_mesh", a["small"])
+    _ply(si, "bunny_mesh", a[mesh])
+    _ply(si, "floor_mesh", a["floor"])
+    _ply(si, "sphere_mesh", a["dome"])          # has uv (needed by the textured / bumpy ball)
+    walls = (("floor1", "floor_shader1", None, None), ("ceiling1", "ceiling_shader1", (0, 0, 180), (0, 1, 0)),
+             ("wall1", "wall_shader1", (0, 0, -90), (-.5, .5, 0)), ("wall2", "wall_shader2", (0, 0, 90), (.5, .5, 0)),
+             ("wall3", "wall_shader3", (90, 0, 0), (0, .5, -.5)))
+    for name, shader, rotate, translate in walls:
+        si.NewObjectInstance(name, "floor_mesh")
+        si.AssignShader(name, "DEFAULT_SHADING_GROUP", shader)
+        si.SetProperty3(name, "scale", .05, .05, .05)      # floor.ply spans +-10 -> +-0.5
+        if rotate:
+            si.SetProperty3(name, "rotate", *rotate)
+        if translate:
+            si.SetProperty3(name, "translate", *translate)
+    if "bunny" in objects:
+        si.NewObjectInstance("bunny1", "bunny_mesh")
+        si.AssignShader("bunny1", "DEFAULT_SHADING_GROUP", "glass_shader1")
+        si.SetProperty3("bunny1", "translate", -.23, 0, .21)
+        si.SetProperty3("bunny1", "scale", .12, .12, .12)
+    if "sphere" in objects:
+        si.NewObjectInstance("sphere2", "sphere_mesh")
+        si.AssignShader("sphere2", "DEFAULT_SHADING_GROUP", "textured_shader1")
+        si.SetProperty3("sphere2", "translate", .3, .0, .23)
+        si.SetProperty3("sphere2", "scale", .0015, .0015, .0015)   # dome.ply hemisphere r = 100
+        si.SetProperty3("sphere2", "rotate", -15, 0, 0)
+    if "happy" in objects:
+        si.NewObjectInstance("happy1", "happy_mesh")
+        si.AssignShader("happy1", "DEFAULT_SHADING_GROUP", "plastic_shader1")
+        si.SetProperty3("happy1", "translate", .0, 0, -.1)
+        si.SetProperty3("happy1", "scale", .15, .15, .15)
+    si.NewObjectInstance("light_source1", "sphere_mesh")
+    si.AssignShader("light_source1", "DEFAULT_SHADING_GROUP", "light_shader1")
+    si.SetProperty3("light_source1", "translate", 0, 1.02, 0)
+    si.SetProperty3("light_source1", "scale", .002, -.0005, .002)  # flattened dome hanging from the ceiling
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
+BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl, "cornell": cornell}
 
 
 def default_asset_dir():

@@ -157,6 +157,9 @@ struct Cxt {
   double time;
   float opacity_threshold;
   int trace_target;       // group index
+  // counter-based RNG contract of the pathtracing restatement:
+  uint32_t sample_uid;    // tile id * 2^20 + sample index inside the tile
+  uint32_t path_key;      // 0 for the camera ray; child k of a ray with key p has 4 p + k
 };
 
 struct SurfIn {
@@ -292,17 +295,17 @@ struct SurfOut { Col Cs; float Os; };
 
 static Cxt ReflectCxt(const RenderState *rs, const Cxt &c, int obj)   // :230-240
 {
-  Cxt r = c; r.reflect_depth++; r.ray_context = CXT_REFLECT_RAY;
+  Cxt r = c; r.reflect_depth++; r.ray_context = CXT_REFLECT_RAY; r.path_key = 4 * c.path_key + 2;
   r.trace_target = rs->sc->d->instances[obj].reflect_target; return r;
 }
 static Cxt RefractCxt(const RenderState *rs, const Cxt &c, int obj)   // :242-252
 {
-  Cxt r = c; r.refract_depth++; r.ray_context = CXT_REFRACT_RAY;
+  Cxt r = c; r.refract_depth++; r.ray_context = CXT_REFRACT_RAY; r.path_key = 4 * c.path_key + 3;
   r.trace_target = rs->sc->d->instances[obj].refract_target; return r;
 }
 static Cxt DiffuseCxt(const RenderState *rs, const Cxt &c, int obj)   // :218-228 (reflect target!)
 {
-  Cxt r = c; r.diffuse_depth++; r.ray_context = CXT_DIFFUSE_RAY;
+  Cxt r = c; r.diffuse_depth++; r.ray_context = CXT_DIFFUSE_RAY; r.path_key = 4 * c.path_key + 1;
   r.trace_target = rs->sc->d->instances[obj].reflect_target; return r;
 }
 
@@ -484,8 +487,106 @@ static void HairEvaluate(RenderState *rs, const fj_shader_desc &sh, const Cxt &c
   out->Os = 1;
 }
 
-// TODO: PathtracingShader (a29) needs the counter-based RNG contract
-static void PathtracingEvaluate(RenderState *, const fj_shader_desc &, const Cxt &, const SurfIn &, SurfOut *out) { out->Cs = Col(); out->Os = 1; }
+// shaders/pathtracing_shader/pathtracing_shader.cc:125-257.
+//
+// RNG contract.  The plugin draws from `mutable XorShift rng[64]` indexed by thread id
+// (:50,186-188): its stream depends on the global shading order and is not reproducible
+// in parallel, not even by the reference itself.  This restatement -- and the
+// device path, identically -- replaces it by a counter-based stream: the two numbers of a
+// diffuse bounce come from the reference's own seeded generator XorShift(seed)
+// (src/fj_random.cc:18-24) with seed = mix(sample_uid, path_key), after four warm-up
+// draws.  Everything else (ONB, cosine-weighted direction, the extra N.D factor, Fresnel
+// weights, per-type depth limits, transmit colour filter) follows the plugin line by line.
+// Parity: GPU == this restatement (1e-4); this restatement ~ reference statistically
+// (tests/test_oracle_golden.py::test_pathtracing_matches_reference_statistically).
+static uint32_t pt_mix(uint32_t uid, uint32_t key)
+{
+  uint32_t h = uid * 0x9E3779B1u ^ (key + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+static void pt_draw2(uint32_t uid, uint32_t key, double *x1, double *x2)
+{
+  uint32_t st[4];
+  uint32_t seed = pt_mix(uid, key);
+  for (uint32_t i = 0; i < 4; i++) st[i] = seed = 1812433253U * (seed ^ (seed >> 30)) + i;   // XorShift(unsigned)
+  XorShift r;
+  for (int i = 0; i < 4; i++) r.s[i] = st[i];
+  for (int i = 0; i < 4; i++) r.NextInteger();
+  *x1 = r.NextFloat01();
+  *x2 = r.NextFloat01();
+}
+
+static float Luminance3(const float c[3]) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2]; }
+
+static void PathtracingEvaluate(RenderState *rs, const fj_shader_desc &sh, const Cxt &cxt, const SurfIn &in0, SurfOut *out)
+{
+  const fj_scene_desc *d = rs->sc->d;
+  SurfIn in = in0;
+  if (sh.diffuse_map >= 0) {
+    const Col4 c = TextureLookup(d->textures[sh.diffuse_map], in0.u, in0.v);
+    in.Cd.r *= c.r; in.Cd.g *= c.g; in.Cd.b *= c.b;
+  }
+  if (sh.bump_map >= 0)
+    in.N = BumpMapping(d->textures[sh.bump_map], in0.dPdu, in0.dPdv, in0.u, in0.v, sh.bump_amplitude, in0.N);
+
+  Col Lo(sh.emission[0], sh.emission[1], sh.emission[2]);
+
+  if (Luminance3(sh.diffuse) > 0.) {                         // integrate_diffuse, :170-203
+    const V3 w = in.N;
+    V3 u = std::abs(w.x) > .001 ? V3(0, 1, 0) : V3(1, 0, 0);
+    u = Normalize(Cross(u, w));
+    const V3 v = Cross(w, u);
+    double x1, x2;
+    pt_draw2(cxt.sample_uid, cxt.path_key, &x1, &x2);
+    const double r1 = 2. * PI * x1;
+    const double r2 = x2;
+    const double r2sqrt = std::sqrt(r2);
+    const V3 D = Normalize(u * std::cos(r1) * r2sqrt + v * std::sin(r1) * r2sqrt + w * std::sqrt(1. - r2));
+    const double Kd = Dot(in.N, D);
+    Col4 C;
+    double t_hit = REAL_MAX;
+    const Cxt dc = DiffuseCxt(rs, cxt, in.shaded_object);
+    SlTrace(rs, dc, in.P, D, .001, 1000, &C, &t_hit);
+    const float kd = Kd;                                      // Color * Real -> Color * float
+    Lo.r += in.Cd.r * kd * sh.diffuse[0] * C.r;
+    Lo.g += in.Cd.g * kd * sh.diffuse[1] * C.g;
+    Lo.b += in.Cd.b * kd * sh.diffuse[2] * C.b;
+  }
+  if (Luminance3(sh.reflect) > 0.) {                         // integrate_reflect, :205-224
+    const V3 R = Normalize(Reflect(in.I, in.N));
+    const double Kr = Fresnel(in.I, in.N, 1. / sh.ior);
+    Col4 C;
+    double t_hit = REAL_MAX;
+    const Cxt rc = ReflectCxt(rs, cxt, in.shaded_object);
+    SlTrace(rs, rc, in.P, R, .001, 1000, &C, &t_hit);
+    const float kr = Kr;
+    Lo.r += kr * sh.reflect[0] * C.r;
+    Lo.g += kr * sh.reflect[1] * C.g;
+    Lo.b += kr * sh.reflect[2] * C.b;
+  }
+  if (Luminance3(sh.refract) > 0.) {                         // integrate_refract, :226-257
+    const V3 T = Normalize(Refract(in.I, in.N, 1. / sh.ior));
+    const double Kr = Fresnel(in.I, in.N, 1 / sh.ior);       // 1/ior in f32 here, as in the plugin
+    const double Kt = 1 - Kr;
+    Col4 C;
+    double t_hit = REAL_MAX;
+    const Cxt tc = RefractCxt(rs, cxt, in.shaded_object);
+    SlTrace(rs, tc, in.P, T, .0001, 1000, &C, &t_hit);
+    if (sh.do_color_filter && Dot(in.I, in.N) < 0) {
+      C.r *= std::pow(sh.filter_color[0], t_hit);
+      C.g *= std::pow(sh.filter_color[1], t_hit);
+      C.b *= std::pow(sh.filter_color[2], t_hit);
+    }
+    const float kt = Kt;
+    Lo.r += kt * sh.refract[0] * C.r;
+    Lo.g += kt * sh.refract[1] * C.g;
+    Lo.b += kt * sh.refract[2] * C.b;
+  }
+  out->Cs = Lo;
+  out->Os = 1;
+}
 
 // =============================================================== light samples
 // SlNewLightSamples (src/fj_shading.cc:380-404) for the deterministic light
@@ -541,7 +642,10 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
   cxt.cast_shadow = r.cast_shadow;
   cxt.opacity_threshold = .995f;
   cxt.trace_target = rs->sc->d->target_group;
+  uint32_t sample_k = 0;
   for (Sample &s : *samples) {
+    cxt.sample_uid = ((uint32_t) tile.id << 20) + sample_k++;
+    cxt.path_key = 0;
     Ray ray;
     CameraGetRay(cam, s.uv, s.time, &ray);
     cxt.time = s.time;

@@ -42,6 +42,8 @@ def check(which, res, spp, **kw):
 
 if __name__ == "__main__":
     print("devices:", gpu.device_count())
+    if len(sys.argv) > 1 and sys.argv[1] == "cornell":
+        check("cornell", (64, 48), (4, 4), mesh="tiny"); check("cornell", (160, 120), (4, 4)); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "furry":
         check("furry", (64, 48), (2, 2), mesh="furball", nlights=4); check("furry", (160, 120), (3, 3), mesh="furball"); sys.exit(0)
     check("teapot", (64, 64), (2, 2))

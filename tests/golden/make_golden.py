@@ -41,6 +41,14 @@ FRAMES = {
 }
 
 
+# rendered by the reference too, but compared STATISTICALLY: PathtracingShader draws from a
+# per-thread serial XorShift in the reference (image depends on the worker schedule), the
+# restatement and the device use the counter-based stream of DESIGN.md 4
+STAT_FRAMES = {
+    "stat_c4_cornell_64x48_8spp": ("cornell", dict(res=(64, 48), spp=(8, 8), mesh="tiny")),
+}
+
+
 def mesh_trace_inputs(asset_dir, tmp):
     """small mesh + 4000 rays (camera-like, grazing, inside-out) as raw binaries"""
     v, q, t = synth.bumpy_sphere(*synth.MESH_CLASSES["small"], seed=synth.SEED + len("small"))
@@ -86,7 +94,7 @@ def main():
     print("wrote", out, os.path.getsize(out))
 
     frames = {}
-    texts = {name: workloads.BUILDERS[builder](asset_dir, **kw) for name, (builder, kw) in FRAMES.items()}
+    texts = {name: workloads.BUILDERS[builder](asset_dir, **kw) for name, (builder, kw) in list(FRAMES.items()) + list(STAT_FRAMES.items())}
     for name, kw in edge_scenes.EDGE_CASES.items():
         texts["edge_" + name] = edge_scenes.custom_scene(asset_dir, **kw)
     for name, text in texts.items():

@@ -58,6 +58,21 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("kw", [dict(res=(64, 48), spp=(3, 3), mesh="tiny"),
+                                dict(res=(48, 32), spp=(2, 2), mesh="tiny", extra=(("max_diffuse_depth", (1,)),)),
+                                dict(res=(48, 32), spp=(2, 2), mesh="tiny", objects=("bunny",),
+                                     extra=(("max_reflect_depth", (2,)), ("max_refract_depth", (1,))))],
+                         ids=["c4_cornell_64x48_3spp", "diffuse_depth_1", "glass_only_depth_limits"])
+def test_pathtracing_matches_oracle(kw, asset_dir):
+    """C4: PathtracingShader with the counter-based bounce stream (uid, path key): the same
+    rays (per-context counts equal), the same pixels.  Also exercises the reference's
+    mirrored instance box for the negatively scaled light blob (fjgpu_build.cc)."""
+    fb, st, ref, rc = render_both(workloads.cornell(asset_dir, **kw))
+    assert st.rays.as_dict() == rc.as_dict()
+    assert rc.diffuse > 0 and rc.shadow == 0
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_frames_match_oracle_and_reference_golden(name, asset_dir, golden_dir):
     builder, kw = CASES[name]
