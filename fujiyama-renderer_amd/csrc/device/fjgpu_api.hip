@@ -194,6 +194,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.n_groups = (int) hs.groups.size();
   S.n_primsets = (int) hs.primsets.size();
   S.has_curves = 0;
+  S.has_hair = 0;
+  for (int i = 0; i < desc->n_shaders; i++) if (desc->shaders[i].type == FJ_SHADER_HAIR) S.has_hair = 1;
   for (const auto &ps : hs.primsets) if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) S.has_curves = 1;
   S.target_group = hs.target_group;
   std::memcpy(S.cam_M, hs.cam_M, sizeof(S.cam_M));

@@ -95,7 +95,10 @@ __device__ __forceinline__ bool has_negative_zero(V3 d)
 // BoxRayIntersect, reference src/fj_box.cc:73-138, operation for operation.  Used where
 // the reference's own box decides the RESULT (instance bounds, which are not always
 // conservative -- see fjgpu_build.cc), as opposed to pure culling.
-__device__ __noinline__ bool box_ray_ref(const double *b, V3 o, V3 d, double ray_tmin, double ray_tmax)
+#ifndef FJ_BOXREF_ATTR
+#define FJ_BOXREF_ATTR __forceinline__
+#endif
+__device__ FJ_BOXREF_ATTR bool box_ray_ref(const double *b, V3 o, V3 d, double ray_tmin, double ray_tmax)
 {
   double tmin, tmax, tymin, tymax, tzmin, tzmax;
   if (d.x >= 0) { tmin = (b[0] - o.x) / d.x; tmax = (b[3] - o.x) / d.x; }
@@ -113,26 +116,33 @@ __device__ __noinline__ bool box_ray_ref(const double *b, V3 o, V3 d, double ray
   return (tmin < ray_tmax) && (tmax > ray_tmin);
 }
 
+#ifdef FJ_EXP_COUNT_FB
+__device__ unsigned long long g_fb_count;
+#endif
 // Same decision as box_ray_ref at a fraction of the cost: the slab interval from the
 // per-ray reciprocal differs from the reference's divisions by a few ulp, so it settles
-// every case that is not within 1e-12 (relative) of a boundary; the rest -- and anything
-// involving NaN / inf -- takes the exact path.
-__device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3 inv, double ray_tmin, double ray_tmax)
+// every case that is not within 1e-12 (relative) of a boundary; the rest takes the exact
+// path.  `plain` = no direction component is zero (else 0 * inf = NaN: exact path);
+// overflow makes m infinite, which also lands in the exact path.
+__device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3 inv, bool plain, double ray_tmin, double ray_tmax)
 {
   const double x0 = (b[0] - o.x) * inv.x, x1 = (b[3] - o.x) * inv.x;
   const double y0 = (b[1] - o.y) * inv.y, y1 = (b[4] - o.y) * inv.y;
   const double z0 = (b[2] - o.z) * inv.z, z1 = (b[5] - o.z) * inv.z;
-  const double lx = fmin(x0, x1), hx = fmax(x0, x1), ly = fmin(y0, y1), hy = fmax(y0, y1);
-  const double lz = fmin(z0, z1), hz = fmax(z0, z1);
-  const double lo = fmax(fmax(lx, ly), lz), hi = fmin(fmin(hx, hy), hz);
-  const double sum = ((x0 + x1) + (y0 + y1)) + (z0 + z1);        // NaN / inf detector
-  const double m = 1e-12 * fmax(fmax(fabs(lo), fabs(hi)), fmax(fabs(ray_tmin), fmin(fabs(ray_tmax), 1e300)));
-  if (sum - sum == 0. && m < 1e300) {
-    if (hi - lo > m && ray_tmax - lo > m && hi - ray_tmin > m) return true;
-    if (lo - hi > m || lo - ray_tmax > m || ray_tmin - hi > m) return false;
+  const double lo = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+  const double hi = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+  const double m = 1e-12 * ((fabs(lo) + fabs(hi)) + (fabs(ray_tmin) + fmin(fabs(ray_tmax), 1e300)));
+  const double g = fmin(fmin(hi - lo, ray_tmax - lo), hi - ray_tmin);
+  if (plain) {
+    if (g > m) return true;
+    if (g < -m) return false;
   }
+#ifdef FJ_EXP_COUNT_FB
+  atomicAdd(&g_fb_count, 1ull);
+#endif
   return box_ray_ref(b, o, d, ray_tmin, ray_tmax);
 }
+__device__ __forceinline__ bool plain_dir(V3 d) { return d.x != 0 && d.y != 0 && d.z != 0; }
 
 // ------------------------------------------------------- triangle test (a21)
 // TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
@@ -418,7 +428,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
   int gfirst = 0, gcount = 0, gi = 0, ii = -1;
   const double *gsb = nullptr;
-  bool anyhit = false, dead_ray = false;
+  bool anyhit = false, dead_ray = false, plain = false;
   const DPrimSet *P = nullptr;
   uint32_t cur = TRAV_DONE;
   int sp = 0;
@@ -449,6 +459,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           cur = TRAV_DONE; sp = 0;
           dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
           winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+          plain = plain_dir(d);
         }
       }
       next += (uint32_t) __popcll(idle);
@@ -469,7 +480,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
         // the reference's own (possibly non-enclosing) instance box, full ray range
-        if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, tmin, tmax)) continue;
+#ifdef FJ_EXP_OLD_INST
+        if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
+#else
+        if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+#endif
         oo = xpoint(I->Minv, o);
         od = xvector(I->Minv, d);
         if (has_negative_zero(od)) continue;
@@ -568,8 +583,14 @@ struct ClosestPolicy {
   }
 };
 
+#ifndef FJ_CLOSEST_MINB
+#define FJ_CLOSEST_MINB 1
+#endif
+#ifndef FJ_SHADOW_MINB
+#define FJ_SHADOW_MINB 1
+#endif
 template <bool kCurves>
-__global__ void __launch_bounds__(BLOCK) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+__global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, int count_events, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
@@ -1109,6 +1130,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
 #define SQ_CHUNK 256u          // shadow-queue slots a wave reserves per global atomic
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
 
+template <bool kHair>
 __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
@@ -1139,8 +1161,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     const uint32_t iters = (nl + sp.lanes - 1) / sp.lanes;     // uniform trip count: ballots stay convergent
     DLightRec R;
     V3 Ps = mk(0, 0, 0), axis = Ps, nml_axis = Ps;
-    DGroup G;
-    G.first = 0; G.count = 0; G.all_opaque = 1; G.pad = 0;
+    int g_first = 0, g_count = 0;
+    const double *g_sbounds = nullptr;     // stays a global-memory pointer (a by-value DGroup lands in scratch)
     double cos_limit = 0;
     if (active) {
       R = lrecs[rec];
@@ -1149,8 +1171,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
       nml_axis = normalize(axis);
       r_sample = R.sample;
       W[0] = R.W[0]; W[1] = R.W[1]; W[2] = R.W[2];
-      cos_limit = R.kind == 0 ? sp.cos_half_pi : sp.cos_pi;
-      G = S.groups[R.group];
+      cos_limit = (!kHair || R.kind == 0) ? sp.cos_half_pi : sp.cos_pi;
+      g_first = S.groups[R.group].first; g_count = S.groups[R.group].count;
+      g_sbounds = S.groups[R.group].sbounds;
     }
     for (uint32_t it = 0; it < iters; it++) {
       const uint32_t l = sub + it * sp.lanes;
@@ -1169,7 +1192,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
         const bool lit = !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
         if (lit) {
           float k[3] = {0.f, 0.f, 0.f};
-          if (R.kind == 0) {             // plastic_shader.cc:131-137
+          if (!kHair || R.kind == 0) {   // plastic_shader.cc:131-137
             float Kd = (float) dot(axis, Ln);
             Kd = (float) (Kd > 0 ? (double) Kd : 0.);
             k[0] = Kd * Cl[0]; k[1] = Kd * Cl[1]; k[2] = Kd * Cl[2];
@@ -1192,9 +1215,27 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             c_shadow++;
             // group bounds test + leaf bounds of the instance BVH, as culling
             if (!has_negative_zero(Ln)) {
-              for (int gi = 0; gi < G.count; gi++) {
-                const DInstance *I = &S.instances[S.group_instances[G.first + gi]];
-                if (box_ray_ref(G.count == 1 ? G.sbounds : I->wbounds, Ps, Ln, .0001, distance)) { maybe_occluded = true; break; }
+              const V3 winv = mk(1. / Ln.x, 1. / Ln.y, 1. / Ln.z);
+              const bool plain = plain_dir(Ln);
+              for (int gi = 0; gi < g_count; gi++) {
+                const DInstance *I = &S.instances[S.group_instances[g_first + gi]];
+#ifdef FJ_EXP_OLD_CULL
+                double tn;
+                if (slab(I->wbounds, I->wbounds + 3, Ps, winv, .0001, distance, &tn)) { maybe_occluded = true; break; }
+#elif defined(FJ_EXP_CULL_NOEXACT)
+                {
+                  const double *b = g_count == 1 ? g_sbounds : I->wbounds;
+                  const double x0 = (b[0] - Ps.x) * winv.x, x1 = (b[3] - Ps.x) * winv.x;
+                  const double y0 = (b[1] - Ps.y) * winv.y, y1 = (b[4] - Ps.y) * winv.y;
+                  const double z0 = (b[2] - Ps.z) * winv.z, z1 = (b[5] - Ps.z) * winv.z;
+                  const double lo = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+                  const double hi = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+                  const double g = fmin(fmin(hi - lo, distance - lo), hi - .0001);
+                  if (g > 0) { maybe_occluded = true; break; }
+                }
+#else
+                if (box_ray_ref_fast(g_count == 1 ? g_sbounds : I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
+#endif
                 c_insts++;
               }
             }
@@ -1296,7 +1337,7 @@ struct ShadowPolicy {
 };
 
 template <bool kCurves>
-__global__ void __launch_bounds__(BLOCK) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
+__global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, int count_events, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
@@ -1430,8 +1471,12 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
     const uint32_t e = (n - b < chunk) ? n : b + chunk;
     (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + trace_head
     const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
-    hipLaunchKernelGGL(k_shadow_cull, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
-        S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    if (S.has_hair)
+      hipLaunchKernelGGL(k_shadow_cull<true>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
+          S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    else
+      hipLaunchKernelGGL(k_shadow_cull<false>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
+          S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
     if (S.has_curves)
       hipLaunchKernelGGL(k_shadow_trace<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
@@ -1444,11 +1489,17 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
   return 0;
 }
 
+#ifdef FJ_EXP_COUNT_FB
+static void dump_fb() { unsigned long long v = 0; hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fb_count), sizeof(v)); fprintf(stderr, "fallbacks so far: %llu\n", v); }
+#endif
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
     const double *s_uv, const float *s_accum, float *fb)
 {
   dim3 grid((max_tile_pixels + BLOCK - 1) / BLOCK, n_tiles);
   hipLaunchKernelGGL(k_resolve, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, s_accum, fb);
   LAUNCH_CHECK();
+#ifdef FJ_EXP_COUNT_FB
+  dump_fb();
+#endif
   return 0;
 }

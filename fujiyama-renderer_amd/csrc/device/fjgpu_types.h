@@ -93,6 +93,7 @@ struct DScene {
   const DLightSample *light_samples;
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
+  int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
   // camera (static): eye, matrix rows, uv_size
