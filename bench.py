@@ -40,7 +40,7 @@ from fujiyama_renderer_amd import gpu, host, workloads  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per traversal event (SURVEY.md 8d / DESIGN.md 7)
-S_NODE, S_PRIM, S_INST, S_RAY_IN, S_HIT_OUT = 64, 72, 192, 64, 40
+S_NODE, S_PRIM, S_INST, S_RAY_IN, S_HIT_OUT = 128, 72, 192, 64, 40
 
 
 def parse_args():

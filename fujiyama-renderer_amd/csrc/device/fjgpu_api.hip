@@ -31,6 +31,7 @@ int fail(int code, const std::string &msg)
 
 struct DeviceBuffers {
   std::vector<void *> ptrs;
+  size_t bytes = 0;
   ~DeviceBuffers() { for (void *p : ptrs) (void) hipFree(p); }
   template <class T> int upload(const T *src, size_t n, const T **out)
   {
@@ -48,6 +49,7 @@ struct DeviceBuffers {
     void *d = nullptr;
     if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return -1;
     ptrs.push_back(d);
+    bytes += std::max<size_t>(n, 1) * sizeof(T);
     *out = static_cast<T *>(d);
     return 0;
   }
@@ -82,6 +84,8 @@ struct fjgpu_scene {
   double *d_jit, *d_tim;
   size_t tab_len;
   int tiles_cap;
+  int stack_need;
+  size_t squeue_max;               // shadow-queue entries allowed by the memory budget
 };
 
 extern "C" {
@@ -193,6 +197,18 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.n_instances = (int) hs.instances.size();
   S.n_groups = (int) hs.groups.size();
   S.n_primsets = (int) hs.primsets.size();
+  // traversal stack: entries beyond the LDS part live in a global overflow area sized for
+  // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
+  {
+    int need = 0;
+    for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
+    S.stack_overflow = nullptr;
+    if (need > FJ_STACK_LDS) {
+      const size_t entries = (size_t) (need - FJ_STACK_LDS) * persistent_threads();
+      if (M.alloc(entries, &S.stack_overflow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
+    }
+    sc->stack_need = need;
+  }
   S.has_curves = 0;
   S.has_hair = 0;
   for (int i = 0; i < desc->n_shaders; i++) if (desc->shaders[i].type == FJ_SHADER_HAIR) S.has_hair = 1;
@@ -253,7 +269,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
     e |= W.alloc(rays, &sc->d_hits);
     e |= W.alloc(rays, &sc->d_lrecs);
-    sc->squeue_cap = std::min<size_t>(rays * 8, (size_t) 24 << 20) + 4096 * 1024;   // + one chunk per resident wave
+    sc->squeue_cap = std::min<size_t>(rays * 8, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
@@ -308,13 +324,28 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   fjgpu::SamplerMargin(*r, margin);
   const size_t full_tile_samples = (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
 
-  // batch size: about 4 M samples per batch unless told otherwise
+  // Batch size.  The persistent traversal kernels pay a tail per launch (ray costs are
+  // heavy tailed: the last waves finish long after the average one), so launches should be
+  // few and large: about 80 M samples per batch -- half a 1080p / 64 spp frame, ~45 GB of
+  // queues plus the shadow queue -- bounded by 40 % of the free HBM, unless told otherwise.
+  // Measured on C3: 4 M samples per batch 473 ms/frame, 80 M 392 ms, whole frame 390 ms.
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
+  const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
   long bt = sc->batch_tiles;
-  if (bt <= 0) bt = std::max<long>(1, (long) ((4u << 20) / full_tile_samples));
+  if (bt <= 0) {
+    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + sizeof(DLightRec);
+    const size_t target = std::min<size_t>((size_t) 80 << 20, (size_t) (.4 * (double) free_now) / per_sample);
+    bt = std::max<long>(1, (long) (target / full_tile_samples));
+  }
   bt = std::min<long>(bt, (long) ids.size());
   if (bt < 1) bt = 1;
   const size_t cap_samples = full_tile_samples * (size_t) bt;
-  const size_t cap_rays = cap_samples * 2 + 1024;
+  // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
+  // max_children), so a queue never needs more than one entry per sample
+  const size_t cap_rays = cap_samples + 1024;
+  sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
+  if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
   // one queue per recursion level: camera + every diffuse / reflect / refract bounce
   {
     const size_t nlev = 2 + (size_t) std::max(0, r->max_diffuse_depth) + std::max(0, r->max_reflect_depth) + std::max(0, r->max_refract_depth);
@@ -344,6 +375,8 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   swp.cos_half_pi = std::cos(3.14159265358979323846 / 2.);
   swp.cos_pi = std::cos(3.14159265358979323846);
   swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, sc->n_light_samples)));
+  swp.lanes = 1;
+  if (const char *e = getenv("FJGPU_CULL_LANES")) swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, atoi(e))));
   swp.cast_shadow = r->cast_shadow;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
   ResolveParams rp;

@@ -2,8 +2,8 @@
 //
 // Replaces the reference's build_accelerators() (src/fj_scene_interface.cc:1161-1202):
 // instead of a uniform grid per mesh (src/fj_grid_accelerator.cc:69-160) the GPU
-// core uses a binned-SAH BVH2 per primitive set ("BLAS") whose leaves hold up to
-// four pre-gathered f64 triangles, laid out for coalesced 64-byte node fetches.
+// core uses a binned-SAH BVH per primitive set ("BLAS"), built binary and collapsed
+// to 4-wide 128-byte nodes, whose leaves hold up to four pre-gathered f64 triangles.
 // Closest-hit results do not depend on the culling structure; the
 // triangle test itself is the reference's FP64 Moller-Trumbore.
 //
@@ -40,9 +40,15 @@ inline float up2(double v)
   return std::nextafterf(f, INFINITY);
 }
 
+struct Node2 {                 // binary node of the SAH build, before the 4-wide collapse
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  uint32_t lc, rc;
+};
+
 struct Builder {
   std::vector<PrimRef> prims;
-  std::vector<DNode> nodes;
+  std::vector<Node2> nodes;
   std::atomic<uint32_t> next_node;
   std::atomic<int> max_depth;
   int max_leaf;
@@ -150,9 +156,62 @@ struct Builder {
       lc = build(begin, mid, depth + 1, 0, lmn, lmx);
       rc = build(mid, end, depth + 1, 0, rmn, rmx);
     }
-    DNode &nd = nodes[me];
+    Node2 &nd = nodes[me];
     for (int k = 0; k < 3; k++) { nd.lmin[k] = lmn[k]; nd.lmax[k] = lmx[k]; nd.rmin[k] = rmn[k]; nd.rmax[k] = rmx[k]; }
-    nd.lc = lc; nd.rc = rc; nd.pad[0] = nd.pad[1] = 0;
+    nd.lc = lc; nd.rc = rc;
+    return me;
+  }
+
+  // ---- collapse to 4-wide nodes: starting from a binary node's two children, the inner
+  // child with the largest surface area is replaced by its own two children until four
+  // slots are filled (or only leaves remain).  Returns the DNode index; *need = worst-case
+  // traversal stack entries below this node (k-1 siblings pushed, deepest child first).
+  struct Cand { float mn[3], mx[3]; uint32_t ref; };
+  std::vector<DNode> wide;
+  uint32_t collapse(uint32_t ref2, int *need)
+  {
+    Cand c[4];
+    int k = 2;
+    {
+      const Node2 &n = nodes[ref2];
+      for (int a = 0; a < 3; a++) { c[0].mn[a] = n.lmin[a]; c[0].mx[a] = n.lmax[a]; c[1].mn[a] = n.rmin[a]; c[1].mx[a] = n.rmax[a]; }
+      c[0].ref = n.lc; c[1].ref = n.rc;
+    }
+    while (k < 4) {
+      int pick = -1;
+      float area = -1.f;
+      for (int i = 0; i < k; i++) {
+        if (c[i].ref & FJ_LEAF_FLAG) continue;
+        const float a = half_area(c[i].mn, c[i].mx);
+        if (a > area) { area = a; pick = i; }
+      }
+      if (pick < 0) break;
+      const Node2 &n = nodes[c[pick].ref];
+      for (int a = 0; a < 3; a++) { c[pick].mn[a] = n.lmin[a]; c[pick].mx[a] = n.lmax[a]; c[k].mn[a] = n.rmin[a]; c[k].mx[a] = n.rmax[a]; }
+      c[pick].ref = n.lc; c[k].ref = n.rc;
+      k++;
+    }
+    const uint32_t me = (uint32_t) wide.size();
+    wide.emplace_back();
+    int worst = 0;
+    uint32_t child[4];
+    for (int i = 0; i < 4; i++) {
+      if (i >= k) { child[i] = FJ_NO_CHILD; continue; }
+      if (c[i].ref & FJ_LEAF_FLAG) { child[i] = c[i].ref; continue; }
+      int nd = 0;
+      child[i] = collapse(c[i].ref, &nd);
+      worst = std::max(worst, nd);
+    }
+    DNode &w = wide[me];
+    for (int i = 0; i < 4; i++) {
+      for (int a = 0; a < 3; a++) {
+        w.box[i][a] = i < k ? c[i].mn[a] : FLT_MAX;
+        w.box[i][3 + a] = i < k ? c[i].mx[a] : -FLT_MAX;
+      }
+      w.child[i] = child[i];
+      w.pad[i] = 0;
+    }
+    *need = (k - 1) + worst;
     return me;
   }
 };
@@ -178,7 +237,13 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
     ps->root = b.build(0, n, 0, 4, mn, mx);
   }
   b.nodes.resize(b.next_node.load() ? b.next_node.load() : 1);
-  ps->nodes.swap(b.nodes);
+  ps->stack_need = 0;
+  if (n > 0 && !(ps->root & FJ_LEAF_FLAG)) {
+    b.wide.reserve(b.nodes.size() / 2 + 1);
+    ps->root = b.collapse(ps->root, &ps->stack_need);
+  }
+  if (b.wide.empty()) b.wide.emplace_back(DNode());
+  ps->nodes.swap(b.wide);
   ps->max_depth = b.max_depth;
   ps->prim_ids.resize(n);
   for (int i = 0; i < n; i++) ps->prim_ids[i] = b.prims[i].id;

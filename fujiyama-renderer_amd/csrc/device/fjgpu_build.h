@@ -25,6 +25,7 @@ struct HostPrimSet {
   int grid_n[3];
   int n_prims;
   int max_depth;
+  int stack_need;                     // worst-case traversal stack entries (4-wide tree)
   const fj_mesh_desc *mesh;
   const fj_curve_desc *curve;
 };

@@ -44,6 +44,9 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt);
 int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
+// threads of the largest persistent grid (sizes per-thread scratch such as the stack overflow area)
+size_t persistent_threads();
+
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
     const double *s_uv, const float *s_accum, float *fb);
 

@@ -409,8 +409,36 @@ struct TravTune { uint32_t refill, steps, grab; };
 
 struct RayIn { V3 o, d; double tmin, tmax; int group; bool anyhit; };
 
+// Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
+// consecutive, conflict free), deeper ones -- the builder reports the worst case of the
+// scene's trees -- in a global overflow area ([depth][global thread]).
+struct TravStack {
+  uint32_t *lds;        // s_stack + threadIdx.x
+  uint32_t *ovf;        // overflow base + global thread id (null when no tree needs it)
+  uint32_t ovf_stride;  // threads in the grid
+  __device__ __forceinline__ void push(int &sp, uint32_t v) const
+  {
+    if (sp < FJ_STACK_LDS) lds[sp * BLOCK] = v;
+    else ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride] = v;
+    sp++;
+  }
+  __device__ __forceinline__ uint32_t pop(int &sp) const
+  {
+    --sp;
+    return sp < FJ_STACK_LDS ? lds[sp * BLOCK] : ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride];
+  }
+};
+__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf)
+{
+  TravStack st;
+  st.lds = s_stack + threadIdx.x;
+  st.ovf_stride = gridDim.x * BLOCK;
+  st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
+  return st;
+}
+
 template <bool kCurves, class Policy>
-__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, uint32_t *stack, LocalCounters *lc)
+__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
   bool head_live = true;                   // wave-uniform: the global head still has entries
@@ -504,26 +532,36 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
       if (__ballot(inner) == 0ull) break;
       if (inner) {
-        const DNode *nd = &P->nodes[cur];
+        const float4 *nd = reinterpret_cast<const float4 *>(&P->nodes[cur]);
         lc->nodes++;
-        // 64-byte node: four 16-byte loads
-        const float4 a = reinterpret_cast<const float4 *>(nd)[0];
-        const float4 b = reinterpret_cast<const float4 *>(nd)[1];
-        const float4 c = reinterpret_cast<const float4 *>(nd)[2];
-        const uint4 e = reinterpret_cast<const uint4 *>(nd)[3];
-        const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-        const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+        // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
+        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
+        const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+        const float b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
         const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
-        double tl, tr;
-        const bool hl = slab_f32box(lmin, lmax, oo, inv, tmin, tf2, &tl);
-        const bool hr = slab_f32box(rmin, rmax, oo, inv, tmin, tf2, &tr);
-        if (hl && hr) {
-          const bool left_first = tl <= tr;
-          stack[(sp++) * BLOCK] = left_first ? e.y : e.x;
-          cur = left_first ? e.x : e.y;
-        } else if (hl) cur = e.x;
-        else if (hr) cur = e.y;
-        else cur = (sp == 0) ? TRAV_DONE : stack[(--sp) * BLOCK];
+        double t0, t1, t2, t3;
+        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv, tmin, tf2, &t0);                          // slot 0 always exists
+        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv, tmin, tf2, &t1);                          // slot 1 always exists
+        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv, tmin, tf2, &t2);
+        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv, tmin, tf2, &t3);
+        // near-to-far order is a heuristic only: f32 keys, misses sort last
+        float k0 = h0 ? fminf((float) t0, FLT_MAX) : INFINITY, k1 = h1 ? fminf((float) t1, FLT_MAX) : INFINITY;
+        float k2 = h2 ? fminf((float) t2, FLT_MAX) : INFINITY, k3 = h3 ? fminf((float) t3, FLT_MAX) : INFINITY;
+        uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
+#define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
+        FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)
+#undef FJ_CSWAP
+        const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
+        if (nh == 0) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+        else {
+          cur = r0;
+          if (nh > 3) stk.push(sp, r3);
+          if (nh > 2) stk.push(sp, r2);
+          if (nh > 1) stk.push(sp, r1);
+        }
       }
     }
 
@@ -533,6 +571,16 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const uint32_t cnt = (cur & 7u) + 1;
       bool stop = false;
       const bool is_curve = kCurves && P->type == FJ_PRIMSET_CURVE;
+#ifdef FJ_EXP_LEAF_TOUCH
+      // a leaf's triangles are contiguous (<= 288 B): put its middle and last cache lines in
+      // flight now instead of discovering them one dependent miss at a time
+      double touch0 = 0, touch1 = 0;
+      if (!is_curve) {
+        const double *vp0 = P->tri_verts + (size_t) first * 9;
+        touch0 = vp0[(cnt * 9) / 2];
+        touch1 = vp0[cnt * 9 - 1];
+      }
+#endif
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u = 0, v = 0;
         lc->prims++;
@@ -554,8 +602,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           if (anyhit) { stop = true; break; }
         }
       }
+#ifdef FJ_EXP_LEAF_TOUCH
+      asm volatile("" :: "v"(touch0), "v"(touch1));
+#endif
       if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
-      else cur = (sp == 0) ? TRAV_DONE : stack[(--sp) * BLOCK];
+      else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
     }
   }
 }
@@ -593,11 +644,11 @@ template <bool kCurves>
 __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, int count_events, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   ClosestPolicy pol;
   pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
+  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -1340,12 +1391,12 @@ template <bool kCurves>
 __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, int count_events, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_BVH_MAX_DEPTH * BLOCK];
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, s_stack + threadIdx.x, &lc);
+  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
   if (count_events) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -1405,13 +1456,15 @@ static unsigned persistent_grid(unsigned long long blocks_needed)
   return (unsigned) (blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap);
 }
 
+size_t persistent_threads() { return (size_t) persistent_grid(~0ull) * BLOCK; }
+
 static TravTune trav_tune()
 {
   static TravTune t = {0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 16);
-    t.steps = env("FJGPU_TRAV_STEPS", 6);
+    t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 128);
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;

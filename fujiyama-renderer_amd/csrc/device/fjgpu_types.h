@@ -6,23 +6,26 @@
 #include <stdint.h>
 #include "fj_scene_desc.h"
 
-// ---- BLAS node: 64 B = one cache-line-half, two child AABBs + two child refs.
-// Boxes are f32, rounded OUTWARD from the f64 primitive bounds and widened by
-// one more ulp, so the f64 slab test on them can never cull a primitive whose
-// f64 Moller-Trumbore test would report a hit.
-// child ref: bit 31 set -> leaf, payload = (first_prim << 3) | (count - 1);
-//            else index of the child DNode.
+// ---- BLAS node: a 4-wide BVH node, 128 B = eight 16-byte loads.  Child boxes are f32,
+// rounded OUTWARD from the f64 primitive bounds (>= 1 ulp), so a box miss proves that no
+// f64 primitive test below it would report a hit.
+// child ref: 0xffffffff -> no child; bit 31 set -> leaf, payload = (first_prim << 3) |
+//            (count - 1); else index of the child DNode.
 struct DNode {
-  float lmin[3], lmax[3];
-  float rmin[3], rmax[3];
-  uint32_t lc, rc;
-  uint32_t pad[2];
+  float box[4][6];             // child k: min xyz, max xyz
+  uint32_t child[4];
+  uint32_t pad[4];
 };
-static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 
+#define FJ_NO_CHILD 0xffffffffu
 #define FJ_LEAF_FLAG 0x80000000u
+#ifndef FJ_MAX_LEAF_PRIMS
 #define FJ_MAX_LEAF_PRIMS 4
-#define FJ_BVH_MAX_DEPTH 40          // traversal stack entries per lane
+#endif
+#define FJ_BVH_MAX_DEPTH 40          // depth bound of the binary tree the builder collapses
+#define FJ_STACK_LDS 32              // traversal stack entries per lane kept in LDS; deeper
+                                     // entries (rare) go to a global overflow area
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
@@ -93,6 +96,7 @@ struct DScene {
   const DLightSample *light_samples;
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
+  uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;

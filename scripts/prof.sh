@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage (GPU box): scripts/prof.sh NAME [bench args]  -> gpurun_out/NAME_{stats.csv,pmc.txt}
+name=$1; shift
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name.stats -- python $root/bench.py --steps 2 --warmup 1 --cpu-tiles 0 "$@" > $out/$name.bench.json 2>$out/$name.err
+find $out/$name.stats -name "*kernel_stats.csv" -exec cp {} $out/${name}_kernel_stats.csv \;
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_SMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$name.pmc_$tag -- python $root/bench.py --steps 1 --warmup 0 --cpu-tiles 0 "$@" > /dev/null 2>>$out/$name.err
+done
+python - <<PY
+import csv,collections,glob
+agg=collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob("$out/$name.pmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name'].split('(')[0][:40]
+        if k.startswith('k_') or 'k_' in k: agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+with open("$out/${name}_pmc.txt","w") as o:
+    for k,v in sorted(agg.items()):
+        o.write(k+"\n")
+        for c,x in sorted(v.items()): o.write("   %-32s %.6g\n"%(c,x))
+PY
+cat $out/${name}_kernel_stats.csv | cut -c1-60,60-200 | head -7
+cat $out/${name}_pmc.txt
