@@ -208,8 +208,13 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
       if (M.alloc(entries, &S.stack_overflow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
     sc->stack_need = need;
+    if (getenv("FJGPU_VERBOSE"))
+      for (const auto &ps : hs.primsets)
+        fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d\n", ps.type, ps.n_prims, ps.nodes.size(), ps.max_depth, ps.stack_need);
   }
   S.has_curves = 0;
+  S.all_opaque = 1;
+  for (const auto &g : hs.groups) if (!g.all_opaque) S.all_opaque = 0;
   S.has_hair = 0;
   for (int i = 0; i < desc->n_shaders; i++) if (desc->shaders[i].type == FJ_SHADER_HAIR) S.has_hair = 1;
   for (const auto &ps : hs.primsets) if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) S.has_curves = 1;

@@ -635,7 +635,7 @@ struct ClosestPolicy {
 };
 
 #ifndef FJ_CLOSEST_MINB
-#define FJ_CLOSEST_MINB 1
+#define FJ_CLOSEST_MINB 3
 #endif
 #ifndef FJ_SHADOW_MINB
 #define FJ_SHADOW_MINB 1
@@ -1403,6 +1403,174 @@ __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_
   }
 }
 
+// ---- lean any-hit traversal: shadow rays of scenes in which every possible occluder is
+// opaque (Os = 1) and no curve set exists -- the common case and the dominant kernel of
+// C1-C3.  Same tests, same order of instances, same result (occluded or not) as
+// traverse_persistent with anyhit rays; what is gone is the closest-hit bookkeeping
+// (best t/u/v/ids, tie rule, range shrinking) and the world-space ray, which is re-read
+// from the queue entry on the rare instance switches.  The point is registers: occupancy
+// decides throughput on this latency-bound walk.
+__device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
+    uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
+{
+  const unsigned lane = __lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  bool head_live = true;
+  uint32_t next = 0, range_end = 0;
+  bool have = false, hit = false;
+  uint32_t idx = 0;
+  V3 oo = mk(0, 0, 0), od = oo, inv = oo;
+  double tmax = 0;
+  int gi = 0, gend = 0;
+  const DNode *nodes = nullptr;
+  const double *tris = nullptr;
+  uint32_t cur = TRAV_DONE;
+  int sp = 0;
+  const double tmin = .0001;
+
+  for (;;) {
+    // ---- refill idle lanes (see traverse_persistent)
+    const unsigned long long idle = __ballot(!have);
+    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
+      base = __shfl(base, 0);
+      if (base >= n) head_live = false;
+      else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
+    }
+    if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
+      if (!have) {
+        const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
+        if (my < range_end && squeue[my].sample != SQ_INVALID) {
+          have = true; hit = false;
+          idx = my;
+          const int g = squeue[my].group;
+          gi = S.groups[g].first;
+          gend = gi + S.groups[g].count;
+          cur = TRAV_DONE; sp = 0;
+        }
+      }
+      next += (uint32_t) __popcll(idle);
+      if (__ballot(have) == 0ull) {
+        if (next >= range_end && !head_live) break;
+        continue;
+      }
+    }
+
+    // ---- between instances: retire the ray or enter the next instance
+    if (have && cur == TRAV_DONE) {
+      const DShadowRay *q = &squeue[idx];
+      bool found = false;
+      if (!hit) {
+        const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
+        tmax = q->tmax;
+        if (!has_negative_zero(d)) {
+          const V3 winv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+          const bool plain = plain_dir(d);
+          const DGroup *G = &S.groups[q->group];
+          const bool single = G->count == 1;
+          while (gi < gend) {
+            const DInstance *I = &S.instances[S.group_instances[gi]];
+            gi++;
+            lc->insts++;
+            if (!box_ray_ref_fast(single ? G->sbounds : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+            oo = xpoint(I->Minv, o);
+            od = xvector(I->Minv, d);
+            if (has_negative_zero(od)) continue;
+            inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+            const DPrimSet *P = &S.primsets[I->primset];
+            if (P->n_prims == 0) continue;
+            double tn;
+            if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
+            nodes = P->nodes; tris = P->tri_verts;
+            cur = P->root; sp = 0;
+            found = true;
+            break;
+          }
+        }
+      }
+      if (!found) {
+        if (!hit) {      // reached the light: add c (an opaque occluder adds c * (1 - Os) = 0)
+          float *acc = s_accum + 4 * (size_t) q->sample;
+          const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
+          if (r0 != 0.f) atomicAdd(acc + 0, r0);
+          if (r1 != 0.f) atomicAdd(acc + 1, r1);
+          if (r2 != 0.f) atomicAdd(acc + 2, r2);
+        }
+        have = false;
+      }
+    }
+
+    // ---- inner nodes
+    for (int step = 0; step < TRAV_STEPS; step++) {
+      const bool inner = have && !(cur & FJ_LEAF_FLAG);
+      if (__ballot(inner) == 0ull) break;
+      if (inner) {
+        const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
+        lc->nodes++;
+        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
+        const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+        const float b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+        double t0, t1, t2, t3;
+        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv, tmin, tmax, &t0);
+        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv, tmin, tmax, &t1);
+        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv, tmin, tmax, &t2);
+        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv, tmin, tmax, &t3);
+        float k0 = h0 ? fminf((float) t0, FLT_MAX) : INFINITY, k1 = h1 ? fminf((float) t1, FLT_MAX) : INFINITY;
+        float k2 = h2 ? fminf((float) t2, FLT_MAX) : INFINITY, k3 = h3 ? fminf((float) t3, FLT_MAX) : INFINITY;
+        uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
+#define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
+        FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)
+#undef FJ_CSWAP
+        const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
+        if (nh == 0) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+        else {
+          cur = r0;
+          if (nh > 3) stk.push(sp, r3);
+          if (nh > 2) stk.push(sp, r2);
+          if (nh > 1) stk.push(sp, r1);
+        }
+      }
+    }
+
+    // ---- leaves: the first triangle hit inside [tmin, tmax] ends the ray
+    if (have && (cur & FJ_LEAF_FLAG) && cur != TRAV_DONE) {
+      const uint32_t first = (cur & 0x7fffffffu) >> 3;
+      const uint32_t cnt = (cur & 7u) + 1;
+      for (uint32_t k = 0; k < cnt; k++) {
+        double t, u, v;
+        lc->prims++;
+        const double *vp = tris + (size_t) (first + k) * 9;
+        if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+        if (!(tmin <= t && t <= tmax)) continue;
+        hit = true;
+        break;
+      }
+      if (hit) { have = false; cur = TRAV_DONE; }
+      else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+    }
+  }
+}
+
+#ifndef FJ_ANYHIT_MINB
+#define FJ_ANYHIT_MINB 4
+#endif
+__global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
+    DCounters *cnt, int count_events, TravTune tune)
+{
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  const uint32_t n = cnt->shadow_count;
+  LocalCounters lc = {0, 0, 0};
+  traverse_anyhit(S, squeue, s_accum, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  if (count_events) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
+  }
+}
+
 // ------------------------------------------------------------------ k_resolve
 // reconstruct_image + apply_pixel_filter (src/fj_renderer.cc:939-995) with
 // eval_gaussian (src/fj_filter.cc:49-58): f32 accumulators += f64 products, in
@@ -1531,7 +1699,10 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
       hipLaunchKernelGGL(k_shadow_cull<false>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
           S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
-    if (S.has_curves)
+    if (S.all_opaque && !S.has_curves)
+      hipLaunchKernelGGL(k_shadow_anyhit, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
+    else if (S.has_curves)
       hipLaunchKernelGGL(k_shadow_trace<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
           S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
     else

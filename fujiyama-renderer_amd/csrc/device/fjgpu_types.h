@@ -97,6 +97,7 @@ struct DScene {
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
+  int32_t all_opaque;          // every group is all_opaque: shadow rays run the lean any-hit kernel
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;

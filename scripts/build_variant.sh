@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/fujiyama-renderer_amd/csrc
 out=$root/fujiyama-renderer_amd/lib/var/$name
 o=/tmp/var_$name
-mkdir -p $out $o
+rm -rf $o $out; mkdir -p $out $o
 for f in fjgpu_kernels fjgpu_api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$root/include -I$src/device "$@" -c -o $o/$f.o $src/device/$f.hip &
 done
