@@ -40,7 +40,11 @@ from fujiyama_renderer_amd import gpu, host, workloads  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per traversal event (SURVEY.md 8d / DESIGN.md 7)
-S_NODE, S_PRIM, S_INST, S_RAY_IN, S_HIT_OUT = 128, 72, 192, 64, 40
+# (node and triangle record sizes are those of the built layout: fjgpu_scene_query)
+# instance test = its 48-B box (the 96-B inverse matrix read on entry is not counted);
+# closest-hit ray = DRay 64 B in + DHit 32 B out; a shadow ray that survives the
+# instance-box cull = its 80-B queue entry (culled ones are never materialised)
+S_INST, S_RAY_IN, S_HIT_OUT, S_SHADOW = 48, 64, 32, 80
 
 
 def parse_args():
@@ -58,9 +62,10 @@ def parse_args():
     return ap.parse_args()
 
 
-def algorithmic_bytes(st):
-    return (st.nodes_visited * S_NODE + st.prims_tested * S_PRIM + st.insts_tested * S_INST +
-            st.rays_traced * (S_RAY_IN + S_HIT_OUT))
+def algorithmic_bytes(st, s_node, s_prim):
+    closest = st.rays_traced - st.rays.shadow
+    return (st.nodes_visited * s_node + st.prims_tested * s_prim + st.insts_tested * S_INST +
+            closest * (S_RAY_IN + S_HIT_OUT) + st.shadow_traversed * S_SHADOW)
 
 
 def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays):
@@ -144,6 +149,7 @@ def main():
     host.run_scene_text(scene_text(), deferred=True)
     scene_ptr, render = host.get_desc()
     gs = gpu.Scene(scene_ptr, device=local_rank)
+    s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
     prep_seconds = time.perf_counter() - t_prep
@@ -179,7 +185,7 @@ def main():
     # ---------------- aggregate over ranks
     rays_local = float(sum(s.rays.total() for s in stats))
     trace_ms_local = float(sum(s.trace_ms for s in stats))
-    alg_bytes_local = float(sum(algorithmic_bytes(s) for s in stats))
+    alg_bytes_local = float(sum(algorithmic_bytes(s, s_node, s_prim) for s in stats))
     launches_local = float(sum(s.trace_launches for s in stats))
     agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
     mx = agg.clone()
@@ -194,7 +200,7 @@ def main():
         per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
         # roofline of the dominant kernels (k_trace_closest + k_shadow) on rank 0:
         # algorithmic bytes of all their launches / summed HIP-event durations
-        alg = float(sum(algorithmic_bytes(s) for s in stats))
+        alg = float(sum(algorithmic_bytes(s, s_node, s_prim) for s in stats))
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
         achieved = alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
@@ -203,7 +209,8 @@ def main():
                 "kernel": "k_trace_closest+k_shadow", "launches": int(nl),
                 "avg_launch_ms": tms / nl if nl else None,
                 "algorithmic_bytes_per_launch": alg / nl if nl else None,
-                "bytes_per_ray": alg / max(1.0, float(sum(s.rays_traced for s in stats)))}
+                "bytes_per_ray": alg / max(1.0, float(sum(s.rays_traced for s in stats))),
+                "record_bytes": {"node": s_node, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW}}
         out = {
             "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
             "value": total_rays / elapsed_max / 1e6,

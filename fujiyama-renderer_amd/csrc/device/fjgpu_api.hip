@@ -85,6 +85,8 @@ struct fjgpu_scene {
   size_t tab_len;
   int tiles_cap;
   int stack_need;
+  double tri_record_bytes;         // 36 when every mesh is stored as f32 triangles, else 72
+  size_t blas_nodes;
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
 };
 
@@ -163,6 +165,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     if (h.type == FJ_PRIMSET_MESH) {
       const fj_mesh_desc &m = *h.mesh;
       e |= M.upload(h.tri_verts.data(), h.tri_verts.size(), &d.tri_verts);
+      e |= M.upload(h.tri_verts32.data(), h.tri_verts32.size(), &d.tri_verts32);
       e |= M.upload(m.P, (size_t) m.n_points * 3, &d.P);
       e |= M.upload(m.N, m.N ? (size_t) m.n_points * 3 : 0, &d.N);
       e |= M.upload(m.uv, m.uv ? (size_t) m.n_points * 2 : 0, &d.uv);
@@ -208,6 +211,11 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
       if (M.alloc(entries, &S.stack_overflow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
     sc->stack_need = need;
+    sc->tri_record_bytes = 36; sc->blas_nodes = 0;
+    for (const auto &ps : hs.primsets) {
+      sc->blas_nodes += ps.nodes.size();
+      if (ps.type == FJ_PRIMSET_MESH && ps.n_prims > 0 && ps.tri_verts32.empty()) sc->tri_record_bytes = 72;
+    }
     if (getenv("FJGPU_VERBOSE"))
       for (const auto &ps : hs.primsets)
         fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d\n", ps.type, ps.n_prims, ps.nodes.size(), ps.max_depth, ps.stack_need);
@@ -245,6 +253,17 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   (void) hipSetDevice(scene->device);
   (void) hipDeviceSynchronize();
   delete scene;
+}
+
+int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
+{
+  if (!scene || !name || !value) return fail(FJGPU_EINVAL, "bad query call");
+  const std::string n(name);
+  if (n == "node_record_bytes") { *value = (double) sizeof(DNode); return 0; }
+  if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
+  if (n == "stack_need") { *value = scene->stack_need; return 0; }
+  if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
+  return fail(FJGPU_EINVAL, "unknown query " + n);
 }
 
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -274,12 +275,21 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
   }
   for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
   BuildBlas(ps, refs);
-  ps->tri_verts.resize((size_t) ps->n_prims * 9);
+  // pre-gathered vertices in leaf order; as f32 when that loses nothing (meshes read from
+  // PLY files carry f32 coordinates): half the bytes per triangle test, identical operands
+  bool f32_exact = true;
+  for (int i = 0; i < m.n_points * 3 && f32_exact; i++) f32_exact = (double) (float) m.P[i] == m.P[i];
+  if (getenv("FJGPU_NO_F32_TRIS")) f32_exact = false;
+  if (f32_exact) ps->tri_verts32.resize((size_t) ps->n_prims * 9);
+  else ps->tri_verts.resize((size_t) ps->n_prims * 9);
   for (int i = 0; i < ps->n_prims; i++) {
     const int f = (int) ps->prim_ids[i];
     for (int k = 0; k < 3; k++) {
       const int p = m.indices[3 * f + k];
-      for (int c = 0; c < 3; c++) ps->tri_verts[(size_t) i * 9 + 3 * k + c] = m.P[3 * p + c];
+      for (int c = 0; c < 3; c++) {
+        if (f32_exact) ps->tri_verts32[(size_t) i * 9 + 3 * k + c] = (float) m.P[3 * p + c];
+        else ps->tri_verts[(size_t) i * 9 + 3 * k + c] = m.P[3 * p + c];
+      }
     }
   }
   return 0;

@@ -13,7 +13,8 @@ namespace fjgpu {
 struct HostPrimSet {
   int type;
   std::vector<DNode> nodes;
-  std::vector<double> tri_verts;      // mesh: [n][9]
+  std::vector<double> tri_verts;      // mesh: [n][9]  (empty when tri_verts32 is used)
+  std::vector<float> tri_verts32;     // mesh: [n][9]  all coordinates exactly representable in f32
   std::vector<uint32_t> prim_ids;
   std::vector<double> curve_cp;       // curves: [n][12]
   std::vector<double> curve_width;    // [n][2]

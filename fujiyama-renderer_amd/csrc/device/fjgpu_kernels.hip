@@ -144,6 +144,20 @@ __device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3
 }
 __device__ __forceinline__ bool plain_dir(V3 d) { return d.x != 0 && d.y != 0 && d.z != 0; }
 
+// vertices of leaf slot i: f64 as stored, or f32 widened (exact) -- see DPrimSet
+__device__ __forceinline__ void load_tri(const double *t64, const float *t32, uint32_t i, V3 *v0, V3 *v1, V3 *v2)
+{
+  if (t32) {
+    const float *p = t32 + (size_t) i * 9;
+    *v0 = mk((double) p[0], (double) p[1], (double) p[2]);
+    *v1 = mk((double) p[3], (double) p[4], (double) p[5]);
+    *v2 = mk((double) p[6], (double) p[7], (double) p[8]);
+  } else {
+    const double *p = t64 + (size_t) i * 9;
+    *v0 = ld3(p); *v1 = ld3(p + 3); *v2 = ld3(p + 6);
+  }
+}
+
 // ------------------------------------------------------- triangle test (a21)
 // TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
 // EPSILON 1e-6 (:12); no t-sign test here -- the range test is the caller's
@@ -575,7 +589,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       // a leaf's triangles are contiguous (<= 288 B): put its middle and last cache lines in
       // flight now instead of discovering them one dependent miss at a time
       double touch0 = 0, touch1 = 0;
-      if (!is_curve) {
+      if (!is_curve && P->tri_verts) {
         const double *vp0 = P->tri_verts + (size_t) first * 9;
         touch0 = vp0[(cnt * 9) / 2];
         touch1 = vp0[cnt * 9 - 1];
@@ -592,8 +606,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           if (!curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
           v = (double) sl;
         } else {
-          const double *vp = P->tri_verts + (size_t) (first + k) * 9;
-          if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+          V3 v0, v1, v2;
+          load_tri(P->tri_verts, P->tri_verts32, first + k, &v0, &v1, &v2);
+          if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
         }
         if (!(tmin <= t && t <= tmax)) continue;
         const int pid = (int) P->prim_ids[first + k];
@@ -1424,6 +1439,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   int gi = 0, gend = 0;
   const DNode *nodes = nullptr;
   const double *tris = nullptr;
+  const float *tris32 = nullptr;
   uint32_t cur = TRAV_DONE;
   int sp = 0;
   const double tmin = .0001;
@@ -1482,7 +1498,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (P->n_prims == 0) continue;
             double tn;
             if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
-            nodes = P->nodes; tris = P->tri_verts;
+            nodes = P->nodes; tris = P->tri_verts; tris32 = P->tri_verts32;
             cur = P->root; sp = 0;
             found = true;
             break;
@@ -1543,8 +1559,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u, v;
         lc->prims++;
-        const double *vp = tris + (size_t) (first + k) * 9;
-        if (!tri_ray(ld3(vp), ld3(vp + 3), ld3(vp + 6), oo, od, &t, &u, &v)) continue;
+        V3 v0, v1, v2;
+        load_tri(tris, tris32, first + k, &v0, &v1, &v2);
+        if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
         if (!(tmin <= t && t <= tmax)) continue;
         hit = true;
         break;
@@ -1586,21 +1603,36 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileD
   const size_t base = (size_t) T.sample_offset + (size_t) (py - T.ymin) * rp.rate_y * T.nx + (size_t) (px - T.xmin) * rp.rate_x;
   float pix[4] = {0.f, 0.f, 0.f, 0.f};
   float wgt_sum = 0.f;
+  // Lanes are pixels, `rate_x` samples (128 B) apart: a lane owns whole cache lines of its
+  // window rows.  Four samples (64 B of uv + 64 B of RGBA) are loaded back to back so that a
+  // line is fetched once, not once per sample after being evicted by the other lanes' lines.
   for (int sy = 0; sy < rp.npx_y; sy++)
-    for (int sx = 0; sx < rp.npx_x; sx++) {
-      const size_t s = base + (size_t) sy * T.nx + sx;
-      const double u = s_uv[2 * s], v = s_uv[2 * s + 1];
-      const float4 d = reinterpret_cast<const float4 *>(s_accum)[s];
-      const double filtx = rp.xres * u - (px + .5);
-      const double filty = rp.yres * (1 - v) - (py + .5);
-      const double xx = 2 * filtx / rp.fw;
-      const double yy = 2 * filty / rp.fh;
-      const double wgt = exp(-2 * (xx * xx + yy * yy));
-      pix[0] = (float) (pix[0] + wgt * (double) d.x);
-      pix[1] = (float) (pix[1] + wgt * (double) d.y);
-      pix[2] = (float) (pix[2] + wgt * (double) d.z);
-      pix[3] = (float) (pix[3] + wgt * (double) d.w);
-      wgt_sum = (float) (wgt_sum + wgt);
+    for (int sx0 = 0; sx0 < rp.npx_x; sx0 += 4) {
+      const size_t s0 = base + (size_t) sy * T.nx + sx0;
+      double2 uv[4];
+      float4 dd[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const size_t s = s0 + (sx0 + j < rp.npx_x ? j : 0);
+        uv[j] = reinterpret_cast<const double2 *>(s_uv)[s];
+        dd[j] = reinterpret_cast<const float4 *>(s_accum)[s];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (sx0 + j >= rp.npx_x) break;
+        const double u = uv[j].x, v = uv[j].y;
+        const float4 d = dd[j];
+        const double filtx = rp.xres * u - (px + .5);
+        const double filty = rp.yres * (1 - v) - (py + .5);
+        const double xx = 2 * filtx / rp.fw;
+        const double yy = 2 * filty / rp.fh;
+        const double wgt = exp(-2 * (xx * xx + yy * yy));
+        pix[0] = (float) (pix[0] + wgt * (double) d.x);
+        pix[1] = (float) (pix[1] + wgt * (double) d.y);
+        pix[2] = (float) (pix[2] + wgt * (double) d.z);
+        pix[3] = (float) (pix[3] + wgt * (double) d.w);
+        wgt_sum = (float) (wgt_sum + wgt);
+      }
     }
   const float inv_sum = 1.f / wgt_sum;
   float4 out;

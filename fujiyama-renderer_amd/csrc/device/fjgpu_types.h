@@ -30,7 +30,10 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
   const DNode *nodes;
-  const double *tri_verts;     // [n_prims][9]  pre-gathered v0 v1 v2 in BLAS leaf order (72 B / tri)
+  const double *tri_verts;     // [n_prims][9]  pre-gathered v0 v1 v2 in BLAS leaf order (72 B / tri), or null:
+  const float *tri_verts32;    // [n_prims][9]  the same values as f32 (36 B / tri) when EVERY coordinate of the
+                               //               mesh is exactly representable in f32 (PLY data is); widened to
+                               //               f64 on load, so the test sees identical operands
   const uint32_t *prim_ids;    // [n_prims]     original primitive id of leaf slot k
   const double *P;             // [n_points][3] object-space positions (attribute fetch)
   const double *N;             // [n_points][3] or null

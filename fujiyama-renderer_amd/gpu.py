@@ -29,6 +29,7 @@ def lib():
         L.fjgpu_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(ffi.GpuStats)]
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -59,6 +60,11 @@ class Scene(object):
             self.close()
         except Exception:
             pass
+
+    def query(self, name):
+        v = C.c_double(0)
+        _check(lib().fjgpu_scene_query(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_option(self, name, value):
         _check(lib().fjgpu_set_option(self._h, name.encode(), int(value)))

@@ -99,6 +99,11 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
  * "count_nodes" 0/1 enable traversal event counters. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
+/* Facts about the built device scene (for measurement: record sizes of the actual layout).
+ * "node_record_bytes" (128), "tri_record_bytes" (36 when every mesh is stored as exact f32
+ * triangles, else 72), "blas_nodes", "stack_need".  Returns 0 or FJGPU_EINVAL. */
+int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);
+
 /* Diagnostics: the host-side math that feeds geometry to the device (matrices,
  * RNG tables, sampler margins), exported so it can be pinned against the
  * reference's golden vectors on a machine without a GPU. */
