@@ -182,10 +182,19 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
+    # One more, UNTIMED frame in the counting instantiation of the traversal kernels: the event
+    # counters (nodes / triangles / instance boxes / rays) cost registers and issue slots, so
+    # the timed frames run without them.  The frame is deterministic: the counts of this frame
+    # are the counts of every timed frame; kernel times come from the timed frames only.
+    gs.set_option("count_nodes", 1)
+    counted = step()
+    sync()
+    gs.set_option("count_nodes", 0)
+
     # ---------------- aggregate over ranks
     rays_local = float(sum(s.rays.total() for s in stats))
     trace_ms_local = float(sum(s.trace_ms for s in stats))
-    alg_bytes_local = float(sum(algorithmic_bytes(s, s_node, s_prim) for s in stats))
+    alg_bytes_local = float(algorithmic_bytes(counted, s_node, s_prim)) * len(stats)
     launches_local = float(sum(s.trace_launches for s in stats))
     agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
     mx = agg.clone()
@@ -200,7 +209,7 @@ def main():
         per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
         # roofline of the dominant kernels (k_trace_closest + k_shadow) on rank 0:
         # algorithmic bytes of all their launches / summed HIP-event durations
-        alg = float(sum(algorithmic_bytes(s, s_node, s_prim) for s in stats))
+        alg = float(algorithmic_bytes(counted, s_node, s_prim)) * len(stats)
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
         achieved = alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
@@ -209,7 +218,7 @@ def main():
                 "kernel": "k_trace_closest+k_shadow", "launches": int(nl),
                 "avg_launch_ms": tms / nl if nl else None,
                 "algorithmic_bytes_per_launch": alg / nl if nl else None,
-                "bytes_per_ray": alg / max(1.0, float(sum(s.rays_traced for s in stats))),
+                "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * len(stats)),
                 "record_bytes": {"node": s_node, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW}}
         out = {
             "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
@@ -226,9 +235,9 @@ def main():
                                              "furry": "furbunny"}.get(args.workload, args.workload),
                        "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
                        "prepare_seconds": prep_seconds,
-                       "counters_last_frame_rank0": {"nodes": int(s0.nodes_visited), "prims": int(s0.prims_tested),
-                                                     "insts": int(s0.insts_tested), "traced": int(s0.rays_traced),
-                                                     "shadow_traversed": int(s0.shadow_traversed)},
+                       "counters_counting_frame_rank0": {"nodes": int(counted.nodes_visited), "prims": int(counted.prims_tested),
+                                                         "insts": int(counted.insts_tested), "traced": int(counted.rays_traced),
+                                                         "shadow_traversed": int(counted.shadow_traversed)},
                        "ms_last_frame_rank0": {"trace": s0.trace_ms, "shade": s0.shade_ms, "gen": s0.gen_ms,
                                                "resolve": s0.resolve_ms, "total": s0.total_ms}},
             "roofline": roof,

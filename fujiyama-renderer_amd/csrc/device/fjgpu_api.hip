@@ -141,7 +141,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   std::unique_ptr<fjgpu_scene> sc(new fjgpu_scene());
   sc->device = device;
   sc->batch_tiles = 0;
-  sc->count_events = 1;
+  sc->count_events = 0;     // traversal event counters are opt-in ("count_nodes"): they cost registers
   sc->count_all_shadow = 1;
   sc->work_samples = sc->work_rays = 0;
   sc->tab_len = 0;

@@ -192,6 +192,8 @@ struct Builder {
       c[pick].ref = n.lc; c[k].ref = n.rc;
       k++;
     }
+    // larger children first: the any-hit kernel visits hit children in slot order
+    std::sort(c, c + k, [](const Cand &a, const Cand &b) { return half_area(a.mn, a.mx) > half_area(b.mn, b.mx); });
     const uint32_t me = (uint32_t) wide.size();
     wide.emplace_back();
     int worst = 0;

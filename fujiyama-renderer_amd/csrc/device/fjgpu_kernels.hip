@@ -451,7 +451,7 @@ __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf
   return st;
 }
 
-template <bool kCurves, class Policy>
+template <bool kCurves, bool kCount, class Policy>
 __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
@@ -518,7 +518,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         ii = S.group_instances[gfirst + gi];
         gi++;
         const DInstance *I = &S.instances[ii];
-        lc->insts++;
+        if (kCount) lc->insts++;
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
         // the reference's own (possibly non-enclosing) instance box, full ray range
@@ -547,7 +547,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       if (__ballot(inner) == 0ull) break;
       if (inner) {
         const float4 *nd = reinterpret_cast<const float4 *>(&P->nodes[cur]);
-        lc->nodes++;
+        if (kCount) lc->nodes++;
         // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
         const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
         const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
@@ -597,7 +597,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 #endif
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u = 0, v = 0;
-        lc->prims++;
+        if (kCount) lc->prims++;
         if (kCurves && is_curve) {
           // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
           const size_t sl = first + k;
@@ -655,16 +655,16 @@ struct ClosestPolicy {
 #ifndef FJ_SHADOW_MINB
 #define FJ_SHADOW_MINB 1
 #endif
-template <bool kCurves>
+template <bool kCurves, bool kCount>
 __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
-    DHit *hits, uint32_t n, DCounters *cnt, int count_events, TravTune tune)
+    DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   ClosestPolicy pol;
   pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
-  if (count_events) {
+  traverse_persistent<kCurves, kCount>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
   }
@@ -1402,20 +1402,69 @@ struct ShadowPolicy {
   }
 };
 
-template <bool kCurves>
+template <bool kCurves, bool kCount>
 __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
-    DCounters *cnt, int count_events, TravTune tune)
+    DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
-  if (count_events) {
+  traverse_persistent<kCurves, kCount>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
   }
+}
+
+// ---- conservative f32 slab test for the any-hit walk.
+// Per (ray, instance) and axis a the entry code keeps  i32 = (float)(1/od_a),
+// o32 = (float)(oo_a/od_a)  and a margin  E = 1.5 * 2^-22 * (Bmax_a * |i32| + |o32|),
+// Bmax_a >= |any box coordinate| of the primitive set.  For a box plane b (f32):
+//   t~ = fmaf(b, i32, -o32)  differs from the exact (b - oo_a)/od_a by at most
+//   |b/od| 2^-24 (i32 rounding) + |oo/od| 2^-24 (o32 rounding) + |t~| 2^-24 (fma rounding)
+//   <= 2^-23 (Bmax |i32| + |o32|) (1 + 2^-22)  <  E,
+// so [min(t~0, t~1) - E, max(t~0, t~1) + E] contains the exact slab interval and the f64
+// interval of slab_f32box (whose own error is ~2^-52 relative): whatever the f64 test
+// accepts this one accepts -- it can only cull less.  An axis whose E is not a finite
+// number below 1e30 (direction component zero or denormal: 1/od = inf, 0 * inf = NaN) is
+// given i32 = o32 = 0, E = 1e30: t~ = 0, interval [-1e30, 1e30], it never culls.  With
+// E < 1e30 every product is below 2.8e36, so no inf and no NaN can arise in the test.
+struct Slab32 { float ix, iy, iz, ox, oy, oz, ex, ey, ez; };
+#ifdef FJ_EXP_SLAB_VALIDATE
+__device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
+#endif
+
+__device__ __forceinline__ void slab32_axis(double inv, double oo, double bmax_abs, float *i32, float *o32, float *e32)
+{
+  float i = (float) inv, o = (float) (oo * inv);
+  float e = 3.6e-7f * ((float) bmax_abs * 1.0000002f * fabsf(i) + fabsf(o));
+  if (!(e < 1e30f)) { i = 0.f; o = 0.f; e = 1e30f; }
+  *i32 = i; *o32 = o; *e32 = e;
+}
+
+__device__ __forceinline__ Slab32 slab32_setup(V3 oo, V3 inv, const double *bounds)
+{
+  Slab32 s;
+  slab32_axis(inv.x, oo.x, fmax(fabs(bounds[0]), fabs(bounds[3])), &s.ix, &s.ox, &s.ex);
+  slab32_axis(inv.y, oo.y, fmax(fabs(bounds[1]), fabs(bounds[4])), &s.iy, &s.oy, &s.ey);
+  slab32_axis(inv.z, oo.z, fmax(fabs(bounds[2]), fabs(bounds[5])), &s.iz, &s.oz, &s.ez);
+  return s;
+}
+
+// box = {min xyz, max xyz}; tmin32 <= tmin and tmax32 >= tmax of the ray
+__device__ __forceinline__ bool slab32_test(const float *b, const Slab32 &s, float tmin32, float tmax32)
+{
+  const float x0 = fmaf(b[0], s.ix, -s.ox), x1 = fmaf(b[3], s.ix, -s.ox);
+  const float y0 = fmaf(b[1], s.iy, -s.oy), y1 = fmaf(b[4], s.iy, -s.oy);
+  const float z0 = fmaf(b[2], s.iz, -s.oz), z1 = fmaf(b[5], s.iz, -s.oz);
+  const float lx = fminf(x0, x1) - s.ex, hx = fmaxf(x0, x1) + s.ex;
+  const float ly = fminf(y0, y1) - s.ey, hy = fmaxf(y0, y1) + s.ey;
+  const float lz = fminf(z0, z1) - s.ez, hz = fmaxf(z0, z1) + s.ez;
+  const float tn = fmaxf(fmaxf(lx, ly), fmaxf(lz, tmin32));
+  const float tf = fminf(fminf(hx, hy), fminf(hz, tmax32));
+  return tn <= tf;
 }
 
 // ---- lean any-hit traversal: shadow rays of scenes in which every possible occluder is
@@ -1425,6 +1474,7 @@ __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_
 // (best t/u/v/ids, tie rule, range shrinking) and the world-space ray, which is re-read
 // from the queue entry on the rare instance switches.  The point is registers: occupancy
 // decides throughput on this latency-bound walk.
+template <bool kCount>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
     uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
 {
@@ -1434,7 +1484,15 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   uint32_t next = 0, range_end = 0;
   bool have = false, hit = false;
   uint32_t idx = 0;
-  V3 oo = mk(0, 0, 0), od = oo, inv = oo;
+  V3 oo = mk(0, 0, 0), od = oo;
+#if !defined(FJ_EXP_ANYHIT_F32SLAB) || defined(FJ_EXP_SLAB_VALIDATE)
+  V3 inv_keep = oo;
+#endif
+#ifdef FJ_EXP_ANYHIT_F32SLAB
+  Slab32 s32 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float tmax32 = 0.f;
+  const float tmin32 = 9.9999e-5f;      // <= .0001
+#endif
   double tmax = 0;
   int gi = 0, gend = 0;
   const DNode *nodes = nullptr;
@@ -1488,16 +1546,23 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           while (gi < gend) {
             const DInstance *I = &S.instances[S.group_instances[gi]];
             gi++;
-            lc->insts++;
+            if (kCount) lc->insts++;
             if (!box_ray_ref_fast(single ? G->sbounds : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
             oo = xpoint(I->Minv, o);
             od = xvector(I->Minv, d);
             if (has_negative_zero(od)) continue;
-            inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+            const V3 inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
             const DPrimSet *P = &S.primsets[I->primset];
             if (P->n_prims == 0) continue;
             double tn;
             if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
+#if !defined(FJ_EXP_ANYHIT_F32SLAB) || defined(FJ_EXP_SLAB_VALIDATE)
+            inv_keep = inv;
+#endif
+#ifdef FJ_EXP_ANYHIT_F32SLAB
+            s32 = slab32_setup(oo, inv, P->bounds);
+            tmax32 = nextafterf((float) tmax, INFINITY);
+#endif
             nodes = P->nodes; tris = P->tri_verts; tris32 = P->tri_verts32;
             cur = P->root; sp = 0;
             found = true;
@@ -1523,24 +1588,45 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (__ballot(inner) == 0ull) break;
       if (inner) {
         const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
-        lc->nodes++;
+        if (kCount) lc->nodes++;
         const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
         const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
         const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
         const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
         const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
         const float b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+#ifndef FJ_EXP_ANYHIT_F32SLAB
         double t0, t1, t2, t3;
-        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv, tmin, tmax, &t0);
-        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv, tmin, tmax, &t1);
-        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv, tmin, tmax, &t2);
-        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv, tmin, tmax, &t3);
-        float k0 = h0 ? fminf((float) t0, FLT_MAX) : INFINITY, k1 = h1 ? fminf((float) t1, FLT_MAX) : INFINITY;
-        float k2 = h2 ? fminf((float) t2, FLT_MAX) : INFINITY, k3 = h3 ? fminf((float) t3, FLT_MAX) : INFINITY;
+        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv_keep, tmin, tmax, &t0);
+        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv_keep, tmin, tmax, &t1);
+        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv_keep, tmin, tmax, &t2);
+        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv_keep, tmin, tmax, &t3);
+#else
+        const bool h0 = slab32_test(b0, s32, tmin32, tmax32);
+        const bool h1 = slab32_test(b1, s32, tmin32, tmax32);
+        const bool h2 = e.z != FJ_NO_CHILD && slab32_test(b2, s32, tmin32, tmax32);
+        const bool h3 = e.w != FJ_NO_CHILD && slab32_test(b3, s32, tmin32, tmax32);
+#ifdef FJ_EXP_SLAB_VALIDATE
+        {   // every box the f64 test accepts must be accepted by the f32 test
+          double tq;
+          const bool g0 = slab_f32box(b0, b0 + 3, oo, inv_keep, tmin, tmax, &tq);
+          const bool g1 = slab_f32box(b1, b1 + 3, oo, inv_keep, tmin, tmax, &tq);
+          const bool g2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv_keep, tmin, tmax, &tq);
+          const bool g3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv_keep, tmin, tmax, &tq);
+          const int lost = (int) (g0 && !h0) + (int) (g1 && !h1) + (int) (g2 && !h2) + (int) (g3 && !h3);
+          const int extra = (int) (h0 && !g0) + (int) (h1 && !g1) + (int) (h2 && !g2) + (int) (h3 && !g3);
+          if (lost) atomicAdd(&g_slab_lost, (unsigned long long) lost);
+          if (extra) atomicAdd(&g_slab_extra, (unsigned long long) extra);
+          atomicAdd(&g_slab_tests, (unsigned long long) (2 + (e.z != FJ_NO_CHILD) + (e.w != FJ_NO_CHILD)));
+        }
+#endif
+#endif
+        // any hit ends the ray, so the visiting order is free: no distance sort; children
+        // are stored by decreasing surface area (the builder), larger ones first
         uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
-#define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
-        FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)
-#undef FJ_CSWAP
+        if (!h2) { r2 = r3; }
+        if (!h1) { r1 = r2; r2 = r3; }
+        if (!h0) { r0 = r1; r1 = r2; r2 = r3; }
         const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
         if (nh == 0) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
         else {
@@ -1558,7 +1644,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       const uint32_t cnt = (cur & 7u) + 1;
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u, v;
-        lc->prims++;
+        if (kCount) lc->prims++;
         V3 v0, v1, v2;
         load_tri(tris, tris32, first + k, &v0, &v1, &v2);
         if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
@@ -1575,14 +1661,15 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #ifndef FJ_ANYHIT_MINB
 #define FJ_ANYHIT_MINB 4
 #endif
+template <bool kCount>
 __global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
-    DCounters *cnt, int count_events, TravTune tune)
+    DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit(S, squeue, s_accum, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
-  if (count_events) {
+  traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
   }
@@ -1691,10 +1778,12 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
   if (n == 0) return 0;
   (void) hipMemsetAsync(&cnt->trace_head, 0, sizeof(uint32_t), st);
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
-  if (S.has_curves)
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
-  else
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(persistent_grid((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, count_events, trav_tune());
+  // (the event counters cost registers and issue slots: counting is its own instantiation)
+  const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));
+#define FJ_LAUNCH_CLOSEST(CURVES, COUNT) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
+  if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true); else FJ_LAUNCH_CLOSEST(true, false); }
+  else { if (count_events) FJ_LAUNCH_CLOSEST(false, true); else FJ_LAUNCH_CLOSEST(false, false); }
+#undef FJ_LAUNCH_CLOSEST
   LAUNCH_CHECK();
   return 0;
 }
@@ -1731,15 +1820,19 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
       hipLaunchKernelGGL(k_shadow_cull<false>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
           S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
-    if (S.all_opaque && !S.has_curves)
-      hipLaunchKernelGGL(k_shadow_anyhit, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
-    else if (S.has_curves)
-      hipLaunchKernelGGL(k_shadow_trace<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
-    else
-      hipLaunchKernelGGL(k_shadow_trace<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-          S, (const DShadowRay *) squeue, s_accum, cnt, count_events, trav_tune());
+    if (S.all_opaque && !S.has_curves) {
+      if (count_events)
+        hipLaunchKernelGGL(k_shadow_anyhit<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+            S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
+      else
+        hipLaunchKernelGGL(k_shadow_anyhit<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
+            S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
+    } else {
+#define FJ_LAUNCH_SHADOW(CURVES, COUNT) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune())
+      if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true); else FJ_LAUNCH_SHADOW(true, false); }
+      else { if (count_events) FJ_LAUNCH_SHADOW(false, true); else FJ_LAUNCH_SHADOW(false, false); }
+#undef FJ_LAUNCH_SHADOW
+    }
     LAUNCH_CHECK();
   }
   return 0;
@@ -1756,6 +1849,10 @@ int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_ti
   LAUNCH_CHECK();
 #ifdef FJ_EXP_COUNT_FB
   dump_fb();
+#endif
+#ifdef FJ_EXP_SLAB_VALIDATE
+  { unsigned long long v[3] = {0, 0, 0}; (void) hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_slab_lost), 8); (void) hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_slab_extra), 8); (void) hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(g_slab_tests), 8);
+    fprintf(stderr, "slab32 validate: lost %llu extra %llu of %llu box tests\n", v[0], v[1], v[2]); }
 #endif
   return 0;
 }

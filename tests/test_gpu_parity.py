@@ -37,7 +37,11 @@ def prepare(text):
 def render_both(text, threads=None):
     sp, rd = prepare(text)
     gs = gpu.Scene(sp)
+    gs.set_option("count_nodes", 1)        # the counting instantiation of the traversal kernels
     fb, st = gs.render_frame(rd)
+    gs.set_option("count_nodes", 0)        # ... and the production one: same pixels
+    fb2, _ = gs.render_frame(rd)
+    assert np.array_equal(fb, fb2) or float(rel_err(fb, fb2).max()) <= 1e-6
     gs.close()
     osc = oracle_ffi.OracleScene(sp)
     ref, rc = osc.render(rd, threads=threads)
@@ -93,6 +97,7 @@ def test_trace_bit_exact_against_reference_grid_vectors(asset_dir, golden_dir):
     sp, _ = prepare(tg._mesh_scene(asset_dir))
     rays = np.load(os.path.join(golden_dir, "mesh_trace_rays.npy"))
     gs = gpu.Scene(sp)
+    gs.set_option("count_nodes", 1)
     t, ids, uv, st = gs.trace(0, rays)
     gs.close()
     assert np.array_equal(t, vec["grid_t"])
