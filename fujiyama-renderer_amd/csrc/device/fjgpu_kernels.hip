@@ -1677,54 +1677,54 @@ __global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene 
 
 // ------------------------------------------------------------------ k_resolve
 // reconstruct_image + apply_pixel_filter (src/fj_renderer.cc:939-995) with
-// eval_gaussian (src/fj_filter.cc:49-58): f32 accumulators += f64 products, in
-// the reference's window order (y-major).
+// eval_gaussian (src/fj_filter.cc:49-58).  One wave per pixel: the lanes take the
+// (rate + 2 margin)^2 samples of the pixel's window in row-major order, so a load
+// instruction reads whole window rows (npx_x * 16 B contiguous each) instead of 64
+// addresses 128 B apart (the one-lane-per-pixel version spent 17.6 ms per C3 frame on L2
+// requests, this one is bandwidth bound).  The weighted sums are reduced in f64 by a
+// butterfly and rounded to f32 once; the reference adds the same f64 products into f32
+// accumulators one by one -- the difference is the accumulators' rounding (~1e-7).
 __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileDesc *tiles,
     const double *s_uv, const float *s_accum, float *fb)
 {
   const TileDesc T = tiles[blockIdx.y];
   const int tw = T.xmax - T.xmin, th = T.ymax - T.ymin;
-  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  const int k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);     // pixel of this wave
   if (k >= tw * th) return;
+  const unsigned lane = __lane_id();
   const int px = T.xmin + k % tw, py = T.ymin + k / tw;
   const size_t base = (size_t) T.sample_offset + (size_t) (py - T.ymin) * rp.rate_y * T.nx + (size_t) (px - T.xmin) * rp.rate_x;
-  float pix[4] = {0.f, 0.f, 0.f, 0.f};
-  float wgt_sum = 0.f;
-  // Lanes are pixels, `rate_x` samples (128 B) apart: a lane owns whole cache lines of its
-  // window rows.  Four samples (64 B of uv + 64 B of RGBA) are loaded back to back so that a
-  // line is fetched once, not once per sample after being evicted by the other lanes' lines.
-  for (int sy = 0; sy < rp.npx_y; sy++)
-    for (int sx0 = 0; sx0 < rp.npx_x; sx0 += 4) {
-      const size_t s0 = base + (size_t) sy * T.nx + sx0;
-      double2 uv[4];
-      float4 dd[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const size_t s = s0 + (sx0 + j < rp.npx_x ? j : 0);
-        uv[j] = reinterpret_cast<const double2 *>(s_uv)[s];
-        dd[j] = reinterpret_cast<const float4 *>(s_accum)[s];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (sx0 + j >= rp.npx_x) break;
-        const double u = uv[j].x, v = uv[j].y;
-        const float4 d = dd[j];
-        const double filtx = rp.xres * u - (px + .5);
-        const double filty = rp.yres * (1 - v) - (py + .5);
-        const double xx = 2 * filtx / rp.fw;
-        const double yy = 2 * filty / rp.fh;
-        const double wgt = exp(-2 * (xx * xx + yy * yy));
-        pix[0] = (float) (pix[0] + wgt * (double) d.x);
-        pix[1] = (float) (pix[1] + wgt * (double) d.y);
-        pix[2] = (float) (pix[2] + wgt * (double) d.z);
-        pix[3] = (float) (pix[3] + wgt * (double) d.w);
-        wgt_sum = (float) (wgt_sum + wgt);
-      }
-    }
-  const float inv_sum = 1.f / wgt_sum;
-  float4 out;
-  out.x = pix[0] * inv_sum; out.y = pix[1] * inv_sum; out.z = pix[2] * inv_sum; out.w = pix[3] * inv_sum;
-  reinterpret_cast<float4 *>(fb)[(size_t) py * rp.xres + px] = out;
+  const int nwin = rp.npx_x * rp.npx_y;
+  double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, wsum = 0;
+  for (int w = (int) lane; w < nwin; w += 64) {
+    const int sy = w / rp.npx_x, sx = w - sy * rp.npx_x;
+    const size_t s = base + (size_t) sy * T.nx + sx;
+    const double2 uv = reinterpret_cast<const double2 *>(s_uv)[s];
+    const float4 d = reinterpret_cast<const float4 *>(s_accum)[s];
+    const double filtx = rp.xres * uv.x - (px + .5);
+    const double filty = rp.yres * (1 - uv.y) - (py + .5);
+    const double xx = 2 * filtx / rp.fw;
+    const double yy = 2 * filty / rp.fh;
+    const double wgt = exp(-2 * (xx * xx + yy * yy));
+    acc0 += wgt * (double) d.x;
+    acc1 += wgt * (double) d.y;
+    acc2 += wgt * (double) d.z;
+    acc3 += wgt * (double) d.w;
+    wsum += wgt;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    acc0 += __shfl_xor(acc0, off);
+    acc1 += __shfl_xor(acc1, off);
+    acc2 += __shfl_xor(acc2, off);
+    acc3 += __shfl_xor(acc3, off);
+    wsum += __shfl_xor(wsum, off);
+  }
+  if (lane == 0) {
+    const float inv_sum = 1.f / (float) wsum;
+    float4 out;
+    out.x = (float) acc0 * inv_sum; out.y = (float) acc1 * inv_sum; out.z = (float) acc2 * inv_sum; out.w = (float) acc3 * inv_sum;
+    reinterpret_cast<float4 *>(fb)[(size_t) py * rp.xres + px] = out;
+  }
 }
 
 // ----------------------------------------------------------- host launchers
@@ -1844,7 +1844,7 @@ static void dump_fb() { unsigned long long v = 0; hipMemcpyFromSymbol(&v, HIP_SY
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
     const double *s_uv, const float *s_accum, float *fb)
 {
-  dim3 grid((max_tile_pixels + BLOCK - 1) / BLOCK, n_tiles);
+  dim3 grid((max_tile_pixels + (BLOCK / 64) - 1) / (BLOCK / 64), n_tiles);   // one wave per pixel
   hipLaunchKernelGGL(k_resolve, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, s_accum, fb);
   LAUNCH_CHECK();
 #ifdef FJ_EXP_COUNT_FB
