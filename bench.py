@@ -213,8 +213,18 @@ def main():
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
         achieved = alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
+        # HBM traffic of the same kernels from the PMC passes committed under profiles/
+        # (rocprofv3 cannot run inside this process): per frame, spread over this run's launches
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tp) and args.workload == "dragon" and not (args.mesh or args.res or args.spp) and world == 1:
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_bytes_per_frame"] * len(stats) / nl if nl else None
+            traffic_src = "profiles/r01_traffic.json"
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src,
                 "kernel": "k_trace_closest+k_shadow", "launches": int(nl),
                 "avg_launch_ms": tms / nl if nl else None,
                 "algorithmic_bytes_per_launch": alg / nl if nl else None,

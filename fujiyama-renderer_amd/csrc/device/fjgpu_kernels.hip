@@ -1762,7 +1762,7 @@ static TravTune trav_tune()
   static TravTune t = {0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
-    t.refill = env("FJGPU_TRAV_REFILL", 16);
+    t.refill = env("FJGPU_TRAV_REFILL", 24);
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 128);
     if (t.refill < 1) t.refill = 1;
