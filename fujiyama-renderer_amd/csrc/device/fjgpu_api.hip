@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <string>
@@ -125,7 +126,11 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   *out = nullptr;
   fjgpu::HostScene hs;
   std::string err;
+  const auto t_build0 = std::chrono::steady_clock::now();
   const int be = fjgpu::BuildHostScene(desc, &hs, &err);
+  if (getenv("FJGPU_VERBOSE"))
+    fprintf(stderr, "fjgpu: host scene build (BLAS, transforms, lights) %.3f s\n",
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
   if (be) return fail(be, err);
   for (int i = 0; i < desc->n_shaders; i++) {
     const int t = desc->shaders[i].type;

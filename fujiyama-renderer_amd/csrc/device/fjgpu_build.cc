@@ -16,9 +16,13 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace fjgpu {
@@ -26,6 +30,28 @@ namespace fjgpu {
 namespace {
 
 const double ACC_PADDING = .0001;     // Accelerator PADDING, src/fj_accelerator.cc:13
+
+// chunked parallel loop over [0, n) on the host threads (scene preparation only)
+template <class F> void ParallelFor(size_t n, F fn)
+{
+  const size_t hc = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nt = std::min<size_t>(std::min<size_t>(hc, 64), n / 65536 + 1);
+  if (nt <= 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([=]() { fn(n * t / nt, n * (t + 1) / nt); });
+  for (auto &x : th) x.join();
+}
+
+struct StageTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  const bool on = getenv("FJGPU_VERBOSE") != nullptr;
+  void lap(const char *what, int n)
+  {
+    const auto t1 = std::chrono::steady_clock::now();
+    if (on && n > 100000) fprintf(stderr, "fjgpu:   %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 // f64 -> f32 rounded toward -inf / +inf, then one extra ulp outward
 inline float down2(double v)
@@ -47,9 +73,22 @@ struct Node2 {                 // binary node of the SAH build, before the 4-wid
   uint32_t lc, rc;
 };
 
+// index allocator: a thread takes 1024 consecutive slots of a shared array at a time
+struct ChunkAlloc {
+  std::atomic<uint32_t> *next;
+  uint32_t cur = 0, end = 0;
+  explicit ChunkAlloc(std::atomic<uint32_t> *n) : next(n) {}
+  uint32_t get()
+  {
+    if (cur == end) { cur = next->fetch_add(1024); end = cur + 1024; }
+    return cur++;
+  }
+};
+
 struct Builder {
   std::vector<PrimRef> prims;
-  std::vector<Node2> nodes;
+  std::vector<PrimRef> scratch;            // out-of-place partition of the large top nodes
+  std::unique_ptr<Node2[]> nodes;          // uninitialised storage, slots handed out in chunks
   std::atomic<uint32_t> next_node;
   std::atomic<int> max_depth;
   int max_leaf;
@@ -66,17 +105,44 @@ struct Builder {
 
   uint32_t leaf_ref(int begin, int count) const { return FJ_LEAF_FLAG | ((uint32_t) begin << 3) | (uint32_t) (count - 1); }
 
-  // returns child ref for range [begin,end); writes its bounds into mn/mx
-  uint32_t build(int begin, int end, int depth, int par_depth, float *mn, float *mx)
+  enum { NB = 16, BIG = 1 << 18 };
+  struct Bins {
+    int cnt[NB];
+    float bmn[NB][3], bmx[NB][3];
+    void clear() { for (int b = 0; b < NB; b++) { cnt[b] = 0; for (int k = 0; k < 3; k++) { bmn[b][k] = FLT_MAX; bmx[b][k] = -FLT_MAX; } } }
+    void merge(const Bins &o) { for (int b = 0; b < NB; b++) { cnt[b] += o.cnt[b]; grow(bmn[b], bmx[b], o.bmn[b], o.bmx[b]); } }
+  };
+  static int bin_of(const PrimRef &p, int axis, float lo, float scale)
+  {
+    const int b = (int) ((p.c[axis] - lo) * scale);
+    return b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+  }
+
+  // returns child ref for range [begin,end); writes its bounds into mn/mx.
+  // Nodes of >= BIG primitives near the top run their passes on all host threads.
+  uint32_t build(int begin, int end, int depth, int par_depth, float *mn, float *mx, ChunkAlloc &alloc)
   {
     const int n = end - begin;
+    const bool big = par_depth > 0 && n >= BIG;
     for (int k = 0; k < 3; k++) { mn[k] = FLT_MAX; mx[k] = -FLT_MAX; }
     float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = begin; i < end; i++) {
-      grow(mn, mx, prims[i].bmin, prims[i].bmax);
-      grow(cmn, cmx, prims[i].c, prims[i].c);
+    if (big) {
+      std::mutex mu;
+      ParallelFor((size_t) n, [&](size_t i0, size_t i1) {
+        float a[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, b[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        float c[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, d[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (size_t i = begin + i0; i < begin + i1; i++) { grow(a, b, prims[i].bmin, prims[i].bmax); grow(c, d, prims[i].c, prims[i].c); }
+        std::lock_guard<std::mutex> g(mu);
+        grow(mn, mx, a, b);
+        grow(cmn, cmx, c, d);
+      });
+    } else {
+      for (int i = begin; i < end; i++) {
+        grow(mn, mx, prims[i].bmin, prims[i].bmax);
+        grow(cmn, cmx, prims[i].c, prims[i].c);
+      }
     }
-    int d = max_depth.load();
+    int d = max_depth.load(std::memory_order_relaxed);
     while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
     if (n <= max_leaf) {
       // leaves of <= 4 prims are always accepted at or below max_leaf
@@ -93,24 +159,37 @@ struct Builder {
     const double cap = std::ldexp((double) max_leaf, std::max(0, budget - 1));
     const bool force_median = (double) n > cap * 0.5 && budget < 30;
     if (ext > 0 && !force_median) {
-      const int NB = 16;
-      int cnt[NB];
-      float bmn[NB][3], bmx[NB][3];
-      for (int b = 0; b < NB; b++) { cnt[b] = 0; for (int k = 0; k < 3; k++) { bmn[b][k] = FLT_MAX; bmx[b][k] = -FLT_MAX; } }
+      Bins B;
+      B.clear();
       const float scale = NB * (1.f - 1e-6f) / ext;
-      for (int i = begin; i < end; i++) {
-        int b = (int) ((prims[i].c[axis] - cmn[axis]) * scale);
-        b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-        cnt[b]++;
-        grow(bmn[b], bmx[b], prims[i].bmin, prims[i].bmax);
+      const float lo = cmn[axis];
+      if (big) {
+        std::mutex mu;
+        ParallelFor((size_t) n, [&](size_t i0, size_t i1) {
+          Bins L;
+          L.clear();
+          for (size_t i = begin + i0; i < begin + i1; i++) {
+            const int b = bin_of(prims[i], axis, lo, scale);
+            L.cnt[b]++;
+            grow(L.bmn[b], L.bmx[b], prims[i].bmin, prims[i].bmax);
+          }
+          std::lock_guard<std::mutex> g(mu);
+          B.merge(L);
+        });
+      } else {
+        for (int i = begin; i < end; i++) {
+          const int b = bin_of(prims[i], axis, lo, scale);
+          B.cnt[b]++;
+          grow(B.bmn[b], B.bmx[b], prims[i].bmin, prims[i].bmax);
+        }
       }
       float rarea[NB];
       int rcnt[NB];
       float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
       int c = 0;
       for (int b = NB - 1; b > 0; b--) {
-        if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
-        c += cnt[b];
+        if (B.cnt[b]) grow(amn, amx, B.bmn[b], B.bmx[b]);
+        c += B.cnt[b];
         rcnt[b] = c;
         rarea[b] = c ? half_area(amn, amx) : 0.f;
       }
@@ -119,8 +198,8 @@ struct Builder {
       float best = FLT_MAX;
       int best_b = -1;
       for (int b = 0; b < NB - 1; b++) {
-        if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
-        c += cnt[b];
+        if (B.cnt[b]) grow(amn, amx, B.bmn[b], B.bmx[b]);
+        c += B.cnt[b];
         if (c == 0 || rcnt[b + 1] == 0) continue;
         const float cost = half_area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
         if (cost < best) { best = cost; best_b = b; }
@@ -129,14 +208,36 @@ struct Builder {
         // leaf cost vs split cost (traversal cost 1 node ~ 1.2 triangle tests)
         const float parent_area = half_area(mn, mx);
         if (n <= max_leaf && best + 1.2f * parent_area >= parent_area * n) return leaf_ref(begin, n);
-        const float split = cmn[axis] + (best_b + 1) / scale;
-        PrimRef *m = std::partition(&prims[begin], &prims[begin] + n, [&](const PrimRef &p) {
-          int b = (int) ((p.c[axis] - cmn[axis]) * scale);
-          b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-          return b <= best_b;
-        });
-        (void) split;
-        mid = (int) (m - &prims[0]);
+        if (big) {
+          // out-of-place parallel partition: per-chunk counts, prefix, scatter, copy back
+          int nleft = 0;
+          for (int b = 0; b <= best_b; b++) nleft += B.cnt[b];
+          const size_t nt = 64;
+          std::vector<int> lcount(nt + 1, 0);
+          ParallelFor(nt, [&](size_t t0, size_t t1) {
+            for (size_t t = t0; t < t1; t++) {
+              int cnt = 0;
+              for (size_t i = begin + (size_t) n * t / nt; i < begin + (size_t) n * (t + 1) / nt; i++) cnt += bin_of(prims[i], axis, lo, scale) <= best_b;
+              lcount[t + 1] = cnt;
+            }
+          });
+          for (size_t t = 0; t < nt; t++) lcount[t + 1] += lcount[t];
+          std::vector<std::thread> th;
+          for (size_t t = 0; t < nt; t++) th.emplace_back([&, t]() {
+            const size_t i0 = begin + (size_t) n * t / nt, i1 = begin + (size_t) n * (t + 1) / nt;
+            size_t l = begin + lcount[t], r = begin + nleft + ((i0 - begin) - lcount[t]);
+            for (size_t i = i0; i < i1; i++) {
+              if (bin_of(prims[i], axis, lo, scale) <= best_b) scratch[l++] = prims[i];
+              else scratch[r++] = prims[i];
+            }
+          });
+          for (auto &x : th) x.join();
+          ParallelFor((size_t) n, [&](size_t i0, size_t i1) { std::memcpy(&prims[begin + i0], &scratch[begin + i0], (i1 - i0) * sizeof(PrimRef)); });
+          mid = begin + nleft;
+        } else {
+          PrimRef *m = std::partition(&prims[begin], &prims[begin] + n, [&](const PrimRef &p) { return bin_of(p, axis, lo, scale) <= best_b; });
+          mid = (int) (m - &prims[0]);
+        }
       }
     }
     if (mid <= begin || mid >= end) {
@@ -146,16 +247,16 @@ struct Builder {
           [axis](const PrimRef &a, const PrimRef &b) { return a.c[axis] < b.c[axis]; });
     }
 
-    const uint32_t me = next_node.fetch_add(1);
+    const uint32_t me = alloc.get();
     float lmn[3], lmx[3], rmn[3], rmx[3];
     uint32_t lc, rc;
     if (par_depth > 0 && n > 20000) {
-      std::thread th([&]() { lc = build(begin, mid, depth + 1, par_depth - 1, lmn, lmx); });
-      rc = build(mid, end, depth + 1, par_depth - 1, rmn, rmx);
+      std::thread th([&]() { ChunkAlloc a2(&next_node); lc = build(begin, mid, depth + 1, par_depth - 1, lmn, lmx, a2); });
+      rc = build(mid, end, depth + 1, par_depth - 1, rmn, rmx, alloc);
       th.join();
     } else {
-      lc = build(begin, mid, depth + 1, 0, lmn, lmx);
-      rc = build(mid, end, depth + 1, 0, rmn, rmx);
+      lc = build(begin, mid, depth + 1, 0, lmn, lmx, alloc);
+      rc = build(mid, end, depth + 1, 0, rmn, rmx, alloc);
     }
     Node2 &nd = nodes[me];
     for (int k = 0; k < 3; k++) { nd.lmin[k] = lmn[k]; nd.lmax[k] = lmx[k]; nd.rmin[k] = rmn[k]; nd.rmax[k] = rmx[k]; }
@@ -167,9 +268,11 @@ struct Builder {
   // child with the largest surface area is replaced by its own two children until four
   // slots are filled (or only leaves remain).  Returns the DNode index; *need = worst-case
   // traversal stack entries below this node (k-1 siblings pushed, deepest child first).
+  // Subtrees near the top are collapsed on their own threads.
   struct Cand { float mn[3], mx[3]; uint32_t ref; };
-  std::vector<DNode> wide;
-  uint32_t collapse(uint32_t ref2, int *need)
+  std::unique_ptr<DNode[]> wide;
+  std::atomic<uint32_t> next_wide;
+  uint32_t collapse(uint32_t ref2, int *need, int par_depth, ChunkAlloc &alloc)
   {
     Cand c[4];
     int k = 2;
@@ -194,17 +297,18 @@ struct Builder {
     }
     // larger children first: the any-hit kernel visits hit children in slot order
     std::sort(c, c + k, [](const Cand &a, const Cand &b) { return half_area(a.mn, a.mx) > half_area(b.mn, b.mx); });
-    const uint32_t me = (uint32_t) wide.size();
-    wide.emplace_back();
-    int worst = 0;
+    const uint32_t me = alloc.get();
+    int nd[4] = {0, 0, 0, 0};
     uint32_t child[4];
+    std::vector<std::thread> th;
     for (int i = 0; i < 4; i++) {
       if (i >= k) { child[i] = FJ_NO_CHILD; continue; }
       if (c[i].ref & FJ_LEAF_FLAG) { child[i] = c[i].ref; continue; }
-      int nd = 0;
-      child[i] = collapse(c[i].ref, &nd);
-      worst = std::max(worst, nd);
+      if (par_depth > 0) th.emplace_back([&, i]() { ChunkAlloc a2(&next_wide); child[i] = collapse(c[i].ref, &nd[i], par_depth - 1, a2); });
+      else child[i] = collapse(c[i].ref, &nd[i], 0, alloc);
     }
+    for (auto &x : th) x.join();
+    const int worst = std::max(std::max(nd[0], nd[1]), std::max(nd[2], nd[3]));
     DNode &w = wide[me];
     for (int i = 0; i < 4; i++) {
       for (int a = 0; a < 3; a++) {
@@ -229,7 +333,8 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
   Builder b;
   b.prims.swap(refs);
   const int n = (int) b.prims.size();
-  b.nodes.resize(n > 1 ? n : 1);
+  // node slots are handed out in chunks of 1024 per thread: capacity = worst count + slack
+  b.nodes.reset(new Node2[(size_t) std::max(n, 1) + 1024 * 132]);
   b.next_node = 0;
   b.max_depth = 0;
   b.max_leaf = FJ_MAX_LEAF_PRIMS;
@@ -237,19 +342,32 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
   if (n == 0) {
     ps->root = FJ_LEAF_FLAG;   // never dereferenced: n_prims == 0 is checked first
   } else {
-    ps->root = b.build(0, n, 0, 4, mn, mx);
+    // task-parallel over the top levels: 2^par_depth subtrees on their own threads, and
+    // the passes of the largest nodes on all of them
+    int par_depth = 0;
+    for (unsigned hc = std::max(1u, std::thread::hardware_concurrency()); hc > 1 && par_depth < 7; hc >>= 1) par_depth++;
+    if (n >= Builder::BIG) b.scratch.resize(b.prims.size());
+    StageTimer tb;
+    ChunkAlloc alloc(&b.next_node);
+    ps->root = b.build(0, n, 0, par_depth, mn, mx, alloc);
+    tb.lap("binned SAH binary build", n);
   }
-  b.nodes.resize(b.next_node.load() ? b.next_node.load() : 1);
+  StageTimer tm;
   ps->stack_need = 0;
+  const int cpar = n > 200000 ? 3 : 0;
+  const size_t wide_cap = (size_t) b.next_node.load() + 1024 * (cpar ? 128 : 2);
+  b.wide.reset(new DNode[wide_cap]);
+  b.next_wide = 0;
   if (n > 0 && !(ps->root & FJ_LEAF_FLAG)) {
-    b.wide.reserve(b.nodes.size() / 2 + 1);
-    ps->root = b.collapse(ps->root, &ps->stack_need);
+    ChunkAlloc alloc(&b.next_wide);
+    ps->root = b.collapse(ps->root, &ps->stack_need, cpar, alloc);
   }
-  if (b.wide.empty()) b.wide.emplace_back(DNode());
-  ps->nodes.swap(b.wide);
+  tm.lap("collapse to 4-wide", n);
+  ps->nodes.n = std::max<size_t>(1, std::min<size_t>(wide_cap, b.next_wide.load()));
+  ps->nodes.p = std::move(b.wide);
   ps->max_depth = b.max_depth;
   ps->prim_ids.resize(n);
-  for (int i = 0; i < n; i++) ps->prim_ids[i] = b.prims[i].id;
+  ParallelFor((size_t) n, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) ps->prim_ids[i] = b.prims[i].id; });
   ps->n_prims = n;
 }
 
@@ -263,37 +381,49 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
   if (m.velocity) { *err = "mesh velocity (motion blur) is not on the device path yet"; return FJGPU_EUNSUPPORTED; }
   if (m.n_faces > (1 << 28)) { *err = "mesh too large"; return FJGPU_EINVAL; }
   for (int k = 0; k < 3; k++) { ps->bounds[k] = m.bounds[k] - ACC_PADDING; ps->bounds[3 + k] = m.bounds[3 + k] + ACC_PADDING; }
+  StageTimer tm;
   std::vector<PrimRef> refs(m.n_faces);
-  for (int f = 0; f < m.n_faces; f++) {
-    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (int k = 0; k < 3; k++) {
-      const int p = m.indices[3 * f + k];
-      if (p < 0 || p >= m.n_points) { *err = "mesh index out of range"; return FJGPU_EINVAL; }
-      for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], m.P[3 * p + c]); mx[c] = std::max(mx[c], m.P[3 * p + c]); }
+  std::atomic<int> bad(0);
+  ParallelFor((size_t) m.n_faces, [&](size_t f0, size_t f1) {
+    for (size_t f = f0; f < f1; f++) {
+      double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+      for (int k = 0; k < 3; k++) {
+        const int p = m.indices[3 * f + k];
+        if (p < 0 || p >= m.n_points) { bad = 1; return; }
+        for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], m.P[3 * p + c]); mx[c] = std::max(mx[c], m.P[3 * p + c]); }
+      }
+      PrimRef &r = refs[f];
+      for (int c = 0; c < 3; c++) { r.bmin[c] = down2(mn[c]); r.bmax[c] = up2(mx[c]); r.c[c] = (float) (.5 * (mn[c] + mx[c])); }
+      r.id = (uint32_t) f;
     }
-    PrimRef &r = refs[f];
-    for (int c = 0; c < 3; c++) { r.bmin[c] = down2(mn[c]); r.bmax[c] = up2(mx[c]); r.c[c] = (float) (.5 * (mn[c] + mx[c])); }
-    r.id = (uint32_t) f;
-  }
+  });
+  if (bad) { *err = "mesh index out of range"; return FJGPU_EINVAL; }
+  tm.lap("primitive boxes", m.n_faces);
   for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
   BuildBlas(ps, refs);
+  tm.lap("BLAS total", m.n_faces);
   // pre-gathered vertices in leaf order; as f32 when that loses nothing (meshes read from
   // PLY files carry f32 coordinates): half the bytes per triangle test, identical operands
-  bool f32_exact = true;
-  for (int i = 0; i < m.n_points * 3 && f32_exact; i++) f32_exact = (double) (float) m.P[i] == m.P[i];
-  if (getenv("FJGPU_NO_F32_TRIS")) f32_exact = false;
+  std::atomic<int> inexact(0);
+  ParallelFor((size_t) m.n_points * 3, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) if ((double) (float) m.P[i] != m.P[i]) { inexact = 1; return; }
+  });
+  const bool f32_exact = !inexact && !getenv("FJGPU_NO_F32_TRIS");
   if (f32_exact) ps->tri_verts32.resize((size_t) ps->n_prims * 9);
   else ps->tri_verts.resize((size_t) ps->n_prims * 9);
-  for (int i = 0; i < ps->n_prims; i++) {
-    const int f = (int) ps->prim_ids[i];
-    for (int k = 0; k < 3; k++) {
-      const int p = m.indices[3 * f + k];
-      for (int c = 0; c < 3; c++) {
-        if (f32_exact) ps->tri_verts32[(size_t) i * 9 + 3 * k + c] = (float) m.P[3 * p + c];
-        else ps->tri_verts[(size_t) i * 9 + 3 * k + c] = m.P[3 * p + c];
+  ParallelFor((size_t) ps->n_prims, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
+      const int f = (int) ps->prim_ids[i];
+      for (int k = 0; k < 3; k++) {
+        const int p = m.indices[3 * f + k];
+        for (int c = 0; c < 3; c++) {
+          if (f32_exact) ps->tri_verts32[i * 9 + 3 * k + c] = (float) m.P[3 * p + c];
+          else ps->tri_verts[i * 9 + 3 * k + c] = m.P[3 * p + c];
+        }
       }
     }
-  }
+  });
+  tm.lap("triangle gather", m.n_faces);
   return 0;
 }
 

@@ -5,14 +5,23 @@
 
 #include "fjgpu_types.h"
 
+#include <memory>
 #include <string>
 #include <vector>
 
 namespace fjgpu {
 
+// BLAS node array (uninitialised storage filled by the parallel collapse)
+struct NodeArray {
+  std::unique_ptr<DNode[]> p;
+  size_t n = 0;
+  const DNode *data() const { return p.get(); }
+  size_t size() const { return n; }
+};
+
 struct HostPrimSet {
   int type;
-  std::vector<DNode> nodes;
+  NodeArray nodes;
   std::vector<double> tri_verts;      // mesh: [n][9]  (empty when tri_verts32 is used)
   std::vector<float> tri_verts32;     // mesh: [n][9]  all coordinates exactly representable in f32
   std::vector<uint32_t> prim_ids;
