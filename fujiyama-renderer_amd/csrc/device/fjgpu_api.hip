@@ -198,6 +198,12 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
   e |= M.upload(hs.group_instances.data(), hs.group_instances.size(), &S.group_instances);
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
+  e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
+  S.cam_xform = nullptr;
+  if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
+  S.has_motion = hs.xforms.empty() ? 0 : 1;
+  S.pad_ = 0;
+  S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
   e |= M.upload(hs.light_samples.data(), hs.light_samples.size(), &S.light_samples);
   if (e) return fail(FJGPU_ENOMEM, "device allocation / upload failed while creating the scene");
@@ -388,6 +394,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   const double aspect = r->xres / (double) r->yres;
   S.cam_uv_size[1] = fjgpu::CameraUvSizeY(sc->cam_fov);
   S.cam_uv_size[0] = S.cam_uv_size[1] * aspect;
+  S.time_tab = sc->d_tim; S.time_start = r->time_start; S.time_end = r->time_end;
 
   GenParams gp;
   gp.rate_x = r->rate_x; gp.rate_y = r->rate_y; gp.margin_x = margin[0]; gp.margin_y = margin[1];

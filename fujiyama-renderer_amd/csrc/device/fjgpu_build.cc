@@ -451,10 +451,11 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
     DInstance &o = out->instances[i];
     std::memset(&o, 0, sizeof(o));
     const fj_xform_desc &x = s.xform;
-    if (x.n_translate != 1 || x.n_rotate != 1 || x.n_scale != 1) {
-      *err = "time-sampled object transforms (motion blur) are not on the device path yet";
-      return FJGPU_EUNSUPPORTED;
-    }
+    for (const int cnt : {x.n_translate, x.n_rotate, x.n_scale})
+      if (cnt < 1 || cnt > FJ_MAX_XFORM_SAMPLES) { *err = "transform sample count out of range"; return FJGPU_EINVAL; }
+    const bool is_static = x.n_translate == 1 && x.n_rotate == 1 && x.n_scale == 1;
+    o.xform = -1;
+    if (!is_static) { o.xform = (int) out->xforms.size(); out->xforms.push_back(x); }
     double M[16], Minv[16];
     MakeTransform(x, 0, M, Minv);
     std::memcpy(o.M, M, sizeof(o.M));
@@ -466,17 +467,40 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
       if (s.primset < 0 || s.primset >= d->n_curves) { *err = "instance curve index out of range"; return FJGPU_EINVAL; }
       o.primset = d->n_meshes + s.primset;
     } else { *err = "unknown primitive set type"; return FJGPU_EINVAL; }
-    // ObjectInstance::merge_sampled_bounds (reference src/fj_object_instance.cc:313-356): the
-    // world box is built from T, R and the ABSOLUTE scale.  With a negative scale it is
-    // mirrored and no longer encloses the geometry -- and the reference's instance BVH
-    // culls with it, so rays that miss this box miss the instance there.  The device tests
-    // the same box with the same BoxRayIntersect arithmetic.
+    // ObjectInstance::merge_sampled_bounds (reference src/fj_object_instance.cc:313-356).
+    // The world box is built from T, R and the largest ABSOLUTE scale over the samples.  With
+    // a negative scale it is mirrored and no longer encloses the geometry -- and the
+    // reference's instance BVH culls with it, so rays that miss this box miss the instance
+    // there.  The device tests the same box with the same BoxRayIntersect arithmetic
+    // (DESIGN.md 4).  Time-sampled transforms: a rotating object's box is first replaced by
+    // the cube around its bounding sphere, then the boxes of all translate samples are
+    // merged (the rotate sample is picked with the TRANSLATE index; slots past the rotate
+    // count hold zero samples, as in the reference's PropertySampleList).
     {
-      fj_xform_desc ax = x;
-      for (int k = 0; k < 3; k++) ax.scale[0].v[k] = std::fabs(x.scale[0].v[k]);
-      double Ma[16], Mai[16];
-      MakeTransform(ax, 0, Ma, Mai);
-      TransformBounds(Ma, out->primsets[o.primset].bounds, o.wbounds);
+      double ob[6];
+      std::memcpy(ob, out->primsets[o.primset].bounds, sizeof(ob));
+      if (x.n_rotate > 1) {
+        const double dx = ob[3] - ob[0], dy = ob[4] - ob[1], dz = ob[5] - ob[2];
+        const double half_diagonal = .5 * std::sqrt(dx * dx + dy * dy + dz * dz);      // Length(Diagonal())
+        const double c[3] = {(ob[0] + ob[3]) / 2, (ob[1] + ob[4]) / 2, (ob[2] + ob[5]) / 2};   // Centroid()
+        for (int k = 0; k < 3; k++) { ob[k] = c[k] - half_diagonal; ob[3 + k] = c[k] + half_diagonal; }
+      }
+      double S[3] = {0, 0, 0};
+      for (int i = 0; i < x.n_scale; i++)
+        for (int k = 0; k < 3; k++) S[k] = std::max(S[k], std::fabs(x.scale[i].v[k]));
+      const double big = 1.7976931348623157e308;
+      double mb[6] = {big, big, big, -big, -big, -big};
+      for (int i = 0; i < x.n_translate; i++) {
+        fj_xform_desc ax = x;
+        ax.n_translate = ax.n_rotate = ax.n_scale = 1;
+        ax.translate[0] = x.translate[i];
+        for (int k = 0; k < 3; k++) { ax.rotate[0].v[k] = i < x.n_rotate ? x.rotate[i].v[k] : 0.; ax.scale[0].v[k] = S[k]; }
+        double Ma[16], Mai[16], sb[6];
+        MakeTransform(ax, 0, Ma, Mai);
+        TransformBounds(Ma, ob, sb);
+        for (int k = 0; k < 3; k++) { mb[k] = std::min(mb[k], sb[k]); mb[3 + k] = std::max(mb[3 + k], sb[3 + k]); }
+      }
+      std::memcpy(o.wbounds, mb, sizeof(mb));
     }
     o.n_shaders = s.n_shaders;
     for (int k = 0; k < FJ_MAX_SHADING_GROUPS; k++) {
@@ -565,10 +589,10 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
   }
 
   const fj_xform_desc &cx = d->camera.xform;
-  if (cx.n_translate != 1 || cx.n_rotate != 1 || cx.n_scale != 1) {
-    *err = "time-sampled camera transforms (motion blur) are not on the device path yet";
-    return FJGPU_EUNSUPPORTED;
-  }
+  for (const int cnt : {cx.n_translate, cx.n_rotate, cx.n_scale})
+    if (cnt < 1 || cnt > FJ_MAX_XFORM_SAMPLES) { *err = "camera transform sample count out of range"; return FJGPU_EINVAL; }
+  out->cam_static = cx.n_translate == 1 && cx.n_rotate == 1 && cx.n_scale == 1;
+  out->cam_xform = cx;      // time-sampled: Camera::GetRay evaluates it per sample (k_gen_camera)
   double M[16], Minv[16];
   MakeTransform(cx, 0, M, Minv);
   std::memcpy(out->cam_M, M, sizeof(out->cam_M));

@@ -46,6 +46,9 @@ struct HostScene {
   std::vector<DGroup> groups;
   std::vector<int32_t> group_instances;
   std::vector<fj_shader_desc> shaders;
+  std::vector<fj_xform_desc> xforms;          // time-sampled instance transforms (DInstance.xform)
+  fj_xform_desc cam_xform;                    // valid when cam_static is false
+  bool cam_static;
   std::vector<DLightSample> light_samples;
   int n_meshes;
   int target_group;

@@ -21,6 +21,7 @@
 
 #include "fjgpu_types.h"
 #include "fjgpu_kernels.h"
+#include "fjgpu_xform_math.h"
 
 #define BLOCK 256
 
@@ -90,6 +91,26 @@ __device__ __forceinline__ bool slab_f32box(const float *bmin, const float *bmax
 __device__ __forceinline__ bool has_negative_zero(V3 d)
 {
   return (d.x == 0 && signbit(d.x)) || (d.y == 0 && signbit(d.y)) || (d.z == 0 && signbit(d.z));
+}
+
+// ---- time-sampled transforms (motion blur).  The sample's time is draw k of the per-tile
+// time stream mapped to sample_time_range (FixedGridSampler, src/fj_fixed_grid_sampler.cc:
+// 73-77: Fit(rnd, 0, 1, start, end)); k = sample index in the tile = low 20 bits of uid.
+__device__ __forceinline__ double sample_time(const DScene &S, uint32_t tindex)
+{
+  const double x = S.time_tab[tindex];
+  if (x <= 0) return S.time_start;
+  if (x >= 1) return S.time_end;
+  return S.time_start + (S.time_end - S.time_start) * ((x - 0) / (1 - 0));
+}
+
+// XfmLerpTransformSample + matrix + Cramer inverse at `time` (fjgpu_xform_math.h: the host's
+// source, compiled for the device).  Out of line on purpose: it is rare and register hungry.
+__device__ __noinline__ void xform_at(const fj_xform_desc *x, double time, double *M, double *Minv)
+{
+  double m[16], mi[16];
+  fjx::make_transform(*x, time, m, mi);
+  for (int k = 0; k < 12; k++) { M[k] = m[k]; Minv[k] = mi[k]; }
 }
 
 // BoxRayIntersect, reference src/fj_box.cc:73-138, operation for operation.  Used where
@@ -433,7 +454,7 @@ struct TravTune { uint32_t refill, steps, grab; };
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
 
-struct RayIn { V3 o, d; double tmin, tmax; int group; bool anyhit; };
+struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
 // consecutive, conflict free), deeper ones -- the builder reports the worst case of the
@@ -463,7 +484,7 @@ __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf
   return st;
 }
 
-template <bool kCurves, bool kCount, class Policy>
+template <bool kCurves, bool kCount, bool kMotion, class Policy>
 __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
@@ -477,7 +498,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, inv = o, d = o, winv = o;
-  double tmin = 0, tmax = 0;
+  double tmin = 0, tmax = 0, rtime = 0;
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
   int gfirst = 0, gcount = 0, gi = 0, ii = -1;
@@ -502,10 +523,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
         if (my < range_end) {
           RayIn r;
-          r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = 0; r.group = 0; r.anyhit = false;
+          r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
           have = pol.fetch(my, &r);
           idx = my;
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          if (kMotion) rtime = r.time;
           const DGroup G = S.groups[r.group];
           gfirst = G.first; gcount = G.count; gi = 0;
           gsb = S.groups[r.group].sbounds;
@@ -539,8 +561,16 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 #else
         if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
 #endif
-        oo = xpoint(I->Minv, o);
-        od = xvector(I->Minv, d);
+        if (kMotion && I->xform >= 0) {
+          // ObjectInstance::RayIntersect evaluates a time-sampled transform at the ray's time
+          double tm[12], tmi[12];
+          xform_at(&S.xforms[I->xform], rtime, tm, tmi);
+          oo = xpoint(tmi, o);
+          od = xvector(tmi, d);
+        } else {
+          oo = xpoint(I->Minv, o);
+          od = xvector(I->Minv, d);
+        }
         if (has_negative_zero(od)) continue;
         inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
         P = &S.primsets[I->primset];
@@ -640,6 +670,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 
 // ------------------------------------------------------------------ k_trace
 struct ClosestPolicy {
+  const DScene *S;
   const DRay *rays;
   const DPath *paths;
   DHit *hits;
@@ -649,6 +680,7 @@ struct ClosestPolicy {
     const DRay q = rays[i];
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = q.tmin; r->tmax = q.tmax;
+    r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].uid & 0xfffffu) : 0.;   // fjgpu_trace: time 0
     r->group = paths ? paths[i].group : default_group;
     r->anyhit = false;
     return true;
@@ -667,15 +699,15 @@ struct ClosestPolicy {
 #ifndef FJ_SHADOW_MINB
 #define FJ_SHADOW_MINB 1
 #endif
-template <bool kCurves, bool kCount>
-__global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+template <bool kCurves, bool kCount, bool kMotion>
+__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   ClosestPolicy pol;
-  pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
+  pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -709,11 +741,16 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   const uint32_t slot = T.sample_offset + k;
   s_uv[2 * (size_t) slot] = u;
   s_uv[2 * (size_t) slot + 1] = v;
-  (void) time_tab;   // static camera / geometry: the per-sample time does not enter the path
+  (void) time_tab;   // (the same table as S.time_tab)
 
+  // Camera::GetRay (src/fj_camera.cc:79-110): a time-sampled camera is evaluated at the
+  // sample's time, a static one uses the host-built matrix
+  const double *cam = S.cam_M;
+  double cm[12], cmi[12];
+  if (S.cam_xform) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
   const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
-  const V3 tw = xpoint(S.cam_M, target);
-  const V3 eye = mk(S.cam_M[3], S.cam_M[7], S.cam_M[11]);
+  const V3 tw = xpoint(cam, target);
+  const V3 eye = mk(cam[3], cam[7], cam[11]);
   const V3 dir = normalize(tw - eye);
 
   DRay r;
@@ -893,6 +930,7 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
 // the reference is linear in the radiance returned by its child SlTrace calls,
 // so `Cs = local + sum_k w_k * C_child_k` unrolls into per-path products
 // (DESIGN.md 6).
+template <bool kMotion>
 __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths,
     DLightRec *lrecs, DCounters *cnt)
@@ -920,8 +958,16 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     const DPrimSet *P = &S.primsets[I->primset];
     const V3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = mk(r.d[0], r.d[1], r.d[2]);
 
-    const V3 oo = xpoint(I->Minv, ro);
-    const V3 od = xvector(I->Minv, rd);
+    // instance matrices: host-built for static instances, evaluated at the ray's time for
+    // time-sampled ones (the traversal did the same, so P and N belong to the same pose)
+    const double *IM = I->M, *IMinv = I->Minv;
+    double tm[12], tmi[12];
+    if (kMotion && I->xform >= 0) {
+      xform_at(&S.xforms[I->xform], sample_time(S, p.uid & 0xfffffu), tm, tmi);
+      IM = tm; IMinv = tmi;
+    }
+    const V3 oo = xpoint(IMinv, ro);
+    const V3 od = xvector(IMinv, rd);
     V3 N = mk(0, 0, 0);
     float tu = 0.f, tv = 0.f;
     V3 dPdu = mk(0, 0, 0), dPdv = mk(0, 0, 0);
@@ -965,9 +1011,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     }
     V3 Pw = oo + h.t * od;                                        // RayPointAt in object space
     // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)
-    Pw = xpoint(I->M, Pw);
-    N = normalize(xvector(I->M, N));
-    dPdv = xvector(I->M, dPdv);
+    Pw = xpoint(IM, Pw);
+    N = normalize(xvector(IM, N));
+    dPdv = xvector(IM, dPdv);
 
     // --- shader lookup: ObjectInstance::GetShader (src/fj_object_instance.cc:177-191)
     int sid;
@@ -1012,8 +1058,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
               dPdu = ((double) dv2 * dP1 - (double) dv1 * dP2) * (double) invdet;
               dPdv = ((double) (-du2) * dP1 + (double) du1 * dP2) * (double) invdet;
             }
-            dPdu = xvector(I->M, dPdu);
-            dPdv = xvector(I->M, dPdv);   // (mesh dPdv is zero until here)
+            dPdu = xvector(IM, dPdu);
+            dPdv = xvector(IM, dPdv);   // (mesh dPdv is zero until here)
           }
           Nf = bump_mapping(S.textures[sh->bump_map], dPdu, dPdv, tu, tv, (double) sh->bump_amplitude, Nf);
         }
@@ -1032,7 +1078,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 0;
-          lr.cxt = p.cxt;
+          lr.uid = p.uid;
           if (lr.W[0] == 0.f && lr.W[1] == 0.f && lr.W[2] == 0.f && !sp.count_all_shadow) want_light = false;
         }
         if (sh->do_reflect && (int) p.rdepth + 1 <= sp.max_reflect_depth) {
@@ -1089,7 +1135,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 1;
-          lr.cxt = p.cxt;
+          lr.uid = p.uid;
         }
         Os = 1.f;
         break;
@@ -1113,8 +1159,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
               dPdu = ((double) dv2 * dP1 - (double) dv1 * dP2) * (double) invdet;
               dPdv = ((double) (-du2) * dP1 + (double) du1 * dP2) * (double) invdet;
             }
-            dPdu = xvector(I->M, dPdu);
-            dPdv = xvector(I->M, dPdv);
+            dPdu = xvector(IM, dPdu);
+            dPdv = xvector(IM, dPdv);
           }
           Np = bump_mapping(S.textures[sh->bump_map], dPdu, dPdv, tu, tv, (double) sh->bump_amplitude, N);
         }
@@ -1324,7 +1370,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             q.d[0] = Ln.x; q.d[1] = Ln.y; q.d[2] = Ln.z;
             q.tmax = distance;
             q.c[0] = W[0] * k[0]; q.c[1] = W[1] * k[1]; q.c[2] = W[2] * k[2];
-            q.sample = r_sample; q.group = R.group; q.pad = 0;
+            q.sample = r_sample; q.group = R.group; q.tindex = R.uid & 0xfffffu;
           } else {
             sum[0] += k[0]; sum[1] += k[1]; sum[2] += k[2];
           }
@@ -1383,6 +1429,7 @@ struct ShadowPolicy {
     if (q.sample == SQ_INVALID) return false;      // padding slot of a partially filled chunk
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = .0001; r->tmax = q.tmax;
+    r->time = S->has_motion ? sample_time(*S, q.tindex) : 0.;
     r->group = q.group;
     r->anyhit = S->groups[q.group].all_opaque != 0;
     return true;
@@ -1414,8 +1461,8 @@ struct ShadowPolicy {
   }
 };
 
-template <bool kCurves, bool kCount>
-__global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
+template <bool kCurves, bool kCount, bool kMotion>
+__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
@@ -1423,7 +1470,7 @@ __global__ void __launch_bounds__(BLOCK, kCurves ? 1 : FJ_SHADOW_MINB) k_shadow_
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -1792,9 +1839,11 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
   // (the event counters cost registers and issue slots: counting is its own instantiation)
   const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));
-#define FJ_LAUNCH_CLOSEST(CURVES, COUNT) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
-  if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true); else FJ_LAUNCH_CLOSEST(true, false); }
-  else { if (count_events) FJ_LAUNCH_CLOSEST(false, true); else FJ_LAUNCH_CLOSEST(false, false); }
+#define FJ_LAUNCH_CLOSEST(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT, MOTION>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
+  if (S.has_motion) {      // time-sampled instance transforms: one general instantiation
+    if (count_events) FJ_LAUNCH_CLOSEST(true, true, true); else FJ_LAUNCH_CLOSEST(true, false, true);
+  } else if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false); }
+  else { if (count_events) FJ_LAUNCH_CLOSEST(false, true, false); else FJ_LAUNCH_CLOSEST(false, false, false); }
 #undef FJ_LAUNCH_CLOSEST
   LAUNCH_CHECK();
   return 0;
@@ -1804,8 +1853,12 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt)
 {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_shade, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
-      s_accum, next_rays, next_paths, lrecs, cnt);
+  if (S.has_motion)
+    hipLaunchKernelGGL(k_shade<true>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
+        s_accum, next_rays, next_paths, lrecs, cnt);
+  else
+    hipLaunchKernelGGL(k_shade<false>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
+        s_accum, next_rays, next_paths, lrecs, cnt);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1832,7 +1885,7 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
       hipLaunchKernelGGL(k_shadow_cull<false>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
           S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
     LAUNCH_CHECK();
-    if (S.all_opaque && !S.has_curves) {
+    if (S.all_opaque && !S.has_curves && !S.has_motion) {
       if (count_events)
         hipLaunchKernelGGL(k_shadow_anyhit<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
             S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
@@ -1840,9 +1893,10 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
         hipLaunchKernelGGL(k_shadow_anyhit<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
             S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
     } else {
-#define FJ_LAUNCH_SHADOW(CURVES, COUNT) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune())
-      if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true); else FJ_LAUNCH_SHADOW(true, false); }
-      else { if (count_events) FJ_LAUNCH_SHADOW(false, true); else FJ_LAUNCH_SHADOW(false, false); }
+#define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune())
+      if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
+      else if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false); }
+      else { if (count_events) FJ_LAUNCH_SHADOW(false, true, false); else FJ_LAUNCH_SHADOW(false, false, false); }
 #undef FJ_LAUNCH_SHADOW
     }
     LAUNCH_CHECK();

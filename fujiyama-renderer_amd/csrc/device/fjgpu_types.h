@@ -68,7 +68,9 @@ struct DInstance {
   int32_t n_shaders;
   int32_t shaders[FJ_MAX_SHADING_GROUPS];
   int32_t reflect_target, refract_target, shadow_target;
-  int32_t pad[3];
+  int32_t xform;               // time-sampled transform: index into DScene.xforms (M / Minv above hold
+                               // the time-0 matrices); -1 = static
+  int32_t pad[2];
 };
 
 struct DGroup {
@@ -104,7 +106,14 @@ struct DScene {
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
-  // camera (static): eye, matrix rows, uv_size
+  // time-sampled transforms (motion blur): evaluated per ray at the sample's time
+  const fj_xform_desc *xforms; // instances with DInstance.xform >= 0
+  const fj_xform_desc *cam_xform;   // null = static camera
+  const double *time_tab;      // draw k of the per-tile time stream (sample index in the tile -> [0,1])
+  double time_start, time_end; // Renderer sample_time_range
+  int32_t has_motion;          // any time-sampled instance transform: traversal / shading evaluate them
+  int32_t pad_;
+  // camera (static case): eye, matrix rows, uv_size
   double cam_M[12];
   double cam_uv_size[2];
   double cam_znear, cam_zfar;
@@ -143,7 +152,7 @@ struct DLightRec {             // one shading event that gathers direct light
   uint32_t sample;
   int32_t group;               // shadow target of the shaded object
   int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair)
-  int32_t cxt;                 // context of the shading ray (shadow contexts never light)
+  uint32_t uid;                // DPath.uid of the shading ray (its low 20 bits index the sample's time)
 };
 
 struct DShadowRay {            // 80 B: a shadow ray that survived the instance-box cull
@@ -151,7 +160,7 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
   float c[3];                  // W * Kd * Cl: added to the sample, scaled by (1 - occluder Os)
   uint32_t sample;
   int32_t group;
-  int32_t pad;
+  uint32_t tindex;             // sample index in its tile: the ray's time is time_tab[tindex] (motion blur)
 };
 
 struct DCounters {

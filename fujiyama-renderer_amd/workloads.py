@@ -158,6 +158,59 @@ def dragon(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="dragon", nlights=32, e
     return si.text()
 
 
+def motion(asset_dir, res=(640, 480), spp=(9, 9), mesh="small", kind="object", nlights=4, extra=()):
+    """Motion blur by time-sampled transforms (scenes/transform_motion_blur.py,
+    scenes/camera_motion_blur.py): `kind` = "object" (the mesh rotates and moves over the
+    shutter), "camera" (the camera dollies and pans), "both", or "scale" (an object that
+    also grows: three samples per channel, not evenly spaced)."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    if kind in ("camera", "both"):
+        si.SetSampleProperty3("cam1", "translate", 0, 1.5, 7, 0)
+        si.SetSampleProperty3("cam1", "translate", .4, 1.6, 6.3, 1)
+        si.SetSampleProperty3("cam1", "rotate", -5.710593137499643, 0, 0, 0)
+        si.SetSampleProperty3("cam1", "rotate", -7, 4, 2, 1)
+    else:
+        si.SetSampleProperty3("cam1", "translate", 0, 1.5, 7, 0)
+        si.SetProperty3("cam1", "rotate", -5.710593137499643, 0, 0)
+    point_lights(si, nlights)
+    si.NewShader("dragon_shader0", "plastic_shader")
+    si.SetProperty3("dragon_shader0", "diffuse", .7, .05, .1)
+    _ply(si, "dragon_mesh", a[mesh])
+    si.NewObjectInstance("dragon1", "dragon_mesh")
+    if kind in ("object", "both"):
+        si.SetSampleProperty3("dragon1", "translate", .2, 0, 0, 0)
+        si.SetSampleProperty3("dragon1", "translate", .5, .2, 0, 1)
+        si.SetSampleProperty3("dragon1", "rotate", 0, -35, 0, 0)
+        si.SetSampleProperty3("dragon1", "rotate", 0, -20, 20, 1)
+        si.SetProperty3("dragon1", "scale", .5, .5, .5)
+    elif kind == "scale":
+        si.SetSampleProperty3("dragon1", "translate", .2, 0, 0, 0)
+        si.SetSampleProperty3("dragon1", "translate", .3, .1, .2, .25)
+        si.SetSampleProperty3("dragon1", "translate", -.2, .3, 0, 1)
+        si.SetSampleProperty3("dragon1", "rotate", 0, -35, 0, 0)
+        si.SetSampleProperty3("dragon1", "rotate", 10, 0, 0, 1)
+        si.SetSampleProperty3("dragon1", "scale", .5, .5, .5, 0)
+        si.SetSampleProperty3("dragon1", "scale", .6, .4, .5, .5)
+        si.SetSampleProperty3("dragon1", "scale", .7, .7, .3, 1)
+    else:
+        si.SetProperty3("dragon1", "scale", .5, .5, .5)
+        si.SetProperty3("dragon1", "rotate", 0, -35, 0)
+        si.SetProperty3("dragon1", "translate", .2, 0, 0)
+    si.AssignShader("dragon1", "DEFAULT_SHADING_GROUP", "dragon_shader0")
+    _stage(si, a, dome_rotate=(0, 180, 0))
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "dragon1")
+    si.AssignObjectGroup("dragon1", "shadow_target", "group1")
+    si.AssignObjectGroup("floor1", "shadow_target", "group1")
+    _renderer(si, res, spp, (("sample_time_range", (0, 1)),) + tuple(extra))
+    return si.text()
+
+
 def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=()):
     """C5: fur (cubic Bezier curves + HairShader) grown on a mesh by
     CurveGeneratorProcedure; plastic mesh and floor without reflection (furry_bunny.scn)."""
@@ -332,7 +385,8 @@ def cornell(asset_dir, res=(1920, 1080), spp=(16, 16), mesh="bunny", extra=(), o
     return si.text()
 
 
-BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl, "cornell": cornell}
+BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl, "cornell": cornell,
+            "motion": motion}
 
 
 def default_asset_dir():

@@ -35,6 +35,10 @@ FRAMES = {
     "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
     "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
     "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
+    "motion_object_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="object")),
+    "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
+    "motion_both_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
+    "motion_scale_3samples_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="scale")),
     "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
                                   extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
                                          ("filterwidth", (3, 2.5))))),

@@ -56,6 +56,10 @@ CASES = {
     "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
     "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
     "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
+    "motion_object_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="object")),
+    "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
+    "motion_both_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
+    "motion_scale_3samples_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="scale")),
     "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
                                   extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
                                          ("filterwidth", (3, 2.5))))),
@@ -222,12 +226,7 @@ def test_si_render_scene_end_to_end(asset_dir):
 def test_unsupported_features_fail_loudly(asset_dir):
     a = synth.ensure_assets(asset_dir, ("tiny",))
     base = _custom_scene(asset_dir, lights=1)
-    # time-sampled transform (motion blur) is a "next" row: explicit error, no silent static render
-    moving = base.replace("RenderScene ren1", "SetSampleProperty3 obj1 translate 1 0 0 1\nRenderScene ren1")
-    sp, rd = prepare(moving)
-    with pytest.raises(gpu.GpuError) as e:
-        gpu.Scene(sp)
-    assert "motion blur" in str(e.value)
+    # features outside the device path: explicit error naming the feature, no silent approximation
     grid = base.replace("NewLight light0 PointLight", "NewLight light0 GridLight")
     sp, rd = prepare(grid)
     with pytest.raises(gpu.GpuError) as e:
