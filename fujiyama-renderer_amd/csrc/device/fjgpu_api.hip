@@ -206,6 +206,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
   e |= M.upload(hs.light_samples.data(), hs.light_samples.size(), &S.light_samples);
+  e |= M.upload(hs.area_lights.data(), hs.area_lights.size(), &S.area_lights);
+  S.has_area = hs.area_lights.empty() ? 0 : 1;
   if (e) return fail(FJGPU_ENOMEM, "device allocation / upload failed while creating the scene");
   S.n_light_samples = (int) hs.light_samples.size();
   S.n_instances = (int) hs.instances.size();

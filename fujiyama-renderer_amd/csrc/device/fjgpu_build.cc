@@ -568,7 +568,7 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
         return FJGPU_EUNSUPPORTED;
       }
       for (int k = 0; k < 3; k++) s.Cl[k] = L.intensity * L.color[k];   // PointLight::illuminate
-      s.light = i;
+      s.light = i; s.type = FJ_POINT_LIGHT; s.ordinal = 0;
       out->light_samples.push_back(s);
     } else if (L.type == FJ_DOME_LIGHT) {
       const int n = std::min(L.sample_count, L.n_dome_samples);
@@ -579,12 +579,32 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
         DLightSample s;
         for (int r = 0; r < 3; r++) s.P[r] = M[4 * r] * p[0] + M[4 * r + 1] * p[1] + M[4 * r + 2] * p[2] + M[4 * r + 3];
         for (int c = 0; c < 3; c++) s.Cl[c] = si * ds.color[c];
-        s.light = i;
+        s.light = i; s.type = FJ_DOME_LIGHT; s.ordinal = k;
+        out->light_samples.push_back(s);
+      }
+    } else if (L.type == FJ_GRID_LIGHT || L.type == FJ_SPHERE_LIGHT) {
+      // RectangleLight / SphereLight: get_sample_count() positions per shading event, drawn on
+      // the device from the counter-based stream of DESIGN.md 4 (the reference's shared,
+      // unsynchronised per-light XorShift makes its own image schedule dependent)
+      if (out->area_lights.empty()) out->area_lights.resize(d->n_lights);
+      DAreaLight &A = out->area_lights[i];
+      std::memset(&A, 0, sizeof(A));
+      std::memcpy(A.M, M, sizeof(A.M));
+      const double n[3] = {M[1], M[5], M[9]};                      // M * (0,1,0) as a vector
+      const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      const double inv = len > 0 ? 1. / len : 0.;                    // Normalize, src/fj_vector.h
+      for (int k = 0; k < 3; k++) { A.N[k] = len > 0 ? n[k] * inv : n[k]; A.color[k] = L.color[k]; }
+      A.sample_intensity = L.intensity / L.sample_count;
+      A.double_sided = L.double_sided;
+      for (int k = 0; k < L.sample_count; k++) {
+        DLightSample s;
+        std::memset(&s, 0, sizeof(s));
+        s.light = i; s.type = L.type; s.ordinal = k;
         out->light_samples.push_back(s);
       }
     } else {
-      *err = "GridLight / SphereLight draw from a shared racy RNG in the reference and are not on the device path";
-      return FJGPU_EUNSUPPORTED;
+      *err = "unknown light type";
+      return FJGPU_EINVAL;
     }
   }
 

@@ -50,6 +50,7 @@ struct HostScene {
   fj_xform_desc cam_xform;                    // valid when cam_static is false
   bool cam_static;
   std::vector<DLightSample> light_samples;
+  std::vector<DAreaLight> area_lights;        // [n_lights] when any rectangle / sphere light exists
   int n_meshes;
   int target_group;
   double cam_M[12];

@@ -834,6 +834,39 @@ __device__ __forceinline__ float luminance3(const float c[3]) { return (float) (
 // Counter-based RNG contract of the pathtracing path: the reference's
 // seeded XorShift (src/fj_random.cc:18-43) with seed = mix(sample uid, path key), four
 // warm-up draws, then the two numbers of the diffuse bounce.
+__device__ __forceinline__ uint32_t pt_mix(uint32_t uid, uint32_t key)
+{
+  uint32_t h = uid * 0x9E3779B1u ^ (key + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+// XorShift of src/fj_random.cc:10-43 (state in registers)
+struct XS {
+  uint32_t a, b, c, d;
+  __device__ __forceinline__ uint32_t next()
+  {
+    const uint32_t t = a ^ (a << 11);
+    a = b; b = c; c = d;
+    d = (d ^ (d >> 19)) ^ (t ^ (t >> 8));
+    return d;
+  }
+  __device__ __forceinline__ double f01() { return (double) next() / 4294967295u; }
+};
+
+// stream of one (shading event, area light): RNG contract of DESIGN.md 4
+__device__ __forceinline__ XS area_stream(uint32_t uid, uint32_t key, int light)
+{
+  uint32_t seed = pt_mix(pt_mix(uid, key) ^ 0x51ED270Bu, (uint32_t) light);
+  XS r;
+  r.a = seed = 1812433253U * (seed ^ (seed >> 30)) + 0u;
+  r.b = seed = 1812433253U * (seed ^ (seed >> 30)) + 1u;
+  r.c = seed = 1812433253U * (seed ^ (seed >> 30)) + 2u;
+  r.d = seed = 1812433253U * (seed ^ (seed >> 30)) + 3u;
+  for (int i = 0; i < 4; i++) r.next();
+  return r;
+}
+
 __device__ void pt_draw2(uint32_t uid, uint32_t key, double *x1, double *x2)
 {
   uint32_t h = uid * 0x9E3779B1u ^ (key + 0x7F4A7C15u) * 0x85EBCA77u;
@@ -1078,7 +1111,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 0;
-          lr.uid = p.uid;
+          lr.uid = p.uid; lr.key = p.rng; lr.pad = 0;
           if (lr.W[0] == 0.f && lr.W[1] == 0.f && lr.W[2] == 0.f && !sp.count_all_shadow) want_light = false;
         }
         if (sh->do_reflect && (int) p.rdepth + 1 <= sp.max_reflect_depth) {
@@ -1135,7 +1168,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 1;
-          lr.uid = p.uid;
+          lr.uid = p.uid; lr.key = p.rng; lr.pad = 0;
         }
         Os = 1.f;
         break;
@@ -1254,7 +1287,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
 #define SQ_CHUNK 256u          // shadow-queue slots a wave reserves per global atomic
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
 
-template <bool kHair>
+template <bool kHair, bool kArea>
 __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
@@ -1284,6 +1317,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     const uint32_t nl = (uint32_t) S.n_light_samples;
     const uint32_t iters = (nl + sp.lanes - 1) / sp.lanes;     // uniform trip count: ballots stay convergent
     DLightRec R;
+    R.uid = R.key = 0;
+    XS xs = {0, 0, 0, 0};
     V3 Ps = mk(0, 0, 0), axis = Ps, nml_axis = Ps;
     int g_first = 0, g_count = 0;
     const double *g_sbounds = nullptr;     // stays a global-memory pointer (a by-value DGroup lands in scratch)
@@ -1305,14 +1340,49 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
       DShadowRay q;
       if (active && l < nl) {
         const DLightSample LS = S.light_samples[l];
-        V3 Ln = mk(LS.P[0] - Ps.x, LS.P[1] - Ps.y, LS.P[2] - Ps.z);
+        V3 Pl = mk(LS.P[0], LS.P[1], LS.P[2]);
+        float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
+        if (kArea && (LS.type == FJ_GRID_LIGHT || LS.type == FJ_SPHERE_LIGHT)) {
+          // RectangleLight / SphereLight::get_samples + illuminate with the per-event stream
+          const DAreaLight *A = &S.area_lights[LS.light];
+          if (LS.ordinal == 0) xs = area_stream(R.uid, R.key, LS.light);
+          V3 Nl;
+          if (LS.type == FJ_GRID_LIGHT) {
+            const double px = xs.f01() - .5;
+            const double pz = xs.f01() - .5;
+            Pl = xpoint(A->M, mk(px, 0, pz));
+            Nl = mk(A->N[0], A->N[1], A->N[2]);
+          } else {
+            V3 o;
+            double dd;
+            for (;;) {                                      // XorShift::HollowSphereRand
+              o.x = 2 * xs.f01() - 1;
+              o.y = 2 * xs.f01() - 1;
+              o.z = 2 * xs.f01() - 1;
+              dd = dot(o, o);
+              if (dd > 0 && dd <= 1) break;
+            }
+            const double inv = 1. / sqrt(dd);
+            const V3 p = mk(o.x * inv, o.y * inv, o.z * inv);
+            Pl = xpoint(A->M, p);
+            Nl = normalize(xvector(A->M, p));
+          }
+          const V3 Lq = normalize(mk(Ps.x - Pl.x, Ps.y - Pl.y, Ps.z - Pl.z));
+          double dl = dot(Lq, Nl);
+          float k;
+          if (LS.type == FJ_GRID_LIGHT) {
+            dl = A->double_sided ? fabs(dl) : (dl > 0. ? dl : 0.);
+            k = (float) (dl * (double) A->sample_intensity);
+          } else k = dl > 0 ? A->sample_intensity : 0.f;
+          Cl[0] = k * A->color[0]; Cl[1] = k * A->color[1]; Cl[2] = k * A->color[2];
+        }
+        V3 Ln = mk(Pl.x - Ps.x, Pl.y - Ps.y, Pl.z - Ps.z);
         const double distance = sqrt(dot(Ln, Ln));
         if (distance > 0) {
           const double inv = 1. / distance;
           Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
         }
         const double cosangle = dot(nml_axis, Ln);
-        float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
         const bool lit = !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
         if (lit) {
           float k[3] = {0.f, 0.f, 0.f};
@@ -1878,12 +1948,11 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
     const uint32_t e = (n - b < chunk) ? n : b + chunk;
     (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + trace_head
     const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
-    if (S.has_hair)
-      hipLaunchKernelGGL(k_shadow_cull<true>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
-          S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
-    else
-      hipLaunchKernelGGL(k_shadow_cull<false>, dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
-          S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+#define FJ_LAUNCH_CULL(HAIR, AREA) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
+    if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation
+    else if (S.has_hair) FJ_LAUNCH_CULL(true, false);
+    else FJ_LAUNCH_CULL(false, false);
+#undef FJ_LAUNCH_CULL
     LAUNCH_CHECK();
     if (S.all_opaque && !S.has_curves && !S.has_motion) {
       if (count_events)

@@ -89,6 +89,19 @@ struct DLightSample {
   double P[3];
   float Cl[3];                 // Light::Illuminate result (position independent for point / dome)
   int32_t light;
+  int32_t type;                // FJ_POINT_LIGHT / FJ_DOME_LIGHT: P and Cl above are final.  FJ_GRID_LIGHT /
+                               // FJ_SPHERE_LIGHT: the position is drawn per shading event (DAreaLight)
+  int32_t ordinal;             // index of this sample inside its light (0 restarts the light's stream)
+};
+
+// RectangleLight / SphereLight (src/fj_rectangle_light.cc, src/fj_sphere_light.cc) at time 0
+struct DAreaLight {
+  double M[12];                // light transform
+  double N[3];                 // rectangle: normalize(M * (0,1,0))
+  float color[3];
+  float sample_intensity;      // intensity / sample_count
+  int32_t double_sided;
+  int32_t pad;
 };
 
 struct DScene {
@@ -99,10 +112,12 @@ struct DScene {
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;
+  const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
   int32_t all_opaque;          // every group is all_opaque: shadow rays run the lean any-hit kernel
+  int32_t has_area;            // any rectangle / sphere light: the light loop draws positions per event
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
@@ -153,6 +168,8 @@ struct DLightRec {             // one shading event that gathers direct light
   int32_t group;               // shadow target of the shaded object
   int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair)
   uint32_t uid;                // DPath.uid of the shading ray (its low 20 bits index the sample's time)
+  uint32_t key;                // path key of the shading ray (area-light stream, with uid)
+  uint32_t pad;
 };
 
 struct DShadowRay {            // 80 B: a shadow ray that survived the instance-box cull

@@ -211,6 +211,51 @@ def motion(asset_dir, res=(640, 480), spp=(9, 9), mesh="small", kind="object", n
     return si.text()
 
 
+def arealights(asset_dir, res=(640, 480), spp=(6, 6), mesh="small", kind="grid", extra=()):
+    """Area lights (scenes/grid_light.py, scenes/sphere_light.py): `kind` = "grid" (a
+    rectangle light above the stage), "sphere", or "both" (+ one point light, so static and
+    per-event light samples are interleaved in the loop)."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetSampleProperty3("cam1", "translate", 0, 1.5, 7, 0)
+    si.SetProperty3("cam1", "rotate", -5.710593137499643, 0, 0)
+    if kind in ("grid", "both"):
+        si.NewLight("light1", "GridLight")
+        si.SetProperty3("light1", "translate", 0, 6, 0)
+        si.SetProperty3("light1", "rotate", 0, 0, 180)
+        si.SetProperty3("light1", "scale", 5, 5, 5)
+        si.SetProperty1("light1", "sample_count", 8)
+    if kind == "both":
+        si.NewLight("light2", "PointLight")
+        si.SetProperty3("light2", "translate", -6, 8, 6)
+        si.SetProperty1("light2", "intensity", .3)
+    if kind in ("sphere", "both"):
+        si.NewLight("light3", "SphereLight")
+        si.SetProperty3("light3", "translate", 2, 2.5, 1.5)
+        si.SetProperty3("light3", "scale", .5, .5, .5)
+        si.SetProperty1("light3", "intensity", 1.5 if kind == "both" else 3)
+        si.SetProperty1("light3", "sample_count", 6)
+    si.NewShader("dragon_shader0", "plastic_shader")
+    si.SetProperty3("dragon_shader0", "diffuse", .7, .5, .2)
+    _ply(si, "dragon_mesh", a[mesh])
+    si.NewObjectInstance("dragon1", "dragon_mesh")
+    si.SetProperty3("dragon1", "scale", .5, .5, .5)
+    si.SetProperty3("dragon1", "rotate", 0, -35, 0)
+    si.SetProperty3("dragon1", "translate", .2, 0, 0)
+    si.AssignShader("dragon1", "DEFAULT_SHADING_GROUP", "dragon_shader0")
+    _stage(si, a, dome_rotate=(0, 180, 0))
+    si.NewObjectGroup("group1")
+    si.AddObjectToGroup("group1", "dragon1")
+    si.AssignObjectGroup("dragon1", "shadow_target", "group1")
+    si.AssignObjectGroup("floor1", "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
 def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=()):
     """C5: fur (cubic Bezier curves + HairShader) grown on a mesh by
     CurveGeneratorProcedure; plastic mesh and floor without reflection (furry_bunny.scn)."""
@@ -386,7 +431,7 @@ def cornell(asset_dir, res=(1920, 1080), spp=(16, 16), mesh="bunny", extra=(), o
 
 
 BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl, "cornell": cornell,
-            "motion": motion}
+            "motion": motion, "arealights": arealights}
 
 
 def default_asset_dir():

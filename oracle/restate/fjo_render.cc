@@ -242,6 +242,22 @@ static V3 BumpMapping(const fj_texture_desc &bump, const V3 &dPdu, const V3 &dPd
 static Col Illuminate(const fj_light_desc &L, const LightSample &s, const V3 &Ps)
 {
   switch (L.type) {
+  case FJ_GRID_LIGHT: {    // RectangleLight::illuminate, src/fj_rectangle_light.cc:47-59
+    const V3 Ln = Normalize(Ps - s.P);
+    double dot = Dot(Ln, s.N);
+    dot = L.double_sided ? std::abs(dot) : Max(dot, 0.);
+    const float si = L.intensity / L.sample_count;
+    const float k = dot * si;                       // Real * float, then operator*(float, Color)
+    return Col(k * L.color[0], k * L.color[1], k * L.color[2]);
+  }
+  case FJ_SPHERE_LIGHT: {  // SphereLight::illuminate, src/fj_sphere_light.cc:47-59
+    const V3 Ln = Normalize(Ps - s.P);
+    if (Dot(Ln, s.N) > 0) {
+      const float si = L.intensity / L.sample_count;
+      return Col(si * L.color[0], si * L.color[1], si * L.color[2]);
+    }
+    return Col();
+  }
   case FJ_POINT_LIGHT:     // src/fj_point_light.cc:36-39
     return Col(L.intensity * L.color[0], L.intensity * L.color[1], L.intensity * L.color[2]);
   case FJ_DOME_LIGHT: {    // src/fj_dome_light.cc:53-56; sample_intensity = intensity / sample_count
@@ -293,6 +309,61 @@ static int Illuminance(RenderState *rs, const Cxt &cxt, const LightSample &smp, 
 
 struct SurfOut { Col Cs; float Os; };
 
+// ---- area lights (RectangleLight / SphereLight get_samples, src/fj_rectangle_light.cc:20-45,
+// src/fj_sphere_light.cc:22-45).  The reference draws the sample positions from ONE XorShift
+// per light, shared unsynchronised by all worker threads: its image depends on the schedule.
+// RNG contract shared with the device: per shading event (sample_uid, path_key)
+// and light index L the stream is the reference's seeded XorShift with
+//   seed = mix(mix(uid, key) ^ 0x51ED270B, L),  four warm-up draws,
+// then the draws of that light's samples in order (rectangle: x, z per sample; sphere:
+// HollowSphereRand's rejection loop, three draws per attempt).
+static uint32_t pt_mix(uint32_t uid, uint32_t key);
+static XorShift area_stream(uint32_t uid, uint32_t key, int light)
+{
+  uint32_t seed = pt_mix(pt_mix(uid, key) ^ 0x51ED270Bu, (uint32_t) light);
+  XorShift r;
+  for (uint32_t i = 0; i < 4; i++) r.s[i] = seed = 1812433253U * (seed ^ (seed >> 30)) + i;   // XorShift(unsigned), src/fj_random.cc:18-24
+  for (int i = 0; i < 4; i++) r.NextInteger();
+  return r;
+}
+
+// SlNewLightSamples for one shading event: the static table, with the samples of area
+// lights generated in place (same order: lights in scene order, samples in draw order)
+static const std::vector<LightSample> &event_light_samples(const RenderState *rs, const Cxt &cxt, std::vector<LightSample> *tmp)
+{
+  const Scene &sc = *rs->sc;
+  if (!sc.has_area_lights) return sc.light_samples;
+  *tmp = sc.light_samples;
+  int cur = -1;
+  XorShift rng;
+  for (LightSample &s : *tmp) {
+    const fj_light_desc &L = sc.d->lights[s.light];
+    if (L.type != FJ_GRID_LIGHT && L.type != FJ_SPHERE_LIGHT) continue;
+    if (s.light != cur) { cur = s.light; rng = area_stream(cxt.sample_uid, cxt.path_key, cur); }
+    const Xfm &x = sc.light_xfm[s.light];
+    if (L.type == FJ_GRID_LIGHT) {
+      const double px = rng.NextFloat01() - .5;
+      const double pz = rng.NextFloat01() - .5;
+      s.P = MatTransformPoint(x.matrix, V3(px, 0, pz));
+      s.N = Normalize(MatTransformVector(x.matrix, V3(0, 1, 0)));
+    } else {
+      V3 o;
+      double dot;
+      for (;;) {                                      // XorShift::HollowSphereRand, src/fj_random.cc:69-87
+        o.x = 2 * rng.NextFloat01() - 1;
+        o.y = 2 * rng.NextFloat01() - 1;
+        o.z = 2 * rng.NextFloat01() - 1;
+        dot = Dot(o, o);
+        if (dot > 0 && dot <= 1) break;
+      }
+      const V3 p = o / std::sqrt(dot);
+      s.P = MatTransformPoint(x.matrix, p);
+      s.N = Normalize(MatTransformVector(x.matrix, p));
+    }
+  }
+  return *tmp;
+}
+
 static Cxt ReflectCxt(const RenderState *rs, const Cxt &c, int obj)   // :230-240
 {
   Cxt r = c; r.reflect_depth++; r.ray_context = CXT_REFLECT_RAY; r.path_key = 4 * c.path_key + 2;
@@ -319,7 +390,8 @@ static void PlasticEvaluate(RenderState *rs, const fj_shader_desc &sh, const Cxt
   if (sh.bump_map >= 0)
     Nf = BumpMapping(d->textures[sh.bump_map], in.dPdu, in.dPdv, in.u, in.v, sh.bump_amplitude, Nf);
 
-  const std::vector<LightSample> &samples = rs->sc->light_samples;
+  std::vector<LightSample> tmp_samples;
+  const std::vector<LightSample> &samples = event_light_samples(rs, cxt, &tmp_samples);
   for (size_t i = 0; i < samples.size(); i++) {
     LightOut L;
     Illuminance(rs, cxt, samples[i], in.P, Nf, rs->cos_half_pi, in, &L);
@@ -465,7 +537,8 @@ static int SlTrace(RenderState *rs, const Cxt &cxt, const V3 &orig, const V3 &di
 static void HairEvaluate(RenderState *rs, const fj_shader_desc &sh, const Cxt &cxt, const SurfIn &in, SurfOut *out)
 {
   out->Cs = Col();
-  const std::vector<LightSample> &samples = rs->sc->light_samples;
+  std::vector<LightSample> tmp_samples;
+  const std::vector<LightSample> &samples = event_light_samples(rs, cxt, &tmp_samples);
   for (size_t i = 0; i < samples.size(); i++) {
     LightOut L;
     L.Cl = Col(); L.Ln = V3(); L.distance = 0;
@@ -597,10 +670,13 @@ static int build_light_samples(Scene *sc)
 {
   const fj_scene_desc *d = sc->d;
   sc->light_samples.clear();
+  sc->light_xfm.resize(d->n_lights);
+  sc->has_area_lights = false;
   for (int i = 0; i < d->n_lights; i++) {
     const fj_light_desc &L = d->lights[i];
     Xfm x;
     LerpXfm(L.xform, 0, &x);
+    sc->light_xfm[i] = x;
     if (L.type == FJ_POINT_LIGHT) {
       LightSample s;
       s.light = i; s.P = x.translate; s.N = V3();
@@ -617,8 +693,16 @@ static int build_light_samples(Scene *sc)
         s.color = Col(ds.color[0], ds.color[1], ds.color[2]);
         sc->light_samples.push_back(s);
       }
+    } else if (L.type == FJ_GRID_LIGHT || L.type == FJ_SPHERE_LIGHT) {
+      // get_sample_count() = sample density; positions are drawn per shading event
+      for (int k = 0; k < L.sample_count; k++) {
+        LightSample s;
+        s.light = i;
+        sc->light_samples.push_back(s);
+      }
+      sc->has_area_lights = true;
     } else {
-      return -1;   // grid / sphere lights draw from a shared racy RNG
+      return -1;
     }
   }
   return 0;

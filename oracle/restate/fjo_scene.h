@@ -73,7 +73,10 @@ struct Scene {
   std::vector<PrimSet> meshes, curves;
   std::vector<Instance> instances;
   std::vector<Group> groups;
-  std::vector<LightSample> light_samples;   // deterministic lights only
+  std::vector<LightSample> light_samples;   // deterministic lights; one placeholder per sample of an
+                                            // area light (filled per shading event, fjo_render.cc)
+  bool has_area_lights = false;
+  std::vector<Xfm> light_xfm;               // per light, time 0
   bool lights_deterministic;
 };
 

@@ -50,6 +50,10 @@ FRAMES = {
 # restatement and the device use the counter-based stream of DESIGN.md 4
 STAT_FRAMES = {
     "stat_c4_cornell_64x48_8spp": ("cornell", dict(res=(64, 48), spp=(8, 8), mesh="tiny")),
+    # area lights draw from one unsynchronised XorShift per light in the reference
+    "stat_area_grid_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="grid")),
+    "stat_area_sphere_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="sphere")),
+    "stat_area_both_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="both")),
 }
 
 

@@ -81,6 +81,16 @@ def test_pathtracing_matches_oracle(kw, asset_dir):
     assert float(rel_err(fb, ref).max()) <= REL_TOL
 
 
+@pytest.mark.parametrize("kind", ["grid", "sphere", "both"])
+def test_area_lights_match_oracle(kind, asset_dir):
+    """RectangleLight / SphereLight with the per-event counter-based stream: the device draws
+    the same positions as the oracle -- same shadow rays (counts equal), same pixels."""
+    fb, st, ref, rc = render_both(workloads.arealights(asset_dir, res=(64, 48), spp=(3, 3), mesh="tiny", kind=kind))
+    assert st.rays.as_dict() == rc.as_dict()
+    assert rc.shadow > rc.camera
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_frames_match_oracle_and_reference_golden(name, asset_dir, golden_dir):
     builder, kw = CASES[name]
@@ -224,14 +234,19 @@ def test_si_render_scene_end_to_end(asset_dir):
 
 
 def test_unsupported_features_fail_loudly(asset_dir):
-    a = synth.ensure_assets(asset_dir, ("tiny",))
+    """features outside the device path: explicit error naming the feature, never a silent
+    approximation or a CPU fallback"""
     base = _custom_scene(asset_dir, lights=1)
-    # features outside the device path: explicit error naming the feature, no silent approximation
-    grid = base.replace("NewLight light0 PointLight", "NewLight light0 GridLight")
-    sp, rd = prepare(grid)
+    adaptive = base.replace("RenderScene ren1", "SetProperty1 ren1 sampler_type 1\nRenderScene ren1")
+    sp, rd = prepare(adaptive)
+    gs = gpu.Scene(sp)
     with pytest.raises(gpu.GpuError) as e:
-        gpu.Scene(sp)
-    assert "GridLight" in str(e.value)
+        gs.render_frame(rd)
+    gs.close()
+    assert "fixed grid sampler" in str(e.value)
+    with pytest.raises(Exception) as e:
+        prepare(base.replace("OpenPlugin plastic_shader PlasticShader.so", "OpenPlugin plastic_shader VolumeShader.so"))
+    assert "no device implementation" in str(e.value) or "VolumeShader" in str(e.value)
 
 
 def test_full_size_headline_properties(asset_dir):
