@@ -171,6 +171,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
       const fj_mesh_desc &m = *h.mesh;
       e |= M.upload(h.tri_verts.data(), h.tri_verts.size(), &d.tri_verts);
       e |= M.upload(h.tri_verts32.data(), h.tri_verts32.size(), &d.tri_verts32);
+      e |= M.upload(h.tri_vel.data(), h.tri_vel.size(), &d.tri_vel);
+      e |= M.upload(m.velocity, m.velocity ? (size_t) m.n_points * 3 : 0, &d.velocity);
       e |= M.upload(m.P, (size_t) m.n_points * 3, &d.P);
       e |= M.upload(m.N, m.N ? (size_t) m.n_points * 3 : 0, &d.N);
       e |= M.upload(m.uv, m.uv ? (size_t) m.n_points * 2 : 0, &d.uv);
@@ -202,6 +204,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.cam_xform = nullptr;
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
+  for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
   S.pad_ = 0;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);

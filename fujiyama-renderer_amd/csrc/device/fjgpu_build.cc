@@ -378,7 +378,6 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
   ps->type = FJ_PRIMSET_MESH;
   ps->mesh = &m;
   ps->curve = nullptr;
-  if (m.velocity) { *err = "mesh velocity (motion blur) is not on the device path yet"; return FJGPU_EUNSUPPORTED; }
   if (m.n_faces > (1 << 28)) { *err = "mesh too large"; return FJGPU_EINVAL; }
   for (int k = 0; k < 3; k++) { ps->bounds[k] = m.bounds[k] - ACC_PADDING; ps->bounds[3 + k] = m.bounds[3 + k] + ACC_PADDING; }
   StageTimer tm;
@@ -390,7 +389,13 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
       for (int k = 0; k < 3; k++) {
         const int p = m.indices[3 * f + k];
         if (p < 0 || p >= m.n_points) { bad = 1; return; }
-        for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], m.P[3 * p + c]); mx[c] = std::max(mx[c], m.P[3 * p + c]); }
+        for (int c = 0; c < 3; c++) {
+          mn[c] = std::min(mn[c], m.P[3 * p + c]); mx[c] = std::max(mx[c], m.P[3 * p + c]);
+          if (m.velocity) {      // swept over the shutter [0, 1]: Mesh::get_primitive_bounds, src/fj_mesh.cc:310-340
+            const double q = m.P[3 * p + c] + m.velocity[3 * p + c];
+            mn[c] = std::min(mn[c], q); mx[c] = std::max(mx[c], q);
+          }
+        }
       }
       PrimRef &r = refs[f];
       for (int c = 0; c < 3; c++) { r.bmin[c] = down2(mn[c]); r.bmax[c] = up2(mx[c]); r.c[c] = (float) (.5 * (mn[c] + mx[c])); }
@@ -423,6 +428,18 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
       }
     }
   });
+  if (m.velocity) {
+    ps->tri_vel.resize((size_t) ps->n_prims * 9);
+    ParallelFor((size_t) ps->n_prims, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) {
+        const int f = (int) ps->prim_ids[i];
+        for (int k = 0; k < 3; k++) {
+          const int p = m.indices[3 * f + k];
+          for (int c = 0; c < 3; c++) ps->tri_vel[i * 9 + 3 * k + c] = m.velocity[3 * p + c];
+        }
+      }
+    });
+  }
   tm.lap("triangle gather", m.n_faces);
   return 0;
 }

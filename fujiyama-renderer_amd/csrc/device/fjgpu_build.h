@@ -23,6 +23,7 @@ struct HostPrimSet {
   int type;
   NodeArray nodes;
   std::vector<double> tri_verts;      // mesh: [n][9]  (empty when tri_verts32 is used)
+  std::vector<double> tri_vel;        // mesh: [n][9] vertex velocities in leaf order (empty = static)
   std::vector<float> tri_verts32;     // mesh: [n][9]  all coordinates exactly representable in f32
   std::vector<uint32_t> prim_ids;
   std::vector<double> curve_cp;       // curves: [n][12]

@@ -650,6 +650,10 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         } else {
           V3 v0, v1, v2;
           load_tri(P->tri_verts, P->tri_verts32, first + k, &v0, &v1, &v2);
+          if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
+            const double *w = P->tri_vel + (size_t) (first + k) * 9;
+            v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
+          }
           if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
         }
         if (!(tmin <= t && t <= tmax)) continue;
@@ -1082,7 +1086,13 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           if (has_uv) {
             // TriComputeDerivatives (src/fj_triangle.cc:51-74) on the object-space
             // vertices, then the instance's M as a vector transform
-            const V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
+              const double tm_ = sample_time(S, p.uid & 0xfffffu);
+              p0 = p0 + tm_ * ld3(P->velocity + 3 * (size_t) i0);
+              p1 = p1 + tm_ * ld3(P->velocity + 3 * (size_t) i1);
+              p2 = p2 + tm_ * ld3(P->velocity + 3 * (size_t) i2);
+            }
             const V3 dP1 = p1 - p0, dP2 = p2 - p0;
             const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;
             const float determinant = du1 * dv2 - dv1 * du2;
@@ -1183,7 +1193,13 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
         }
         if (sh->bump_map >= 0) {
           if (has_uv) {
-            const V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
+              const double tm_ = sample_time(S, p.uid & 0xfffffu);
+              p0 = p0 + tm_ * ld3(P->velocity + 3 * (size_t) i0);
+              p1 = p1 + tm_ * ld3(P->velocity + 3 * (size_t) i1);
+              p2 = p2 + tm_ * ld3(P->velocity + 3 * (size_t) i2);
+            }
             const V3 dP1 = p1 - p0, dP2 = p2 - p0;
             const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;
             const float determinant = du1 * dv2 - dv1 * du2;

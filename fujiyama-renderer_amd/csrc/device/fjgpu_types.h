@@ -34,6 +34,9 @@ struct DPrimSet {
   const float *tri_verts32;    // [n_prims][9]  the same values as f32 (36 B / tri) when EVERY coordinate of the
                                //               mesh is exactly representable in f32 (PLY data is); widened to
                                //               f64 on load, so the test sees identical operands
+  const double *tri_vel;       // [n_prims][9]  per-vertex velocities in leaf order (Mesh::ray_intersect
+                               //               moves each vertex by time * velocity) or null = static mesh
+  const double *velocity;      // [n_points][3] the same per point (derivatives in the shading kernel) or null
   const uint32_t *prim_ids;    // [n_prims]     original primitive id of leaf slot k
   const double *P;             // [n_points][3] object-space positions (attribute fetch)
   const double *N;             // [n_points][3] or null

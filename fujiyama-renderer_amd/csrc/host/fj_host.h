@@ -145,6 +145,7 @@ Scene *get_scene();
 // procedures (fj_host_procedures.cc)
 int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err);
 int RunProcedure(Scene *sc, Procedure *proc, std::string *err);
+int RunVelocityGenerator(Scene *sc, Procedure *proc, std::string *err);
 
 // dome light importance sampling (fj_host_dome.cc)
 int PreprocessDomeLight(Scene *sc, Light *light);

@@ -93,7 +93,40 @@ double smooth_step(double a, double b, double x)        // src/fj_numeric.h:76-8
 
 inline double unit_rand() { return ((double) std::rand()) / RAND_MAX; }
 
+// PerlinNoise3d, src/fj_noise.cc:50-66: three decorrelated scalar fields
+V perlin_noise3d(V P, double lacunarity, double persistence, int octaves)
+{
+  V out;
+  out.x = perlin_noise(P, lacunarity, persistence, octaves);
+  out.y = perlin_noise(P + V{131.977, 21.1823, 71.0231}, lacunarity, persistence, octaves);
+  out.z = perlin_noise(P + V{237.492, 11.1312, 133.129}, lacunarity, persistence, octaves);
+  return out;
+}
+
 }  // namespace
+
+// VelocityGeneratorProcedure (procedures/velocity_generator_procedure/
+// velocity_generator_procedure.cc:98-121): a noise velocity field that fades out along z,
+// then ComputeNormals + ComputeBounds (the bounds now include the end-of-shutter positions)
+int RunVelocityGenerator(Scene *sc, Procedure *proc, std::string *err)
+{
+  if (proc->mesh < 0) { *err = "VelocityGeneratorProcedure: no mesh assigned"; return -1; }
+  Mesh &mesh = *sc->meshes[proc->mesh];
+  const int n = mesh.point_count();
+  const double zmin = mesh.bounds[2], zmax = mesh.bounds[5];
+  mesh.velocity.assign((size_t) n * 3, 0.);
+  for (int i = 0; i < n; i++) {
+    const V pos = at(mesh.P, i);
+    const double znml = (pos.z - zmin) / (zmax - zmin);
+    const double vscale = .2 * (1 - smooth_step(.2, .7, znml));
+    const V noise_vec = perlin_noise3d(.2 * pos, 2, .5, 1);
+    const V vel = vscale * noise_vec;
+    mesh.velocity[3 * i] = vel.x; mesh.velocity[3 * i + 1] = vel.y; mesh.velocity[3 * i + 2] = vel.z;
+  }
+  mesh.ComputeNormals();
+  mesh.ComputeBounds();
+  return 0;
+}
 
 // Curve::ComputeBounds, src/fj_curve.cc:124-146: union of the per-curve bounds (control
 // points +- that curve's max radius, at shutter open and close), expanded once more by

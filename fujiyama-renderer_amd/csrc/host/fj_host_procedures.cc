@@ -198,6 +198,7 @@ int RunProcedure(Scene *sc, Procedure *proc, std::string *err)
     return ReadPlyFile(fp->second, sc->meshes[proc->mesh].get(), err);
   }
   if (proc->plugin->name == "CurveGeneratorProcedure") return RunCurveGenerator(sc, proc, err);
+  if (proc->plugin->name == "VelocityGeneratorProcedure") return RunVelocityGenerator(sc, proc, err);
   *err = "procedure " + proc->plugin->name + " is not built in";
   return -1;
 }

@@ -550,6 +550,7 @@ ID SiOpenPlugin(const char *filename)
     {"GlassShader", PLUGIN_SHADER, FJ_SHADER_GLASS}, {"HairShader", PLUGIN_SHADER, FJ_SHADER_HAIR},
     {"PathtracingShader", PLUGIN_SHADER, FJ_SHADER_PATHTRACING},
     {"StanfordPlyProcedure", PLUGIN_PROCEDURE, 0}, {"CurveGeneratorProcedure", PLUGIN_PROCEDURE, 0},
+    {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0},
   };
   for (const auto &k : known)
     if (base == k.name) {

@@ -161,8 +161,9 @@ def dragon(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="dragon", nlights=32, e
 def motion(asset_dir, res=(640, 480), spp=(9, 9), mesh="small", kind="object", nlights=4, extra=()):
     """Motion blur by time-sampled transforms (scenes/transform_motion_blur.py,
     scenes/camera_motion_blur.py): `kind` = "object" (the mesh rotates and moves over the
-    shutter), "camera" (the camera dollies and pans), "both", or "scale" (an object that
-    also grows: three samples per channel, not evenly spaced)."""
+    shutter), "camera" (the camera dollies and pans), "both", "scale" (an object that also
+    grows: three samples per channel, not evenly spaced), "velocity" (per-vertex velocities
+    from VelocityGeneratorProcedure, scenes/mesh_velocity_blur.py) or "velocity+object"."""
     a = synth.ensure_assets(asset_dir, (mesh,))
     si = SceneInterface(parse_args=False)
     si.OpenPlugin("plastic_shader", "PlasticShader")
@@ -181,8 +182,14 @@ def motion(asset_dir, res=(640, 480), spp=(9, 9), mesh="small", kind="object", n
     si.NewShader("dragon_shader0", "plastic_shader")
     si.SetProperty3("dragon_shader0", "diffuse", .7, .05, .1)
     _ply(si, "dragon_mesh", a[mesh])
+    if kind in ("velocity", "velocity+object"):
+        # per-vertex velocities (scenes/mesh_velocity_blur.py)
+        si.OpenPlugin("velocity_generator_procedure", "VelocityGeneratorProcedure")
+        si.NewProcedure("velgen_proc", "velocity_generator_procedure")
+        si.AssignMesh("velgen_proc", "mesh", "dragon_mesh")
+        si.RunProcedure("velgen_proc")
     si.NewObjectInstance("dragon1", "dragon_mesh")
-    if kind in ("object", "both"):
+    if kind in ("object", "both", "velocity+object"):
         si.SetSampleProperty3("dragon1", "translate", .2, 0, 0, 0)
         si.SetSampleProperty3("dragon1", "translate", .5, .2, 0, 1)
         si.SetSampleProperty3("dragon1", "rotate", 0, -35, 0, 0)

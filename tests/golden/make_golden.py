@@ -39,6 +39,8 @@ FRAMES = {
     "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
     "motion_both_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
     "motion_scale_3samples_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="scale")),
+    "motion_vertex_velocity_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="velocity")),
+    "motion_velocity_and_object_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="velocity+object")),
     "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
                                   extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
                                          ("filterwidth", (3, 2.5))))),
