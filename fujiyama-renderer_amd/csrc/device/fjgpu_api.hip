@@ -78,6 +78,7 @@ struct fjgpu_scene {
   int max_children;                // most child rays one shading event can emit in this scene
   DHit *d_hits;
   DLightRec *d_lrecs;
+  DLightHair *d_lhair;             // only when the scene has a HairShader
   DShadowRay *d_squeue;
   size_t squeue_cap;
   DCounters *d_cnt;
@@ -207,6 +208,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
   S.pad_ = 0;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
+  S.lrec_hair = nullptr;
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
   e |= M.upload(hs.light_samples.data(), hs.light_samples.size(), &S.light_samples);
   e |= M.upload(hs.area_lights.data(), hs.area_lights.size(), &S.area_lights);
@@ -309,6 +311,8 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
     e |= W.alloc(rays, &sc->d_hits);
     e |= W.alloc(rays, &sc->d_lrecs);
+    sc->d_lhair = nullptr;
+    if (sc->S.has_hair) e |= W.alloc(rays, &sc->d_lhair);
     sc->squeue_cap = std::min<size_t>(rays * 8, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     e |= W.alloc(1, &sc->d_cnt);
@@ -400,6 +404,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   S.cam_uv_size[1] = fjgpu::CameraUvSizeY(sc->cam_fov);
   S.cam_uv_size[0] = S.cam_uv_size[1] * aspect;
   S.time_tab = sc->d_tim; S.time_start = r->time_start; S.time_end = r->time_end;
+  S.lrec_hair = sc->d_lhair;
 
   GenParams gp;
   gp.rate_x = r->rate_x; gp.rate_y = r->rate_y; gp.margin_x = margin[0]; gp.margin_y = margin[1];

@@ -723,6 +723,7 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? 1 : FJ_CLOSEST_M
 // per-tile XorShift streams read from host-built tables (the stream restarts
 // for every tile, so draw k is the same number in every tile), then
 // Camera::GetRay (src/fj_camera.cc:79-110) with the host-built camera matrix.
+template <bool kMovingCamera>
 __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, const TileDesc *tiles,
     const double *jitter_tab, const double *time_tab, double *s_uv, DRay *rays, DPath *paths)
 {
@@ -751,7 +752,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   // sample's time, a static one uses the host-built matrix
   const double *cam = S.cam_M;
   double cm[12], cmi[12];
-  if (S.cam_xform) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
+  if (kMovingCamera) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
   const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
   const V3 tw = xpoint(cam, target);
   const V3 eye = mk(cam[3], cam[7], cam[11]);
@@ -983,6 +984,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
   c0.want = c1.want = c2.want = false;
   bool want_light = false;
   DLightRec lr;
+  DLightHair lh;
+  lr.kind = 0;
   uint32_t sample = 0, rng = 0, uid = 0;
 
   if (hit) {
@@ -1116,12 +1119,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           lr.W[0] = p.T[0] * (sh->diffuse[0] * dm[0]);
           lr.W[1] = p.T[1] * (sh->diffuse[1] * dm[1]);
           lr.W[2] = p.T[2] * (sh->diffuse[2] * dm[2]);
-          lr.Cd[0] = lr.Cd[1] = lr.Cd[2] = 0.f;
-          for (int k = 0; k < 6; k++) lr.aux[k] = 0;
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 0;
-          lr.uid = p.uid; lr.key = p.rng; lr.pad = 0;
+          lr.uid = p.uid; lr.key = p.rng;
           if (lr.W[0] == 0.f && lr.W[1] == 0.f && lr.W[2] == 0.f && !sp.count_all_shadow) want_light = false;
         }
         if (sh->do_reflect && (int) p.rdepth + 1 <= sp.max_reflect_depth) {
@@ -1171,14 +1172,14 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
           want_light = true;
           lr.P[0] = Pw.x; lr.P[1] = Pw.y; lr.P[2] = Pw.z;
           lr.N[0] = N.x; lr.N[1] = N.y; lr.N[2] = N.z;     // illuminance axis = in.N (zero for curves)
-          lr.aux[0] = tangent.x; lr.aux[1] = tangent.y; lr.aux[2] = tangent.z;
-          lr.aux[3] = Iw.x; lr.aux[4] = Iw.y; lr.aux[5] = Iw.z;
+          lh.aux[0] = tangent.x; lh.aux[1] = tangent.y; lh.aux[2] = tangent.z;
+          lh.aux[3] = Iw.x; lh.aux[4] = Iw.y; lh.aux[5] = Iw.z;
           lr.W[0] = p.T[0]; lr.W[1] = p.T[1]; lr.W[2] = p.T[2];
-          lr.Cd[0] = Cd[0] * sh->diffuse[0]; lr.Cd[1] = Cd[1] * sh->diffuse[1]; lr.Cd[2] = Cd[2] * sh->diffuse[2];
+          lh.Cd[0] = Cd[0] * sh->diffuse[0]; lh.Cd[1] = Cd[1] * sh->diffuse[1]; lh.Cd[2] = Cd[2] * sh->diffuse[2]; lh.pad = 0;
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 1;
-          lr.uid = p.uid; lr.key = p.rng; lr.pad = 0;
+          lr.uid = p.uid; lr.key = p.rng;
         }
         Os = 1.f;
         break;
@@ -1278,7 +1279,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
   // ---- compaction: ballot + prefix count, one atomic per wave and queue
   const uint32_t lslot = wave_append(want_light, &cnt->light_count, nullptr);
   if (want_light) {
-    if (lslot < sp.light_capacity) lrecs[lslot] = lr;
+    if (lslot < sp.light_capacity) {
+      lrecs[lslot] = lr;
+      if (lr.kind == 1 && S.lrec_hair) S.lrec_hair[lslot] = lh;
+    }
     else cnt->overflow = 1;
   }
   emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity);
@@ -1333,7 +1337,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     const uint32_t nl = (uint32_t) S.n_light_samples;
     const uint32_t iters = (nl + sp.lanes - 1) / sp.lanes;     // uniform trip count: ballots stay convergent
     DLightRec R;
-    R.uid = R.key = 0;
+    DLightHair H;
+    for (int q = 0; q < 6; q++) H.aux[q] = 0;
+    H.Cd[0] = H.Cd[1] = H.Cd[2] = 0.f;
+    R.uid = R.key = 0; R.kind = 0;
     XS xs = {0, 0, 0, 0};
     V3 Ps = mk(0, 0, 0), axis = Ps, nml_axis = Ps;
     int g_first = 0, g_count = 0;
@@ -1341,6 +1348,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     double cos_limit = 0;
     if (active) {
       R = lrecs[rec];
+      if (kHair && R.kind == 1) H = S.lrec_hair[rec];
       Ps = mk(R.P[0], R.P[1], R.P[2]);
       axis = mk(R.N[0], R.N[1], R.N[2]);
       nml_axis = normalize(axis);
@@ -1408,17 +1416,17 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             k[0] = Kd * Cl[0]; k[1] = Kd * Cl[1]; k[2] = Kd * Cl[2];
           } else {                       // hair_shader.cc:184-206 (the plugin's sqrt / pow are the C
                                          // library's double versions on float arguments)
-            const V3 tangent = mk(R.aux[0], R.aux[1], R.aux[2]);
-            const V3 Iv = mk(R.aux[3], R.aux[4], R.aux[5]);
+            const V3 tangent = mk(H.aux[0], H.aux[1], H.aux[2]);
+            const V3 Iv = mk(H.aux[3], H.aux[4], H.aux[5]);
             const float TL = (float) dot(tangent, Ln);
             const float diff = (float) sqrt((double) (1 - TL * TL));
             const float roughness = .05f;
             const float TI = (float) dot(tangent, Iv);
             float spec = (float) (sqrt((double) (1 - TL * TL)) * sqrt((double) (1 - TI * TI)) + (double) (TL * TI));
             spec = (float) pow((double) spec, (double) (1 / roughness));
-            k[0] = (R.Cd[0] * diff + spec) * Cl[0];
-            k[1] = (R.Cd[1] * diff + spec) * Cl[1];
-            k[2] = (R.Cd[2] * diff + spec) * Cl[2];
+            k[0] = (H.Cd[0] * diff + spec) * Cl[0];
+            k[1] = (H.Cd[1] * diff + spec) * Cl[1];
+            k[2] = (H.Cd[2] * diff + spec) * Cl[2];
           }
           bool maybe_occluded = false;
           if (sp.cast_shadow) {
@@ -1912,7 +1920,8 @@ int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, cons
     uint32_t max_tile_samples, const double *jit, const double *tim, double *s_uv, DRay *rays, DPath *paths)
 {
   dim3 grid((max_tile_samples + BLOCK - 1) / BLOCK, n_tiles);
-  hipLaunchKernelGGL(k_gen_camera, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
+  if (S.cam_xform) hipLaunchKernelGGL(k_gen_camera<true>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
+  else hipLaunchKernelGGL(k_gen_camera<false>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
   LAUNCH_CHECK();
   return 0;
 }

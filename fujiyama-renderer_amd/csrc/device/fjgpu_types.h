@@ -107,6 +107,8 @@ struct DAreaLight {
   int32_t pad;
 };
 
+struct DLightHair;
+
 struct DScene {
   const DPrimSet *primsets;
   const DInstance *instances;
@@ -115,6 +117,7 @@ struct DScene {
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;
+  DLightHair *lrec_hair;       // work buffer (set per render call) or null
   const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
@@ -161,17 +164,20 @@ struct DHit {                  // 32 B
   int32_t inst, prim;          // inst < 0: miss
 };
 
-struct DLightRec {             // one shading event that gathers direct light
+struct DLightRec {             // 80 B: one shading event that gathers direct light
   double P[3];
   double N[3];                 // illuminance axis (Nf for plastic, N for hair)
-  double aux[6];               // hair: tangent (3), I (3)
   float W[3];                  // throughput * diffuse * diffuse_map (plastic) or throughput (hair)
-  float Cd[3];                 // hair: Cd * diffuse
   uint32_t sample;
   int32_t group;               // shadow target of the shaded object
-  int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair)
+  int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair: + DLightHair of the same slot)
   uint32_t uid;                // DPath.uid of the shading ray (its low 20 bits index the sample's time)
   uint32_t key;                // path key of the shading ray (area-light stream, with uid)
+};
+
+struct DLightHair {            // 64 B, only in scenes with a HairShader: same slot as its DLightRec
+  double aux[6];               // tangent (3), I (3)
+  float Cd[3];                 // Cd * diffuse
   uint32_t pad;
 };
 
