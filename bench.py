@@ -118,14 +118,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
+    torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=device)
 
     # ---------------- untimed: assets, scene, BLAS build, upload
     kw = {}
