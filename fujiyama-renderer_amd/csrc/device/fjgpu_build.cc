@@ -92,6 +92,7 @@ struct Builder {
   std::atomic<uint32_t> next_node;
   std::atomic<int> max_depth;
   int max_leaf;
+  float trav_cost;                         // cost of one node step in primitive tests (SAH leaf decision)
 
   static void grow(float *mn, float *mx, const float *a, const float *b)
   {
@@ -146,7 +147,7 @@ struct Builder {
     while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
     if (n <= max_leaf) {
       // leaves of <= 4 prims are always accepted at or below max_leaf
-      if (n <= 2 || depth >= FJ_BVH_MAX_DEPTH - 2) return leaf_ref(begin, n);
+      if (n <= std::min(2, max_leaf) || depth >= FJ_BVH_MAX_DEPTH - 2) return leaf_ref(begin, n);
     }
 
     // binned SAH on the axis with the widest centroid extent
@@ -207,7 +208,7 @@ struct Builder {
       if (best_b >= 0) {
         // leaf cost vs split cost (traversal cost 1 node ~ 1.2 triangle tests)
         const float parent_area = half_area(mn, mx);
-        if (n <= max_leaf && best + 1.2f * parent_area >= parent_area * n) return leaf_ref(begin, n);
+        if (n <= max_leaf && best + trav_cost * parent_area >= parent_area * n) return leaf_ref(begin, n);
         if (big) {
           // out-of-place parallel partition: per-chunk counts, prefix, scatter, copy back
           int nleft = 0;
@@ -328,7 +329,7 @@ struct Builder {
 float RoundDown2(double v) { return down2(v); }
 float RoundUp2(double v) { return up2(v); }
 
-void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
+void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float trav_cost)
 {
   Builder b;
   b.prims.swap(refs);
@@ -337,7 +338,8 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs)
   b.nodes.reset(new Node2[(size_t) std::max(n, 1) + 1024 * 132]);
   b.next_node = 0;
   b.max_depth = 0;
-  b.max_leaf = FJ_MAX_LEAF_PRIMS;
+  b.max_leaf = std::max(1, std::min(max_leaf, FJ_MAX_LEAF_PRIMS));
+  b.trav_cost = trav_cost;
   float mn[3], mx[3];
   if (n == 0) {
     ps->root = FJ_LEAF_FLAG;   // never dereferenced: n_prims == 0 is checked first
@@ -405,7 +407,7 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
   if (bad) { *err = "mesh index out of range"; return FJGPU_EINVAL; }
   tm.lap("primitive boxes", m.n_faces);
   for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
-  BuildBlas(ps, refs);
+  BuildBlas(ps, refs, FJ_MAX_LEAF_PRIMS, 1.2f);    // a node step ~ 1.2 triangle tests
   tm.lap("BLAS total", m.n_faces);
   // pre-gathered vertices in leaf order; as f32 when that loses nothing (meshes read from
   // PLY files carry f32 coordinates): half the bytes per triangle test, identical operands

@@ -60,7 +60,7 @@ struct HostScene {
 
 // BLAS build over arbitrary primitive boxes (meshes and curve sets share it)
 struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
-void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs);
+void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float trav_cost);
 float RoundDown2(double v);   // f64 -> f32 toward -inf, one more ulp outward
 float RoundUp2(double v);
 

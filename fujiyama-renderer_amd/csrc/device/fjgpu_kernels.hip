@@ -506,6 +506,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   bool anyhit = false, dead_ray = false, plain = false;
   const DPrimSet *P = nullptr;
   uint32_t cur = TRAV_DONE;
+  uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
   int sp = 0;
 
   for (;;) {
@@ -579,7 +580,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         found = true;
         break;
       }
-      if (found) { cur = P->root; sp = 0; }
+      if (found) { cur = P->root; sp = 0; last_curve = 0xffffffffu; }
       else { pol.finish(idx, best); have = false; }
     }
 
@@ -639,10 +640,16 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 #endif
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u = 0, v = 0;
-        if (kCount) lc->prims++;
+        if (kCount && !(kCurves && is_curve)) lc->prims++;
         if (kCurves && is_curve) {
-          // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
+          // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch).
+          // BLAS entries are sub-segments of curves: the full ribbon test of a curve runs
+          // once, not once per piece entered (same ray, same instance: same result)
           const size_t sl = first + k;
+          const uint32_t cid = P->prim_ids[sl];
+          if (cid == last_curve) continue;
+          last_curve = cid;
+          if (kCount) lc->prims++;
           if (!curve_ray(P->curve_cp + sl * 12, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
                          (int) P->curve_depth[sl], oo, od, &t, &u)) continue;
           if (!curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
