@@ -704,6 +704,9 @@ struct ClosestPolicy {
   }
 };
 
+#ifndef FJ_CURVE_MINB
+#define FJ_CURVE_MINB 2
+#endif
 #ifndef FJ_CLOSEST_MINB
 #define FJ_CLOSEST_MINB 3
 #endif
@@ -711,7 +714,7 @@ struct ClosestPolicy {
 #define FJ_SHADOW_MINB 1
 #endif
 template <bool kCurves, bool kCount, bool kMotion>
-__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? 1 : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
@@ -1563,7 +1566,7 @@ struct ShadowPolicy {
 };
 
 template <bool kCurves, bool kCount, bool kMotion>
-__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? 1 : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
+__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
