@@ -24,8 +24,10 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 #define FJ_MAX_LEAF_PRIMS 4
 #endif
 #define FJ_BVH_MAX_DEPTH 40          // depth bound of the binary tree the builder collapses
+#ifndef FJ_STACK_LDS
 #define FJ_STACK_LDS 32              // traversal stack entries per lane kept in LDS; deeper
                                      // entries (rare) go to a global overflow area
+#endif
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
