@@ -11,6 +11,7 @@
 // has at most a few dozen entries and is kept as a flat per-group list with
 // world-space AABBs.
 #include "fjgpu_build.h"
+#include "fjgpu_xform_math.h"
 #include "fjgpu.h"
 
 #include <algorithm>
@@ -580,12 +581,11 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
     MakeTransform(L.xform, 0, M, Minv);
     if (L.type == FJ_POINT_LIGHT) {
       DLightSample s;
-      // Transform.translate of the lerped sample (channel value itself)
-      s.P[0] = L.xform.translate[0].v[0]; s.P[1] = L.xform.translate[0].v[1]; s.P[2] = L.xform.translate[0].v[2];
-      if (L.xform.n_translate > 1 && !(L.xform.translate[0].time >= 0)) {
-        *err = "time-sampled light transforms are not on the device path yet";
-        return FJGPU_EUNSUPPORTED;
-      }
+      // Transform.translate of the sample list evaluated at time 0 (lights are not time
+      // sampled in the reference: "TODO time sampling", src/fj_point_light.cc:25-27)
+      double T0[3] = {0, 0, 0};
+      fjx::lerp_samples(L.xform.translate, L.xform.n_translate, 0., T0);
+      s.P[0] = T0[0]; s.P[1] = T0[1]; s.P[2] = T0[2];
       for (int k = 0; k < 3; k++) s.Cl[k] = L.intensity * L.color[k];   // PointLight::illuminate
       s.light = i; s.type = FJ_POINT_LIGHT; s.ordinal = 0;
       out->light_samples.push_back(s);
