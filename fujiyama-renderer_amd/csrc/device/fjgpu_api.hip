@@ -16,6 +16,7 @@
 #include "fjgpu.h"
 #include "fjgpu_build.h"
 #include "fjgpu_kernels.h"
+#include "fjgpu_lbvh.h"
 
 namespace {
 
@@ -92,7 +93,16 @@ struct fjgpu_scene {
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
 };
 
+static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip)
+
 extern "C" {
+
+int fjgpu_global_option(const char *name, long value)
+{
+  if (!name) return fail(FJGPU_EINVAL, "bad option call");
+  if (std::string(name) == "device_build") { g_device_build = value != 0; return 0; }
+  return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
+}
 
 const char *fjgpu_last_error(void) { return t_last_error.c_str(); }
 
@@ -128,7 +138,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   fjgpu::HostScene hs;
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
-  const int be = fjgpu::BuildHostScene(desc, &hs, &err);
+  const bool device_build = g_device_build || getenv("FJGPU_DEVICE_BUILD") != nullptr;
+  const int be = fjgpu::BuildHostScene(desc, &hs, &err, device_build);
   if (getenv("FJGPU_VERBOSE"))
     fprintf(stderr, "fjgpu: host scene build (BLAS, transforms, lights) %.3f s\n",
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
@@ -166,19 +177,42 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     d.n_prims = h.n_prims;
     std::memcpy(d.bounds, h.bounds, sizeof(d.bounds));
     for (int k = 0; k < 3; k++) { d.grid_cell[k] = h.grid_cell[k]; d.grid_n[k] = h.grid_n[k]; }
-    e |= M.upload(h.nodes.data(), h.nodes.size(), &d.nodes);
-    e |= M.upload(h.prim_ids.data(), h.prim_ids.size(), &d.prim_ids);
+    if (!h.device_build) {
+      e |= M.upload(h.nodes.data(), h.nodes.size(), &d.nodes);
+      e |= M.upload(h.prim_ids.data(), h.prim_ids.size(), &d.prim_ids);
+    }
     if (h.type == FJ_PRIMSET_MESH) {
       const fj_mesh_desc &m = *h.mesh;
-      e |= M.upload(h.tri_verts.data(), h.tri_verts.size(), &d.tri_verts);
-      e |= M.upload(h.tri_verts32.data(), h.tri_verts32.size(), &d.tri_verts32);
-      e |= M.upload(h.tri_vel.data(), h.tri_vel.size(), &d.tri_vel);
       e |= M.upload(m.velocity, m.velocity ? (size_t) m.n_points * 3 : 0, &d.velocity);
       e |= M.upload(m.P, (size_t) m.n_points * 3, &d.P);
       e |= M.upload(m.N, m.N ? (size_t) m.n_points * 3 : 0, &d.N);
       e |= M.upload(m.uv, m.uv ? (size_t) m.n_points * 2 : 0, &d.uv);
       e |= M.upload(m.indices, (size_t) m.n_faces * 3, &d.indices);
       e |= M.upload(m.face_group, m.face_group ? (size_t) m.n_faces : 0, &d.face_group);
+      if (h.device_build) {
+        // BLAS on the device: Morton sort, radix tree, fit, collapse, triangle gather
+        if (e) return fail(FJGPU_ENOMEM, "device allocation / upload failed while creating the scene");
+        const auto tb0 = std::chrono::steady_clock::now();
+        LbvhOut lo;
+        std::string lerr;
+        if (LbvhBuildMesh(d.P, d.velocity, d.indices, m.n_faces, m.n_points, h.bounds, h.f32_exact, &lo, &lerr))
+          return fail(FJGPU_ENODEV, lerr);
+        for (void *p : {(void *) lo.nodes, (void *) lo.prim_ids, (void *) lo.tri_verts, (void *) lo.tri_verts32, (void *) lo.tri_vel})
+          if (p) M.ptrs.push_back(p);
+        d.nodes = lo.nodes; d.prim_ids = lo.prim_ids; d.root = lo.root;
+        d.tri_verts = lo.tri_verts; d.tri_verts32 = lo.tri_verts32; d.tri_vel = lo.tri_vel;
+        hs.primsets[i].stack_need = lo.stack_need;
+        hs.primsets[i].nodes.n = lo.n_nodes;
+        if (lo.tri_verts32) hs.primsets[i].tri_verts32.resize(1);      // (layout flags read below)
+        if (lo.tri_vel) hs.primsets[i].tri_vel.resize(1);
+        if (getenv("FJGPU_VERBOSE") && m.n_faces > 100000)
+          fprintf(stderr, "fjgpu: device BLAS build of %d triangles: %.3f s, %zu wide nodes\n", m.n_faces,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(), lo.n_nodes);
+      } else {
+        e |= M.upload(h.tri_verts.data(), h.tri_verts.size(), &d.tri_verts);
+        e |= M.upload(h.tri_verts32.data(), h.tri_verts32.size(), &d.tri_verts32);
+        e |= M.upload(h.tri_vel.data(), h.tri_vel.size(), &d.tri_vel);
+      }
     } else {
       e |= M.upload(h.curve_cp.data(), h.curve_cp.size(), &d.curve_cp);
       e |= M.upload(h.curve_width.data(), h.curve_width.size(), &d.curve_width);

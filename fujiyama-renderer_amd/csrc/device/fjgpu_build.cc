@@ -376,13 +376,27 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float 
 
 namespace {
 
-int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
+int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err, bool device_build)
 {
+  ps->device_build = false;
+  ps->f32_exact = false;
   ps->type = FJ_PRIMSET_MESH;
   ps->mesh = &m;
   ps->curve = nullptr;
   if (m.n_faces > (1 << 28)) { *err = "mesh too large"; return FJGPU_EINVAL; }
   for (int k = 0; k < 3; k++) { ps->bounds[k] = m.bounds[k] - ACC_PADDING; ps->bounds[3 + k] = m.bounds[3 + k] + ACC_PADDING; }
+  if (device_build) {
+    // the device builds the tree and gathers the triangles; the host only decides the layout
+    std::atomic<int> inexact0(0);
+    ParallelFor((size_t) m.n_points * 3, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) if ((double) (float) m.P[i] != m.P[i]) { inexact0 = 1; return; }
+    });
+    ps->device_build = true;
+    ps->f32_exact = !inexact0 && !getenv("FJGPU_NO_F32_TRIS");
+    ps->root = FJ_LEAF_FLAG; ps->n_prims = m.n_faces; ps->max_depth = 0; ps->stack_need = 0;
+    for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
+    return 0;
+  }
   StageTimer tm;
   std::vector<PrimRef> refs(m.n_faces);
   std::atomic<int> bad(0);
@@ -451,13 +465,13 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err)
 
 int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err);   // fjgpu_curve_build.cc
 
-int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err)
+int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, bool device_mesh_build)
 {
   if (!d) { *err = "null scene description"; return FJGPU_EINVAL; }
   out->n_meshes = d->n_meshes;
   out->primsets.resize(d->n_meshes + d->n_curves);
   for (int i = 0; i < d->n_meshes; i++) {
-    const int e = build_mesh(d->meshes[i], &out->primsets[i], err);
+    const int e = build_mesh(d->meshes[i], &out->primsets[i], err, device_mesh_build);
     if (e) return e;
   }
   for (int i = 0; i < d->n_curves; i++) {

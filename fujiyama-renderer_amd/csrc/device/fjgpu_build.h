@@ -37,6 +37,8 @@ struct HostPrimSet {
   int n_prims;
   int max_depth;
   int stack_need;                     // worst-case traversal stack entries (4-wide tree)
+  bool device_build;                  // BLAS left to the device builder (fjgpu_lbvh.hip): nodes / triangles empty
+  bool f32_exact;                     // every coordinate of the mesh is exactly representable in f32
   const fj_mesh_desc *mesh;
   const fj_curve_desc *curve;
 };
@@ -65,7 +67,7 @@ float RoundDown2(double v);   // f64 -> f32 toward -inf, one more ulp outward
 float RoundUp2(double v);
 
 // returns 0 or a negative FJGPU_E* code with *err set
-int BuildHostScene(const fj_scene_desc *desc, HostScene *out, std::string *err);
+int BuildHostScene(const fj_scene_desc *desc, HostScene *out, std::string *err, bool device_mesh_build = false);
 
 // reference-exact host math used while flattening (fjgpu_xform.cc)
 void MakeTransform(const fj_xform_desc &x, double time, double M[16], double Minv[16]);

@@ -34,6 +34,8 @@ static int split_depth_limit(const double *cp, double epsilon)
 int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
 {
   ps->type = FJ_PRIMSET_CURVE;
+  ps->device_build = false;
+  ps->f32_exact = false;
   ps->mesh = nullptr;
   ps->curve = &c;
   if (c.velocity) { *err = "curve velocity (motion blur) is not on the device path yet"; return FJGPU_EUNSUPPORTED; }

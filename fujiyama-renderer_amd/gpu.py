@@ -29,6 +29,7 @@ def lib():
         L.fjgpu_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(ffi.GpuStats)]
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.fjgpu_global_option.argtypes = [C.c_char_p, C.c_long]
         L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -99,6 +100,11 @@ class Scene(object):
         _check(lib().fjgpu_trace(self._h, group, n, rays.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
                                  ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p), C.byref(st)))
         return t, ids, uv, st
+
+
+def global_option(name, value):
+    """process-wide option of the core, e.g. global_option("device_build", 1)"""
+    _check(lib().fjgpu_global_option(name.encode(), int(value)))
 
 
 def tile_count(render):

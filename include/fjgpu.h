@@ -99,6 +99,11 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
  * "count_nodes" 0/1 enable traversal event counters. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
+/* Process-wide options read by fjgpu_scene_create: "device_build" 0/1 -- build the BLAS of
+ * meshes on the GPU (LBVH; tens of ms for millions of triangles) instead of the host's
+ * binned-SAH build (slower to build, faster to trace: the default).  0 or FJGPU_EINVAL. */
+int fjgpu_global_option(const char *name, long value);
+
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).
  * "node_record_bytes" (128), "tri_record_bytes" (36 when every mesh is stored as exact f32
  * triangles, else 72), "blas_nodes", "stack_need".  Returns 0 or FJGPU_EINVAL. */

@@ -235,6 +235,32 @@ def test_si_render_scene_end_to_end(asset_dir):
     assert st.rays.as_dict() == rc.as_dict() and st.render_seconds > 0
 
 
+def test_device_blas_build_gives_the_same_hits_and_pixels(asset_dir, golden_dir):
+    """BLAS built on the device (LBVH, fjgpu_lbvh.hip) instead of the host's binned-SAH tree:
+    closest hits do not depend on the culling structure, so t / ids stay bit-exact against the
+    reference grid vectors and a frame matches the oracle."""
+    import test_oracle_golden as tg
+    vec = golden_io.read_vectors(os.path.join(golden_dir, "ref_vectors.bin"))
+    gpu.global_option("device_build", 1)
+    try:
+        sp, _ = prepare(tg._mesh_scene(asset_dir))
+        rays = np.load(os.path.join(golden_dir, "mesh_trace_rays.npy"))
+        gs = gpu.Scene(sp)
+        assert gs.query("blas_nodes") > 0
+        t, ids, uv, st = gs.trace(0, rays)
+        gs.close()
+        assert np.array_equal(t, vec["grid_t"])
+        assert np.array_equal(ids[:, 1], vec["grid_prim"])
+        fb, st, ref, rc = render_both(workloads.dragon(asset_dir, res=(96, 54), spp=(3, 3), mesh="small"))
+        assert st.rays.as_dict() == rc.as_dict()
+        assert float(rel_err(fb, ref).max()) <= REL_TOL
+        fb, st, ref, rc = render_both(workloads.motion(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", kind="velocity+object"))
+        assert st.rays.as_dict() == rc.as_dict()
+        assert float(rel_err(fb, ref).max()) <= REL_TOL
+    finally:
+        gpu.global_option("device_build", 0)
+
+
 def test_unsupported_features_fail_loudly(asset_dir):
     """features outside the device path: explicit error naming the feature, never a silent
     approximation or a CPU fallback"""
