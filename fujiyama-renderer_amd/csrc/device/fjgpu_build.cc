@@ -162,10 +162,36 @@ struct Builder {
     const bool force_median = (double) n > cap * 0.5 && budget < 30;
     if (ext > 0 && !force_median) {
       Bins B;
-      B.clear();
-      const float scale = NB * (1.f - 1e-6f) / ext;
-      const float lo = cmn[axis];
+      float scale = NB * (1.f - 1e-6f) / ext;
+      float lo = cmn[axis];
+      float best = FLT_MAX;
+      int best_b = -1;
+      // SAH over the bins of one axis: best split plane and its cost
+      auto sweep = [&](const Bins &Bx, float *cost_out, int *b_out) {
+        float rarea[NB];
+        int rcnt[NB];
+        float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        int c = 0;
+        for (int b = NB - 1; b > 0; b--) {
+          if (Bx.cnt[b]) grow(amn, amx, Bx.bmn[b], Bx.bmx[b]);
+          c += Bx.cnt[b];
+          rcnt[b] = c;
+          rarea[b] = c ? half_area(amn, amx) : 0.f;
+        }
+        for (int k = 0; k < 3; k++) { amn[k] = FLT_MAX; amx[k] = -FLT_MAX; }
+        c = 0;
+        *cost_out = FLT_MAX; *b_out = -1;
+        for (int b = 0; b < NB - 1; b++) {
+          if (Bx.cnt[b]) grow(amn, amx, Bx.bmn[b], Bx.bmx[b]);
+          c += Bx.cnt[b];
+          if (c == 0 || rcnt[b + 1] == 0) continue;
+          const float cost = half_area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
+          if (cost < *cost_out) { *cost_out = cost; *b_out = b; }
+        }
+      };
       if (big) {
+        // the few largest nodes: widest centroid axis only, binned on all threads
+        B.clear();
         std::mutex mu;
         ParallelFor((size_t) n, [&](size_t i0, size_t i1) {
           Bins L;
@@ -178,33 +204,27 @@ struct Builder {
           std::lock_guard<std::mutex> g(mu);
           B.merge(L);
         });
+        sweep(B, &best, &best_b);
       } else {
-        for (int i = begin; i < end; i++) {
-          const int b = bin_of(prims[i], axis, lo, scale);
-          B.cnt[b]++;
-          grow(B.bmn[b], B.bmx[b], prims[i].bmin, prims[i].bmax);
+        // all three axes, keep the cheapest split
+        int best_axis = axis;
+        for (int ax = 0; ax < 3; ax++) {
+          const float e = cmx[ax] - cmn[ax];
+          if (!(e > 0)) continue;
+          const float sc = NB * (1.f - 1e-6f) / e;
+          Bins Bx;
+          Bx.clear();
+          for (int i = begin; i < end; i++) {
+            const int b = bin_of(prims[i], ax, cmn[ax], sc);
+            Bx.cnt[b]++;
+            grow(Bx.bmn[b], Bx.bmx[b], prims[i].bmin, prims[i].bmax);
+          }
+          float cst;
+          int bb;
+          sweep(Bx, &cst, &bb);
+          if (bb >= 0 && cst < best) { best = cst; best_b = bb; best_axis = ax; B = Bx; scale = sc; lo = cmn[ax]; }
         }
-      }
-      float rarea[NB];
-      int rcnt[NB];
-      float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-      int c = 0;
-      for (int b = NB - 1; b > 0; b--) {
-        if (B.cnt[b]) grow(amn, amx, B.bmn[b], B.bmx[b]);
-        c += B.cnt[b];
-        rcnt[b] = c;
-        rarea[b] = c ? half_area(amn, amx) : 0.f;
-      }
-      for (int k = 0; k < 3; k++) { amn[k] = FLT_MAX; amx[k] = -FLT_MAX; }
-      c = 0;
-      float best = FLT_MAX;
-      int best_b = -1;
-      for (int b = 0; b < NB - 1; b++) {
-        if (B.cnt[b]) grow(amn, amx, B.bmn[b], B.bmx[b]);
-        c += B.cnt[b];
-        if (c == 0 || rcnt[b + 1] == 0) continue;
-        const float cost = half_area(amn, amx) * c + rarea[b + 1] * rcnt[b + 1];
-        if (cost < best) { best = cost; best_b = b; }
+        axis = best_axis;
       }
       if (best_b >= 0) {
         // leaf cost vs split cost (traversal cost 1 node ~ 1.2 triangle tests)
