@@ -137,9 +137,6 @@ __device__ FJ_BOXREF_ATTR bool box_ray_ref(const double *b, V3 o, V3 d, double r
   return (tmin < ray_tmax) && (tmax > ray_tmin);
 }
 
-#ifdef FJ_EXP_COUNT_FB
-__device__ unsigned long long g_fb_count;
-#endif
 // Same decision as box_ray_ref at a fraction of the cost: the slab interval from the
 // per-ray reciprocal differs from the reference's divisions by a few ulp, so it settles
 // every case that is not within 1e-12 (relative) of a boundary; the rest takes the exact
@@ -158,9 +155,6 @@ __device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3
     if (g > m) return true;
     if (g < -m) return false;
   }
-#ifdef FJ_EXP_COUNT_FB
-  atomicAdd(&g_fb_count, 1ull);
-#endif
   return box_ray_ref(b, o, d, ray_tmin, ray_tmax);
 }
 __device__ __forceinline__ bool plain_dir(V3 d) { return d.x != 0 && d.y != 0 && d.z != 0; }
@@ -557,11 +551,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
         // the reference's own (possibly non-enclosing) instance box, full ray range
-#ifdef FJ_EXP_OLD_INST
-        if (!slab(I->wbounds, I->wbounds + 3, o, winv, tmin, tfar, &tn)) continue;
-#else
         if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
-#endif
         if (kMotion && I->xform >= 0) {
           // ObjectInstance::RayIntersect evaluates a time-sampled transform at the ray's time
           double tm[12], tmi[12];
@@ -628,16 +618,6 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const uint32_t cnt = (cur & 7u) + 1;
       bool stop = false;
       const bool is_curve = kCurves && P->type == FJ_PRIMSET_CURVE;
-#ifdef FJ_EXP_LEAF_TOUCH
-      // a leaf's triangles are contiguous (<= 288 B): put its middle and last cache lines in
-      // flight now instead of discovering them one dependent miss at a time
-      double touch0 = 0, touch1 = 0;
-      if (!is_curve && P->tri_verts) {
-        const double *vp0 = P->tri_verts + (size_t) first * 9;
-        touch0 = vp0[(cnt * 9) / 2];
-        touch1 = vp0[cnt * 9 - 1];
-      }
-#endif
       for (uint32_t k = 0; k < cnt; k++) {
         double t, u = 0, v = 0;
         if (kCount && !(kCurves && is_curve)) lc->prims++;
@@ -670,9 +650,6 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           if (anyhit) { stop = true; break; }
         }
       }
-#ifdef FJ_EXP_LEAF_TOUCH
-      asm volatile("" :: "v"(touch0), "v"(touch1));
-#endif
       if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
       else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
     }
@@ -1447,23 +1424,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
               const bool plain = plain_dir(Ln);
               for (int gi = 0; gi < g_count; gi++) {
                 const DInstance *I = &S.instances[S.group_instances[g_first + gi]];
-#ifdef FJ_EXP_OLD_CULL
-                double tn;
-                if (slab(I->wbounds, I->wbounds + 3, Ps, winv, .0001, distance, &tn)) { maybe_occluded = true; break; }
-#elif defined(FJ_EXP_CULL_NOEXACT)
-                {
-                  const double *b = g_count == 1 ? g_sbounds : I->wbounds;
-                  const double x0 = (b[0] - Ps.x) * winv.x, x1 = (b[3] - Ps.x) * winv.x;
-                  const double y0 = (b[1] - Ps.y) * winv.y, y1 = (b[4] - Ps.y) * winv.y;
-                  const double z0 = (b[2] - Ps.z) * winv.z, z1 = (b[5] - Ps.z) * winv.z;
-                  const double lo = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
-                  const double hi = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
-                  const double g = fmin(fmin(hi - lo, distance - lo), hi - .0001);
-                  if (g > 0) { maybe_occluded = true; break; }
-                }
-#else
                 if (box_ray_ref_fast(g_count == 1 ? g_sbounds : I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
-#endif
                 c_insts++;
               }
             }
@@ -2008,18 +1969,12 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
   return 0;
 }
 
-#ifdef FJ_EXP_COUNT_FB
-static void dump_fb() { unsigned long long v = 0; hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fb_count), sizeof(v)); fprintf(stderr, "fallbacks so far: %llu\n", v); }
-#endif
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
     const double *s_uv, const float *s_accum, float *fb)
 {
   dim3 grid((max_tile_pixels + (BLOCK / 64) - 1) / (BLOCK / 64), n_tiles);   // one wave per pixel
   hipLaunchKernelGGL(k_resolve, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, s_accum, fb);
   LAUNCH_CHECK();
-#ifdef FJ_EXP_COUNT_FB
-  dump_fb();
-#endif
 #ifdef FJ_EXP_SLAB_VALIDATE
   { unsigned long long v[3] = {0, 0, 0}; (void) hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_slab_lost), 8); (void) hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_slab_extra), 8); (void) hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(g_slab_tests), 8);
     fprintf(stderr, "slab32 validate: lost %llu extra %llu of %llu box tests\n", v[0], v[1], v[2]); }
