@@ -68,6 +68,32 @@ def test_box_ray_intersect(vec, O):
     assert 0.2 < vec["box_hit"].mean() < 0.9
 
 
+def test_reference_box_test_known_answers(O):
+    """The known-answer cases of the reference's own unit test (tests/box_test.cc:14-110, the
+    only reference test that pins a result on this path): unit cube [-1,1]^3 and a
+    ray along +z; expected (hit, hit_tmin, hit_tmax) as asserted there.  A miss leaves the
+    outputs untouched in the reference (-FLT_MAX / FLT_MAX); the oracle's C entry returns 0."""
+    REAL_MAX = 1.7976931348623157e308
+    cube = [-1, -1, -1, 1, 1, 1]
+    reversed_infinite = [REAL_MAX] * 3 + [-REAL_MAX] * 3            # Box::ReverseInfinite
+    cases = [   # box, orig, dir, ray_tmin, ray_tmax -> hit, tmin, tmax
+        (cube, [0, 0, 0], [0, 0, 1], 0, 1000, 1, -1, 1),
+        (cube, [0, 0, -2], [0, 0, 1], 0, 1000, 1, 1, 3),
+        (cube, [0, 0, -2], [0, 0, 1], 0, 2, 1, 1, 3),
+        (cube, [0, 0, 2], [0, 0, 1], 0, 1000, 0, None, None),
+        (cube, [0, 0, -2], [0, 0, 1], 0, 1, 0, None, None),
+        (reversed_infinite, [0, 0, 0], [0, 0, 1], 0, 1, 0, None, None),
+    ]
+    x = np.array([c[0] + c[1] + c[2] + [c[3], c[4]] for c in cases], dtype=np.float64)
+    hit = np.empty(len(cases), dtype=np.int32)
+    t = np.empty((len(cases), 2))
+    O.fjo_box_ray(len(cases), _p(x), _p(hit), _p(t))
+    for k, c in enumerate(cases):
+        assert hit[k] == c[5], k
+        if c[5]:
+            assert t[k, 0] == c[6] and t[k, 1] == c[7], (k, t[k])
+
+
 def test_tri_ray_intersect(vec, O):
     x = np.ascontiguousarray(vec["tri_in"])
     n = x.shape[0]
