@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--cpu-tiles", type=int, default=-1,
                     help="tiles in the CPU-baseline sample (-1: two per host core so every core stays busy; 0 disables)")
     ap.add_argument("--batch-tiles", type=int, default=0)
+    ap.add_argument("--as-rank-of", type=int, default=0,
+                    help="diagnostic: on ONE GPU render only the tiles rank 0 of an N-GPU job would own (per-rank cost)")
     ap.add_argument("--device-build", action="store_true",
                     help="build the BLAS on the GPU (LBVH: faster prepare, slower trace) instead of the host SAH build")
     return ap.parse_args()
@@ -156,10 +158,15 @@ def main():
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
+    if world > 1 or args.as_rank_of > 1:
+        # small per-rank launches: let the shadow work of a level overlap the next level's tails
+        gs.set_option("overlap_shadow", 1)
     prep_seconds = time.perf_counter() - t_prep
 
     n_tiles = gpu.tile_count(render)
     my_tiles = fjdist.tiles_of_rank(n_tiles, rank, world)
+    if args.as_rank_of > 1 and world == 1:
+        my_tiles = fjdist.tiles_of_rank(n_tiles, 0, args.as_rank_of)
     fb = torch.zeros((render.yres, render.xres, 4), dtype=torch.float32, device=device)
     host_fb = torch.empty((render.yres, render.xres, 4), dtype=torch.float32).pin_memory()
     stream = torch.cuda.current_stream(device).cuda_stream

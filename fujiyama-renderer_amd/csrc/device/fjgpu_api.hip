@@ -78,8 +78,12 @@ struct fjgpu_scene {
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   int max_children;                // most child rays one shading event can emit in this scene
   DHit *d_hits;
-  DLightRec *d_lrecs;
-  DLightHair *d_lhair;             // only when the scene has a HairShader
+  DLightRec *d_lrecs[2];           // double buffered: the shadow stream consumes one while shading fills the other
+  DLightHair *d_lhair[2];          // only when the scene has a HairShader
+  long overlap;                    // option "overlap_shadow"
+  hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
+  hipEvent_t ev_shadow_done[2];    // shadow work reading d_lrecs[k] has finished
+  std::vector<hipEvent_t> ev_pool; // per-launch timing events (resolved at the end of the frame: no host sync per launch)
   DShadowRay *d_squeue;
   size_t squeue_cap;
   DCounters *d_cnt;
@@ -92,6 +96,20 @@ struct fjgpu_scene {
   size_t blas_nodes;
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
 };
+
+// Option "overlap_shadow": the light loop + shadow traversal of a level on their own stream,
+// concurrent with the next level's closest-hit work.  Measured on C3: the kernels do overlap,
+// but a persistent kernel fills the chip until its tail, so a frame gains nothing at 1 GPU and
+// 2.5 % at the per-rank load of an 8-GPU job, while per-kernel durations (and the roofline
+// derived from them) inflate.  Off by default; bench.py turns it on for multi-GPU runs.
+static int enable_overlap(fjgpu_scene *sc)
+{
+  if (sc->shadow_stream) return 0;
+  if (hipStreamCreateWithFlags(&sc->shadow_stream, hipStreamNonBlocking) != hipSuccess) { sc->shadow_stream = nullptr; return -1; }
+  for (int k = 0; k < 2; k++)
+    if (hipEventCreateWithFlags(&sc->ev_shadow_done[k], hipEventDisableTiming) != hipSuccess) return -1;
+  return 0;
+}
 
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip)
 
@@ -162,8 +180,10 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   sc->count_all_shadow = 1;
   sc->work_samples = sc->work_rays = 0;
   sc->tab_len = 0;
-  sc->tiles_cap = 0;
-  sc->d_jit = sc->d_tim = nullptr;
+  sc->overlap = 0;
+  sc->shadow_stream = nullptr;
+  sc->ev_shadow_done[0] = sc->ev_shadow_done[1] = nullptr;
+  if (getenv("FJGPU_OVERLAP")) { if (enable_overlap(sc.get())) return fail(FJGPU_ENODEV, "could not create the shadow stream"); sc->overlap = 1; }
   DeviceBuffers &M = sc->mem;
   int e = 0;
 
@@ -258,9 +278,10 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     int need = 0;
     for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
+    S.stack_overflow_shadow = nullptr;
     if (need > FJ_STACK_LDS) {
       const size_t entries = (size_t) (need - FJ_STACK_LDS) * persistent_threads();
-      if (M.alloc(entries, &S.stack_overflow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
+      if (M.alloc(entries, &S.stack_overflow) || M.alloc(entries, &S.stack_overflow_shadow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
     sc->stack_need = need;
     sc->tri_record_bytes = 36; sc->blas_nodes = 0;
@@ -304,6 +325,9 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   if (!scene) return;
   (void) hipSetDevice(scene->device);
   (void) hipDeviceSynchronize();
+  if (scene->shadow_stream) (void) hipStreamDestroy(scene->shadow_stream);
+  for (hipEvent_t e : scene->ev_shadow_done) if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : scene->ev_pool) (void) hipEventDestroy(e);
   delete scene;
 }
 
@@ -325,6 +349,11 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
   if (n == "batch_tiles") { scene->batch_tiles = value; return 0; }
   if (n == "count_nodes") { scene->count_events = value != 0; return 0; }
   if (n == "count_all_shadow") { scene->count_all_shadow = value != 0; return 0; }
+  if (n == "overlap_shadow") {
+    if (value) { if (enable_overlap(scene)) return fail(FJGPU_ENODEV, "could not create the shadow stream"); scene->overlap = 1; }
+    else scene->overlap = 0;
+    return 0;
+  }
   return fail(FJGPU_EINVAL, "unknown option " + n);
 }
 
@@ -344,9 +373,11 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     e |= W.alloc(samples * 4, &sc->d_accum);
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
     e |= W.alloc(rays, &sc->d_hits);
-    e |= W.alloc(rays, &sc->d_lrecs);
-    sc->d_lhair = nullptr;
-    if (sc->S.has_hair) e |= W.alloc(rays, &sc->d_lhair);
+    for (int k = 0; k < 2; k++) {
+      e |= W.alloc(rays, &sc->d_lrecs[k]);
+      sc->d_lhair[k] = nullptr;
+      if (sc->S.has_hair) e |= W.alloc(rays, &sc->d_lhair[k]);
+    }
     sc->squeue_cap = std::min<size_t>(rays * 8, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     e |= W.alloc(1, &sc->d_cnt);
@@ -412,7 +443,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
   long bt = sc->batch_tiles;
   if (bt <= 0) {
-    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + sizeof(DLightRec);
+    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec);
     const size_t target = std::min<size_t>((size_t) 80 << 20, (size_t) (.4 * (double) free_now) / per_sample);
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
@@ -438,7 +469,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   S.cam_uv_size[1] = fjgpu::CameraUvSizeY(sc->cam_fov);
   S.cam_uv_size[0] = S.cam_uv_size[1] * aspect;
   S.time_tab = sc->d_tim; S.time_start = r->time_start; S.time_end = r->time_end;
-  S.lrec_hair = sc->d_lhair;
+  S.lrec_hair = nullptr;      // set per launch (double buffered)
 
   GenParams gp;
   gp.rate_x = r->rate_x; gp.rate_y = r->rate_y; gp.margin_x = margin[0]; gp.margin_y = margin[1];
@@ -464,22 +495,34 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   rp.npx_x = r->rate_x + 2 * margin[0]; rp.npx_y = r->rate_y + 2 * margin[1];
   rp.fw = (double) r->filter_w; rp.fh = (double) r->filter_h;
 
-  hipEvent_t ev[2];
-  HIP_TRY(hipEventCreate(&ev[0]));
-  HIP_TRY(hipEventCreate(&ev[1]));
   fjgpu_stats acc;
   std::memset(&acc, 0, sizeof(acc));
   float ms = 0;
-  auto timed = [&](double *bucket, auto &&launch) -> int {
-    (void) hipEventRecord(ev[0], st);
+  // Per-launch timing without a host round trip per launch: event pairs are recorded around
+  // every launch on its stream and turned into durations once, after the frame's last sync.
+  struct Span { size_t a, b; double *bucket; };
+  std::vector<Span> spans;
+  size_t ev_used = 0;
+  auto take_event = [&]() -> size_t {
+    if (ev_used == sc->ev_pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return (size_t) -1; sc->ev_pool.push_back(e); }
+    return ev_used++;
+  };
+  auto timed = [&](hipStream_t stream, double *bucket, auto &&launch) -> int {
+    const size_t a = take_event(), b = take_event();
+    if (a == (size_t) -1 || b == (size_t) -1) return -1;
+    (void) hipEventRecord(sc->ev_pool[a], stream);
     const int le = launch();
-    (void) hipEventRecord(ev[1], st);
+    (void) hipEventRecord(sc->ev_pool[b], stream);
     if (le) return le;
-    if (hipEventSynchronize(ev[1]) != hipSuccess) return -1;
-    (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
-    *bucket += ms;
+    spans.push_back(Span{a, b, bucket});
     return 0;
   };
+  // The light loop and the shadow traversal of level L are independent of the closest-hit
+  // work of level L+1 (both consume what shading L produced), so they run on their own
+  // stream and fill each other's tails; light records are double buffered between them.
+  hipStream_t sst = (sc->overlap && sc->shadow_stream) ? sc->shadow_stream : st;
+  unsigned shade_seq = 0;
+  bool shadow_pending[2] = {false, false};
   int rc = 0;
   hipEvent_t ev_all[2];
   HIP_TRY(hipEventCreate(&ev_all[0]));
@@ -507,7 +550,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     (void) hipMemsetAsync(sc->d_accum, 0, sizeof(float) * 4 * (size_t) n_samples, st);
     (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
 
-    rc = timed(&acc.gen_ms, [&]() {
+    rc = timed(st, &acc.gen_ms, [&]() {
       return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->levels[0].rays, sc->levels[0].paths);
     });
     if (rc) break;
@@ -529,24 +572,31 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         const DRay *rays = sc->levels[level].rays + off;
         const DPath *paths = sc->levels[level].paths + off;
         (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
-        int e = timed(&acc.trace_ms, [&]() {
+        int e = timed(st, &acc.trace_ms, [&]() {
           return launch_trace_closest(st, S, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
         });
         if (e) return e;
         acc.trace_launches++;
-        e = timed(&acc.shade_ms, [&]() {
-          return launch_shade(st, S, shp, rays, paths, sc->d_hits, n, sc->d_accum,
-              sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_lrecs, sc->d_cnt);
+        const unsigned lb = shade_seq++ & 1u;          // light-record buffer of this shading call
+        if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
+        shadow_pending[lb] = false;
+        DScene Sl = S;
+        Sl.lrec_hair = sc->d_lhair[lb];
+        e = timed(st, &acc.shade_ms, [&]() {
+          return launch_shade(st, Sl, shp, rays, paths, sc->d_hits, n, sc->d_accum,
+              sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_lrecs[lb], sc->d_cnt);
         });
         if (e) return e;
         DCounters hc;
         if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         if (hc.overflow) return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option");
         if (hc.light_count) {
-          e = timed(&acc.trace_ms, [&]() {
-            return launch_shadow(st, S, swp, sc->d_lrecs, hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
+          // shading has completed (the host just synchronised with it): no event needed
+          e = timed(sst, &acc.trace_ms, [&]() {
+            return launch_shadow(sst, Sl, swp, sc->d_lrecs[lb], hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
           });
           if (e) return e;
+          if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[lb], sst); shadow_pending[lb] = true; }
           acc.trace_launches++;
         }
         if (hc.next_count) {
@@ -559,7 +609,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     rc = process(0, n_samples);
     if (rc) break;
 
-    rc = timed(&acc.resolve_ms, [&]() {
+    // the filter needs every shadow contribution of the batch
+    for (int k = 0; k < 2; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
+    rc = timed(st, &acc.resolve_ms, [&]() {
       return launch_resolve(st, rp, sc->d_tiles, nb, max_px, sc->d_suv, sc->d_accum, d_fb);
     });
     if (rc) break;
@@ -578,12 +630,14 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     acc.batches++;
   }
   (void) hipEventRecord(ev_all[1], st);
-  const hipError_t se = hipStreamSynchronize(st);
+  hipError_t se = hipStreamSynchronize(st);
+  if (sst != st) { const hipError_t s2 = hipStreamSynchronize(sst); if (se == hipSuccess) se = s2; }
   if (rc == 0 && se == hipSuccess) {
     (void) hipEventElapsedTime(&ms, ev_all[0], ev_all[1]);
     acc.total_ms = ms;
+    for (const Span &sp : spans)
+      if (hipEventElapsedTime(&ms, sc->ev_pool[sp.a], sc->ev_pool[sp.b]) == hipSuccess) *sp.bucket += ms;
   }
-  (void) hipEventDestroy(ev[0]); (void) hipEventDestroy(ev[1]);
   (void) hipEventDestroy(ev_all[0]); (void) hipEventDestroy(ev_all[1]);
   if (rc > 0 || rc == -1) return fail(FJGPU_ENODEV, std::string("HIP failure in the wavefront loop: ") + hipGetErrorString(hipGetLastError()));
   if (rc) return rc;

@@ -448,6 +448,17 @@ struct TravTune { uint32_t refill, steps, grab; };
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
 
+// Claim size.  A wave takes `grab` consecutive rays per atomic; with few rays per launch (a
+// rank of an 8-GPU job, a deep recursion level) whole claims decide the load balance -- 4
+// claims per wave leave the slowest wave ~25 % behind -- so the claim shrinks until every
+// wave gets at least ~16 of them (never below 16 rays: a wave has 64 lanes to fill).
+__device__ __forceinline__ uint32_t adaptive_grab(uint32_t grab, uint32_t n)
+{
+  const uint32_t waves = gridDim.x * (BLOCK / 64);
+  const uint32_t want = n / (waves * 16u);
+  return want >= grab ? grab : (want < 16u ? 16u : want);
+}
+
 struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
@@ -489,6 +500,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   // measurably worse: neighbouring rays have correlated cost, so whole slices
   // end up cheap or expensive and the slowest wave sets the kernel time.
   uint32_t next = 0, range_end = 0;        // wave-uniform
+  tune.grab = adaptive_grab(tune.grab, n);
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, inv = o, d = o, winv = o;
@@ -1535,7 +1547,7 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : 
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -1606,6 +1618,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   bool head_live = true;
   uint32_t next = 0, range_end = 0;
+  tune.grab = adaptive_grab(tune.grab, n);
   bool have = false, hit = false;
   uint32_t idx = 0;
   V3 oo = mk(0, 0, 0), od = oo;
@@ -1792,7 +1805,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene 
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
@@ -1942,7 +1955,7 @@ int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const
   if (chunk == 0) chunk = 1;
   for (uint32_t b = 0; b < n; b += chunk) {
     const uint32_t e = (n - b < chunk) ? n : b + chunk;
-    (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + trace_head
+    (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
     const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
 #define FJ_LAUNCH_CULL(HAIR, AREA) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
     if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation

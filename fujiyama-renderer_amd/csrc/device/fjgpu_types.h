@@ -124,6 +124,7 @@ struct DScene {
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
+  uint32_t *stack_overflow_shadow;   // the same for the shadow kernels (they run concurrently on their own stream)
   int32_t all_opaque;          // every group is all_opaque: shadow rays run the lean any-hit kernel
   int32_t has_area;            // any rectangle / sphere light: the light loop draws positions per event
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
@@ -198,8 +199,9 @@ struct DCounters {
   uint32_t light_count;        // entries appended to the light-record queue
   uint32_t overflow;
   uint32_t shadow_count;       // slots reserved in the shadow-ray queue
-  uint32_t trace_head;         // persistent traversal: next unclaimed queue index
-  uint32_t pad_[3];
+  uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
+  uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (path stream)
+  uint32_t pad_[2];
 };
 
 #endif

@@ -96,7 +96,8 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
     double *out_t, int32_t *out_ids, double *out_uv, fjgpu_stats *stats);
 
 /* Tunables (all have defaults): "batch_tiles" tiles per wavefront batch,
- * "count_nodes" 0/1 enable traversal event counters. Returns 0 or FJGPU_EINVAL. */
+ * "count_nodes" 0/1 enable traversal event counters, "overlap_shadow" 0/1 run the shadow work of
+ * a recursion level on its own stream, concurrent with the next level. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
 /* Process-wide options read by fjgpu_scene_create: "device_build" 0/1 -- build the BLAS of
