@@ -158,9 +158,6 @@ def main():
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
-    if world > 1 or args.as_rank_of > 1:
-        # small per-rank launches: let the shadow work of a level overlap the next level's tails
-        gs.set_option("overlap_shadow", 1)
     prep_seconds = time.perf_counter() - t_prep
 
     n_tiles = gpu.tile_count(render)

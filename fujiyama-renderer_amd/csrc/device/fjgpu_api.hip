@@ -101,7 +101,9 @@ struct fjgpu_scene {
 // concurrent with the next level's closest-hit work.  Measured on C3: the kernels do overlap,
 // but a persistent kernel fills the chip until its tail, so a frame gains nothing at 1 GPU and
 // 2.5 % at the per-rank load of an 8-GPU job, while per-kernel durations (and the roofline
-// derived from them) inflate.  Off by default; bench.py turns it on for multi-GPU runs.
+// derived from them) inflate; since the shadow traversal became ONE launch per batch (its
+// tail was what overlapped) it even loses, because the queue bound cannot be refreshed from
+// the device without synchronising the second stream.  Off by default; kept as an experiment.
 static int enable_overlap(fjgpu_scene *sc)
 {
   if (sc->shadow_stream) return 0;
@@ -562,6 +564,25 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     // queue is drained completely before the next chunk is taken.  Memory is bounded
     // by levels x capacity whatever the branching of the shaders (glass: 2 children,
     // pathtracing: up to 3), while plastic-only scenes run whole levels at once.
+    // shadow-ray queue of this batch: the light loops of every level append, one traversal
+    // launch consumes it (flush) at the end of the batch or when it could overflow
+    const uint64_t sq_cap = sc->squeue_cap, sq_pad = shadow_queue_padding();
+    const uint64_t nl_q = (uint64_t) std::max(1, sc->n_light_samples);
+    uint64_t sq_bound = 0;             // upper bound of the entries reserved so far
+    bool sq_dirty = false;
+    shadow_queue_reset(sst, sc->d_cnt);
+    auto flush_shadow = [&](const DScene &Sx) -> int {
+      if (sq_dirty) {
+        const int fe = timed(sst, &acc.trace_ms, [&]() {
+          return launch_shadow_trace(sst, Sx, sc->d_squeue, sc->d_accum, sc->d_cnt, (int) sc->count_events);
+        });
+        if (fe) return fe;
+        acc.trace_launches++;
+        shadow_queue_reset(sst, sc->d_cnt);
+      }
+      sq_bound = 0; sq_dirty = false;
+      return 0;
+    };
     std::function<int(int, uint32_t)> process = [&](int level, uint32_t count) -> int {
       if (level + 1 >= (int) sc->levels.size()) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
       if (ensure_level(sc, level + 1, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for a ray queue level");
@@ -591,13 +612,40 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         if (hc.overflow) return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option");
         if (hc.light_count) {
-          // shading has completed (the host just synchronised with it): no event needed
-          e = timed(sst, &acc.trace_ms, [&]() {
-            return launch_shadow(sst, Sl, swp, sc->d_lrecs[lb], hc.light_count, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
-          });
-          if (e) return e;
+          // shading has completed (the host just synchronised with it): no event needed.
+          // The queue holds hc.shadow_count entries so far (exact when the shadow work runs on
+          // this stream, a lower bound otherwise: then the host-side bound is kept).
+          if (sst == st) sq_bound = hc.shadow_count;
+          uint32_t b = 0;
+          bool bound_is_exact = sst == st;
+          while (b < hc.light_count) {
+            const uint64_t room = sq_cap > (uint64_t) sq_bound + sq_pad ? sq_cap - sq_bound - sq_pad : 0;
+            uint32_t can = (uint32_t) std::min<uint64_t>(room / nl_q, hc.light_count - b);
+            if (can < hc.light_count - b && !bound_is_exact && sst == st) {
+              // the bound assumed that every (record, light) pair survived the cull: ask the
+              // device how full the queue really is before paying for a traversal launch
+              uint32_t used = 0;
+              if (hipMemcpyAsync(&used, &sc->d_cnt->shadow_count, sizeof(used), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+              sq_bound = used;
+              bound_is_exact = true;
+              continue;
+            }
+            if (can == 0 || (can < hc.light_count - b && can < (1u << 16))) {
+              // not worth a light-loop launch of its own: empty the queue first (an empty queue
+              // that still cannot take one record's rays takes them one record at a time)
+              if (sq_bound > 0) { e = flush_shadow(Sl); if (e) return e; continue; }
+              if (can == 0) can = 1;
+            }
+            e = timed(sst, &acc.trace_ms, [&]() {
+              return launch_shadow_cull(sst, Sl, swp, sc->d_lrecs[lb], b, b + can, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
+            });
+            if (e) return e;
+            sq_bound += (uint64_t) can * nl_q + sq_pad;      // worst case: every pair survives, every wave leaves a padded chunk
+            bound_is_exact = false;
+            sq_dirty = true;
+            b += can;
+          }
           if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[lb], sst); shadow_pending[lb] = true; }
-          acc.trace_launches++;
         }
         if (hc.next_count) {
           e = process(level + 1, hc.next_count);
@@ -610,6 +658,8 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     if (rc) break;
 
     // the filter needs every shadow contribution of the batch
+    { DScene Sf = S; Sf.lrec_hair = nullptr; rc = flush_shadow(Sf); if (rc) break;
+      if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[0], sst); shadow_pending[0] = true; } }
     for (int k = 0; k < 2; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
     rc = timed(st, &acc.resolve_ms, [&]() {
       return launch_resolve(st, rp, sc->d_tiles, nb, max_px, sc->d_suv, sc->d_accum, d_fb);

@@ -42,8 +42,11 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events);
 int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const DRay *rays, const DPath *paths,
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt);
-int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
+uint32_t shadow_queue_padding();
+void shadow_queue_reset(hipStream_t st, DCounters *cnt);
+int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
+int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events);
 // threads of the largest persistent grid (sizes per-thread scratch such as the stack overflow area)
 size_t persistent_threads();
 

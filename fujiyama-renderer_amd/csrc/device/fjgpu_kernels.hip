@@ -1942,43 +1942,50 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
   return 0;
 }
 
-int launch_shadow(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t n,
+// Shadow work in two steps.  The light loop APPENDS the surviving shadow rays of records
+// [b, e) to the queue (cnt->shadow_count keeps growing); the traversal consumes the whole
+// queue in ONE launch per batch of tiles (or when the queue would overflow) -- a persistent
+// kernel ends with a tail of a few slow rays (~1 ms on C3), so it pays to launch it once for
+// the rays of every recursion level instead of once per level.
+uint32_t shadow_queue_padding()          // every resident wave may leave one partially filled chunk
+{
+  return persistent_grid(1ull << 30) * (BLOCK / 64) * SQ_CHUNK;
+}
+
+void shadow_queue_reset(hipStream_t st, DCounters *cnt)
+{
+  (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
+}
+
+int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
-  if (n == 0) return 0;
-  // records are processed in chunks whose worst case (every pair survives the cull)
-  // fits the shadow-ray queue; the trace stage reads the queue length on the device
-  const uint32_t nl = (uint32_t) (S.n_light_samples > 0 ? S.n_light_samples : 1);
-  // every resident wave may leave one partially filled (padded) chunk behind
-  const uint32_t pad = persistent_grid(1ull << 30) * (BLOCK / 64) * SQ_CHUNK;
-  uint32_t chunk = (sp.queue_capacity > pad ? sp.queue_capacity - pad : 0) / nl;
-  if (chunk == 0) chunk = 1;
-  for (uint32_t b = 0; b < n; b += chunk) {
-    const uint32_t e = (n - b < chunk) ? n : b + chunk;
-    (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
-    const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
+  if (e <= b) return 0;
+  const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
 #define FJ_LAUNCH_CULL(HAIR, AREA) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
-    if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation
-    else if (S.has_hair) FJ_LAUNCH_CULL(true, false);
-    else FJ_LAUNCH_CULL(false, false);
+  if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation
+  else if (S.has_hair) FJ_LAUNCH_CULL(true, false);
+  else FJ_LAUNCH_CULL(false, false);
 #undef FJ_LAUNCH_CULL
-    LAUNCH_CHECK();
-    if (S.all_opaque && !S.has_curves && !S.has_motion) {
-      if (count_events)
-        hipLaunchKernelGGL(k_shadow_anyhit<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-            S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
-      else
-        hipLaunchKernelGGL(k_shadow_anyhit<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st,
-            S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune());
-    } else {
-#define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, (const DShadowRay *) squeue, s_accum, cnt, trav_tune())
-      if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
-      else if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false); }
-      else { if (count_events) FJ_LAUNCH_SHADOW(false, true, false); else FJ_LAUNCH_SHADOW(false, false, false); }
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
+{
+  if (S.all_opaque && !S.has_curves && !S.has_motion) {
+    if (count_events)
+      hipLaunchKernelGGL(k_shadow_anyhit<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+    else
+      hipLaunchKernelGGL(k_shadow_anyhit<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+  } else {
+#define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
+    if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
+    else if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false); }
+    else { if (count_events) FJ_LAUNCH_SHADOW(false, true, false); else FJ_LAUNCH_SHADOW(false, false, false); }
 #undef FJ_LAUNCH_SHADOW
-    }
-    LAUNCH_CHECK();
   }
+  LAUNCH_CHECK();
   return 0;
 }
 
