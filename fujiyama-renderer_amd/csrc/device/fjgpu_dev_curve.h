@@ -1,0 +1,191 @@
+// fjgpu_dev_curve.h -- Bezier ribbon test (Curve::ray_intersect) and the reference grid's cell-listing predicate.
+// Part of the kernels translation unit: included by fjgpu_kernels.hip only (device code,
+// compiled with -ffp-contract=off; see the header of that file).
+#ifndef FJGPU_DEV_CURVE_H
+#define FJGPU_DEV_CURVE_H
+
+// --------------------------------------------------------- curve test (a23)
+// Curve::ray_intersect + converge_bezier3, reference src/fj_curve.cc:187-232,300-390
+// (Nakamaru-Ono subdivision in ray space).  The reference recurses with a
+// Bezier3 per level; here every leaf segment is re-derived from the root by
+// the same sequence of split_bezier3 calls (identical arithmetic, no per-lane
+// stack of control points), and subtrees whose ancestor fails the reference's
+// bounds test are skipped.  Children of a node start from a fresh "no hit"
+// (t = REAL_MAX) in the reference, so nothing is pruned by depth; the combine
+// rule `t_left < t_right ? left : right` selects the RIGHTMOST leaf among those
+// with the smallest z, which is what `z <= best` in a left-to-right sweep does.
+struct Bz { V3 c0, c1, c2, c3; double w0, w1; };
+
+__device__ __forceinline__ V3 bez_eval(const Bz &b, double t)       // eval_bezier3, :464-472
+{
+  const double u = 1 - t;
+  const double a = u * u * u;
+  const double bb = 3 * u * u * t;
+  const double c = 3 * u * t * t;
+  const double d = t * t * t;
+  return a * b.c0 + bb * b.c1 + c * b.c2 + d * b.c3;
+}
+__device__ __forceinline__ V3 mid_point(V3 a, V3 b) { return (a + b) * .5; }
+__device__ __forceinline__ double dmax(double x, double y) { return x > y ? x : y; }   // Max, src/fj_numeric.h
+__device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : y; }
+__device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
+
+__device__ bool curve_ray(const double *cpw, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+{
+  // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
+  const double ray_scale = sqrt(dot(od, od));
+  const double sinv = 1. / ray_scale;
+  const V3 nd = od * sinv;
+  // compute_world_to_ray_matrix, :268-295: dst = rotate * translate
+  const double lx = nd.x, ly = nd.y, lz = nd.z;
+  const double d = sqrt(lx * lx + lz * lz);
+  const double d_inv = 1. / d;
+  const V3 r0 = mk(lz * d_inv, 0, -lx * d_inv);
+  const V3 r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
+  const V3 r2 = mk(lx, ly, lz);
+  const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
+  const double m03 = r0.x * nox + r0.y * noy + r0.z * noz;
+  const double m13 = r1.x * nox + r1.y * noy + r1.z * noz;
+  const double m23 = r2.x * nox + r2.y * noy + r2.z * noz;
+  Bz root;
+  {
+    V3 p[4];
+    for (int k = 0; k < 4; k++) {
+      const V3 q = ld3(cpw + 3 * k);
+      p[k] = mk(r0.x * q.x + r0.y * q.y + r0.z * q.z + m03,
+                r1.x * q.x + r1.y * q.y + r1.z * q.z + m13,
+                r2.x * q.x + r2.y * q.y + r2.z * q.z + m23);
+    }
+    root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
+    root.w0 = w0; root.w1 = w1;
+  }
+  double best_z = DBL_MAX, best_v = DBL_MAX;
+  bool any = false;
+  const uint32_t nleaf = 1u << depth;
+  uint32_t j = 0;
+  while (j < nleaf) {
+    Bz b = root;
+    double v0 = 0, vn = 1;
+    bool pruned = false;
+    for (int L = 0;; L++) {
+      // converge_bezier3 entry test: get_bezier3_bounds (cp bounds +- max radius)
+      const double radius = .5 * dmax(b.w0, b.w1);
+      const double mnx = dmin(dmin(dmin(b.c0.x, b.c1.x), b.c2.x), b.c3.x) - radius;
+      const double mxx = dmax(dmax(dmax(b.c0.x, b.c1.x), b.c2.x), b.c3.x) + radius;
+      const double mny = dmin(dmin(dmin(b.c0.y, b.c1.y), b.c2.y), b.c3.y) - radius;
+      const double mxy = dmax(dmax(dmax(b.c0.y, b.c1.y), b.c2.y), b.c3.y) + radius;
+      const double mxz = dmax(dmax(dmax(b.c0.z, b.c1.z), b.c2.z), b.c3.z) + radius;
+      if (mnx >= radius || mxx <= -radius || mny >= radius || mxy <= -radius || mxz <= 1e-6) {
+        const uint32_t span = 1u << (depth - L);
+        j = ((j / span) + 1) * span;
+        pruned = true;
+        break;
+      }
+      if (L == depth) break;
+      // split_bezier3, :488-508, keeping the half selected by bit (depth-L-1) of j
+      const V3 midP = bez_eval(b, .5);
+      const V3 midCP = mid_point(b.c1, b.c2);
+      const double vm = (v0 + vn) * .5;
+      const double wm = (b.w0 + b.w1) * .5;
+      if (((j >> (depth - L - 1)) & 1u) == 0) {
+        const V3 l1 = mid_point(b.c0, b.c1);
+        const V3 l2 = mid_point(l1, midCP);
+        b.c1 = l1; b.c2 = l2; b.c3 = midP;
+        b.w1 = wm;
+        vn = vm;
+      } else {
+        const V3 q2 = mid_point(b.c3, b.c2);
+        const V3 q1 = mid_point(q2, midCP);
+        b.c0 = midP; b.c1 = q1; b.c2 = q2;
+        b.w0 = wm;
+        v0 = vm;
+      }
+    }
+    if (pruned) continue;
+    j++;
+    // depth == 0 block of converge_bezier3
+    const V3 dir = b.c3 - b.c0;
+    V3 dP0 = b.c1 - b.c0;
+    if (dot_xy(dir, dP0) < 0) dP0 = dP0 * -1;
+    if (-1 * dot_xy(dP0, b.c0) < 0) continue;
+    V3 dPn = b.c3 - b.c2;
+    if (dot_xy(dir, dPn) < 0) dPn = dPn * -1;
+    if (dot_xy(dPn, b.c3) < 0) continue;
+    double w = dir.x * dir.x + dir.y * dir.y;
+    if (fabs(w) < 1e-6) continue;
+    w = -(b.c0.x * dir.x + b.c0.y * dir.y) / w;
+    w = clampd(w, 0, 1);
+    const double v = v0 * (1 - w) + vn * w;
+    const double radius_w = .5 * ((1 - w) * b.w0 + w * b.w1);
+    const V3 vP = bez_eval(b, w);
+    if (vP.x * vP.x + vP.y * vP.y >= radius_w * radius_w) continue;
+    if (vP.z <= 1e-6) continue;
+    if (vP.z <= best_z) { best_z = vP.z; best_v = v; any = true; }
+  }
+  if (!any) return false;
+  *t_out = best_z / ray_scale;
+  *v_out = best_v;
+  return true;
+}
+
+// The reference's GridAccelerator accepts a primitive hit only when the hit point
+// lies inside the cell being walked (src/fj_grid_accelerator.cc:253-260), and a curve
+// is listed in a cell only if one of its 32 depth-5 sub-segments' control-point boxes
+// overlaps the cell (Curve::box_intersect, src/fj_curve.cc:234-242,399-462) -- WITHOUT
+// the ribbon radius.  A ribbon hit whose ray point falls in a neighbouring cell that
+// does not list the curve is therefore rejected by the reference.  The same rule is
+// applied here so the two renderers see the same fur.
+__device__ bool curve_listed_in_cell_of(const DPrimSet *P, const double *cpw, V3 hitp)
+{
+  int ci[3];
+  double cmin[3], cmax[3];
+  const double hp[3] = {hitp.x, hitp.y, hitp.z};
+  for (int a = 0; a < 3; a++) {
+    int c = (int) floor((hp[a] - P->bounds[a]) / P->grid_cell[a]);
+    c = c < 0 ? 0 : (c > P->grid_n[a] - 1 ? P->grid_n[a] - 1 : c);
+    ci[a] = c;
+    cmin[a] = P->bounds[a] + (double) c * P->grid_cell[a];       // get_grid_cell, :334-343
+    cmax[a] = cmin[a] + P->grid_cell[a];
+    if (hp[a] < cmin[a] || cmax[a] < hp[a]) return false;        // Box::ContainsPoint (inclusive)
+  }
+  (void) ci;
+  // box_bezier3_intersect_recursive(cell, bezier, 5) with zero velocity
+  const V3 r0 = ld3(cpw), r1 = ld3(cpw + 3), r2 = ld3(cpw + 6), r3 = ld3(cpw + 9);
+  const uint32_t depth = 5, nleaf = 32;
+  uint32_t j = 0;
+  while (j < nleaf) {
+    V3 c0 = r0, c1 = r1, c2 = r2, c3 = r3;
+    bool pruned = false;
+    for (uint32_t L = 0;; L++) {
+      // AABB of the control polygon vs the cell (BoxBoxIntersect, inclusive).  Inner
+      // levels are tested too: a sub-segment's control points stay inside the parent's hull
+      const double mn[3] = {dmin(dmin(dmin(c0.x, c1.x), c2.x), c3.x), dmin(dmin(dmin(c0.y, c1.y), c2.y), c3.y), dmin(dmin(dmin(c0.z, c1.z), c2.z), c3.z)};
+      const double mx[3] = {dmax(dmax(dmax(c0.x, c1.x), c2.x), c3.x), dmax(dmax(dmax(c0.y, c1.y), c2.y), c3.y), dmax(dmax(dmax(c0.z, c1.z), c2.z), c3.z)};
+      const bool overlap = !(mx[0] < cmin[0] || mn[0] > cmax[0] || mx[1] < cmin[1] || mn[1] > cmax[1] || mx[2] < cmin[2] || mn[2] > cmax[2]);
+      if (!overlap) {
+        const uint32_t span = 1u << (depth - L);
+        j = ((j / span) + 1) * span;
+        pruned = true;
+        break;
+      }
+      if (L == depth) return true;
+      Bz b;
+      b.c0 = c0; b.c1 = c1; b.c2 = c2; b.c3 = c3; b.w0 = b.w1 = 0;
+      const V3 midP = bez_eval(b, .5);
+      const V3 midCP = mid_point(c1, c2);
+      if (((j >> (depth - L - 1)) & 1u) == 0) {
+        const V3 l1 = mid_point(c0, c1);
+        const V3 l2 = mid_point(l1, midCP);
+        c1 = l1; c2 = l2; c3 = midP;
+      } else {
+        const V3 q2 = mid_point(c3, c2);
+        const V3 q1 = mid_point(q2, midCP);
+        c0 = midP; c1 = q1; c2 = q2;
+      }
+    }
+    if (!pruned) j++;
+  }
+  return false;
+}
+
+#endif

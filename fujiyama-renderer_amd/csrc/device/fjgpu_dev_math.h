@@ -1,0 +1,223 @@
+// fjgpu_dev_math.h -- vectors, culling and exact box tests, time-sampled transforms, Moller-Trumbore, wave helpers.
+// Part of the kernels translation unit: included by fjgpu_kernels.hip only (device code,
+// compiled with -ffp-contract=off; see the header of that file).
+#ifndef FJGPU_DEV_MATH_H
+#define FJGPU_DEV_MATH_H
+
+// ------------------------------------------------------------------ vectors
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// Normalize, reference src/fj_vector.h:339-345: a * (1./len), len == 0 -> a
+__device__ __forceinline__ V3 normalize(V3 a)
+{
+  const double len = sqrt(dot(a, a));
+  if (len == 0) return a;
+  const double inv = 1. / len;
+  return a * inv;
+}
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+// MatTransformPoint / MatTransformVector, reference src/fj_matrix.cc:208-222
+__device__ __forceinline__ V3 xpoint(const double *m, V3 p)
+{
+  return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
+            m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+__device__ __forceinline__ V3 xvector(const double *m, V3 v)
+{
+  return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z,
+            m[4] * v.x + m[5] * v.y + m[6] * v.z,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+__device__ __forceinline__ double clampd(double x, double a, double b) { return x < a ? a : (x > b ? b : x); }
+
+// ------------------------------------------------------------ culling tests
+// Conservative slab test (culling only).  NaN from 0 * inf is ignored by
+// fmin/fmax, which return the non-NaN operand.
+__device__ __forceinline__ bool slab(const double bmin[3], const double bmax[3], V3 o, V3 inv,
+    double tmin, double tmax, double *tnear)
+{
+  const double x0 = (bmin[0] - o.x) * inv.x, x1 = (bmax[0] - o.x) * inv.x;
+  const double y0 = (bmin[1] - o.y) * inv.y, y1 = (bmax[1] - o.y) * inv.y;
+  const double z0 = (bmin[2] - o.z) * inv.z, z1 = (bmax[2] - o.z) * inv.z;
+  const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), tmin));
+  const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tmax));
+  *tnear = tn;
+  return tn <= tf;
+}
+
+__device__ __forceinline__ bool slab_f32box(const float *bmin, const float *bmax, V3 o, V3 inv,
+    double tmin, double tmax, double *tnear)
+{
+  const double mn[3] = {(double) bmin[0], (double) bmin[1], (double) bmin[2]};
+  const double mx[3] = {(double) bmax[0], (double) bmax[1], (double) bmax[2]};
+  return slab(mn, mx, o, inv, tmin, tmax, tnear);
+}
+
+// Reference quirk kept for identical results: BoxRayIntersect (src/fj_box.cc:73-138)
+// branches on `dir >= 0`, which is true for -0.0, and then divides by -0.0: the
+// slab interval comes out reversed (+inf, -inf) and EVERY box test on that ray
+// fails -- the group's bounds test in world space, an instance's accelerator
+// bounds test in object space.  A ray with a negative-zero direction component
+// therefore hits nothing there.  (+0.0 behaves normally.)
+__device__ __forceinline__ bool has_negative_zero(V3 d)
+{
+  return (d.x == 0 && signbit(d.x)) || (d.y == 0 && signbit(d.y)) || (d.z == 0 && signbit(d.z));
+}
+
+// ---- time-sampled transforms (motion blur).  The sample's time is draw k of the per-tile
+// time stream mapped to sample_time_range (FixedGridSampler, src/fj_fixed_grid_sampler.cc:
+// 73-77: Fit(rnd, 0, 1, start, end)); k = sample index in the tile = low 20 bits of uid.
+__device__ __forceinline__ double sample_time(const DScene &S, uint32_t tindex)
+{
+  const double x = S.time_tab[tindex];
+  if (x <= 0) return S.time_start;
+  if (x >= 1) return S.time_end;
+  return S.time_start + (S.time_end - S.time_start) * ((x - 0) / (1 - 0));
+}
+
+// XfmLerpTransformSample + matrix + Cramer inverse at `time` (fjgpu_xform_math.h: the host's
+// source, compiled for the device).  Out of line on purpose: it is rare and register hungry.
+__device__ __noinline__ void xform_at(const fj_xform_desc *x, double time, double *M, double *Minv)
+{
+  double m[16], mi[16];
+  fjx::make_transform(*x, time, m, mi);
+  for (int k = 0; k < 12; k++) { M[k] = m[k]; Minv[k] = mi[k]; }
+}
+
+// BoxRayIntersect, reference src/fj_box.cc:73-138, operation for operation.  Used where
+// the reference's own box decides the RESULT (instance bounds, which are not always
+// conservative -- see fjgpu_build.cc), as opposed to pure culling.
+#ifndef FJ_BOXREF_ATTR
+#define FJ_BOXREF_ATTR __forceinline__
+#endif
+__device__ FJ_BOXREF_ATTR bool box_ray_ref(const double *b, V3 o, V3 d, double ray_tmin, double ray_tmax)
+{
+  double tmin, tmax, tymin, tymax, tzmin, tzmax;
+  if (d.x >= 0) { tmin = (b[0] - o.x) / d.x; tmax = (b[3] - o.x) / d.x; }
+  else          { tmin = (b[3] - o.x) / d.x; tmax = (b[0] - o.x) / d.x; }
+  if (d.y >= 0) { tymin = (b[1] - o.y) / d.y; tymax = (b[4] - o.y) / d.y; }
+  else          { tymin = (b[4] - o.y) / d.y; tymax = (b[1] - o.y) / d.y; }
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  if (d.z >= 0) { tzmin = (b[2] - o.z) / d.z; tzmax = (b[5] - o.z) / d.z; }
+  else          { tzmin = (b[5] - o.z) / d.z; tzmax = (b[2] - o.z) / d.z; }
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  return (tmin < ray_tmax) && (tmax > ray_tmin);
+}
+
+// Same decision as box_ray_ref at a fraction of the cost: the slab interval from the
+// per-ray reciprocal differs from the reference's divisions by a few ulp, so it settles
+// every case that is not within 1e-12 (relative) of a boundary; the rest takes the exact
+// path.  `plain` = no direction component is zero (else 0 * inf = NaN: exact path);
+// overflow makes m infinite, which also lands in the exact path.
+__device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3 inv, bool plain, double ray_tmin, double ray_tmax)
+{
+  const double x0 = (b[0] - o.x) * inv.x, x1 = (b[3] - o.x) * inv.x;
+  const double y0 = (b[1] - o.y) * inv.y, y1 = (b[4] - o.y) * inv.y;
+  const double z0 = (b[2] - o.z) * inv.z, z1 = (b[5] - o.z) * inv.z;
+  const double lo = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+  const double hi = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+  const double m = 1e-12 * ((fabs(lo) + fabs(hi)) + (fabs(ray_tmin) + fmin(fabs(ray_tmax), 1e300)));
+  const double g = fmin(fmin(hi - lo, ray_tmax - lo), hi - ray_tmin);
+  if (plain) {
+    if (g > m) return true;
+    if (g < -m) return false;
+  }
+  return box_ray_ref(b, o, d, ray_tmin, ray_tmax);
+}
+__device__ __forceinline__ bool plain_dir(V3 d) { return d.x != 0 && d.y != 0 && d.z != 0; }
+
+// reciprocal for the FILTER only (box_ray_ref_fast decides nothing within 1e-12 of a boundary,
+// and asks box_ray_ref there): hardware estimate + two Newton steps, ~1e-16 relative, a
+// quarter of the instructions of a correctly rounded division.  Zero gives inf / NaN, which
+// plain_dir() has already routed to the exact path.
+__device__ __forceinline__ double filter_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return r;
+}
+
+// vertices of leaf slot i: f64 as stored, or f32 widened (exact) -- see DPrimSet
+__device__ __forceinline__ void load_tri(const double *t64, const float *t32, uint32_t i, V3 *v0, V3 *v1, V3 *v2)
+{
+  if (t32) {
+    const float *p = t32 + (size_t) i * 9;
+    *v0 = mk((double) p[0], (double) p[1], (double) p[2]);
+    *v1 = mk((double) p[3], (double) p[4], (double) p[5]);
+    *v2 = mk((double) p[6], (double) p[7], (double) p[8]);
+  } else {
+    const double *p = t64 + (size_t) i * 9;
+    *v0 = ld3(p); *v1 = ld3(p + 3); *v2 = ld3(p + 6);
+  }
+}
+
+// ------------------------------------------------------- triangle test (a21)
+// TriRayIntersect, reference src/fj_triangle.cc:81-153, non-culling branch,
+// EPSILON 1e-6 (:12); no t-sign test here -- the range test is the caller's
+// (PrimitiveSet::RayIntersect, src/fj_primitive_set.cc:10-26).
+__device__ __forceinline__ bool tri_ray(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
+{
+  const V3 edge1 = v1 - v0;
+  const V3 edge2 = v2 - v0;
+  const V3 pvec = cross(dir, edge2);
+  const double det = dot(edge1, pvec);
+  if (det > -1e-6 && det < 1e-6) return false;
+  const double inv_det = 1.0 / det;
+  const V3 tvec = orig - v0;
+  const double uu = dot(tvec, pvec) * inv_det;
+  if (uu < 0.0 || uu > 1.0) return false;
+  const V3 qvec = cross(tvec, edge1);
+  const double vv = dot(dir, qvec) * inv_det;
+  if (vv < 0.0 || uu + vv > 1.0) return false;
+  *t = dot(edge2, qvec) * inv_det;
+  *u = uu;
+  *v = vv;
+  return true;
+}
+
+// ----------------------------------------------------------------- traversal
+struct Best { double t, u, v; int inst, prim; };
+
+struct LocalCounters { uint32_t nodes, prims, insts; };
+
+// sum over the 64 lanes of the wave (butterfly; every lane gets the total)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned) (v & 0xffffffffull), off);
+    const unsigned hi = __shfl_xor((unsigned) (v >> 32), off);
+    v += ((unsigned long long) hi << 32) | lo;
+  }
+  return v;
+}
+
+// one global atomic per counter per WAVE, issued once at the end of a
+// persistent kernel (a per-thread atomic on one address serialises in L2)
+__device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long long nodes, unsigned long long prims,
+    unsigned long long insts, unsigned long long traced, unsigned long long shadow)
+{
+  nodes = wave_sum(nodes); prims = wave_sum(prims); insts = wave_sum(insts);
+  traced = wave_sum(traced); shadow = wave_sum(shadow);
+  if (__lane_id() == 0) {
+    if (nodes) atomicAdd(&cnt->nodes, nodes);
+    if (prims) atomicAdd(&cnt->prims, prims);
+    if (insts) atomicAdd(&cnt->insts, insts);
+    if (traced) atomicAdd(&cnt->traced, traced);
+    if (shadow) atomicAdd(&cnt->rays[CXT_SHADOW_RAY], shadow);
+  }
+}
+
+#endif

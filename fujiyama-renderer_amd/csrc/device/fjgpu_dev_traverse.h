@@ -1,0 +1,299 @@
+// fjgpu_dev_traverse.h -- persistent per-lane traversal engine and the closest-hit kernel.
+// Part of the kernels translation unit: included by fjgpu_kernels.hip only (device code,
+// compiled with -ffp-contract=off; see the header of that file).
+#ifndef FJGPU_DEV_TRAVERSE_H
+#define FJGPU_DEV_TRAVERSE_H
+
+// ----------------------------------------------------- persistent traversal
+// One traversal engine for closest-hit and any-hit rays, written as a per-lane
+// state machine so that a lane that finishes its ray is refilled from the
+// wave's slice of the queue instead of idling until the slowest lane of the
+// wave is done (ray costs are heavy tailed: most shadow rays leave the BLAS
+// after a few nodes, a few walk hundreds).  Each wave owns a contiguous slice
+// of the ray queue (static split, no global work counter) and hands indices to
+// its idle lanes with ballot + prefix popcount.
+//
+// Semantics reproduced: a hit counts iff tmin <= t <= tmax with
+// the ORIGINAL ray range (RayInRange, src/fj_ray.h:29-32); the closest one wins
+// with strict '<' (src/fj_bvh_accelerator.cc:183, src/fj_grid_accelerator.cc:263);
+// at exactly equal t inside one mesh the larger primitive id wins (the grid's
+// LIFO cell lists test it first).  Instances of the group are visited in group
+// order (ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: the ray
+// goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
+#define TRAV_DONE 0xffffffffu
+// tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
+struct TravTune { uint32_t refill, steps, grab; };
+#define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
+#define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
+#define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
+
+// Claim size.  A wave takes `grab` consecutive rays per atomic; with few rays per launch (a
+// rank of an 8-GPU job, a deep recursion level) whole claims decide the load balance -- 4
+// claims per wave leave the slowest wave ~25 % behind -- so the claim shrinks until every
+// wave gets at least ~16 of them (never below 16 rays: a wave has 64 lanes to fill).
+__device__ __forceinline__ uint32_t adaptive_grab(uint32_t grab, uint32_t n)
+{
+  const uint32_t waves = gridDim.x * (BLOCK / 64);
+  const uint32_t want = n / (waves * 16u);
+  return want >= grab ? grab : (want < 16u ? 16u : want);
+}
+
+struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
+
+// Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
+// consecutive, conflict free), deeper ones -- the builder reports the worst case of the
+// scene's trees -- in a global overflow area ([depth][global thread]).
+struct TravStack {
+  uint32_t *lds;        // s_stack + threadIdx.x
+  uint32_t *ovf;        // overflow base + global thread id (null when no tree needs it)
+  uint32_t ovf_stride;  // threads in the grid
+  __device__ __forceinline__ void push(int &sp, uint32_t v) const
+  {
+    if (sp < FJ_STACK_LDS) lds[sp * BLOCK] = v;
+    else ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride] = v;
+    sp++;
+  }
+  __device__ __forceinline__ uint32_t pop(int &sp) const
+  {
+    --sp;
+    return sp < FJ_STACK_LDS ? lds[sp * BLOCK] : ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride];
+  }
+};
+__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf)
+{
+  TravStack st;
+  st.lds = s_stack + threadIdx.x;
+  st.ovf_stride = gridDim.x * BLOCK;
+  st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
+  return st;
+}
+
+template <bool kCurves, bool kCount, bool kMotion, class Policy>
+__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
+{
+  const unsigned lane = __lane_id();
+  bool head_live = true;                   // wave-uniform: the global head still has entries
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // work distribution: waves claim TRAV_GRAB consecutive queue entries at a time
+  // from a global head (one atomic per 1024 rays).  Static per-wave slices were
+  // measurably worse: neighbouring rays have correlated cost, so whole slices
+  // end up cheap or expensive and the slowest wave sets the kernel time.
+  uint32_t next = 0, range_end = 0;        // wave-uniform
+  tune.grab = adaptive_grab(tune.grab, n);
+  bool have = false;
+  uint32_t idx = 0;
+  V3 o = mk(0, 0, 0), oo = o, od = o, inv = o, d = o, winv = o;
+  double tmin = 0, tmax = 0, rtime = 0;
+  Best best;
+  best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+  int gfirst = 0, gcount = 0, gi = 0, ii = -1;
+  const double *gsb = nullptr;
+  bool anyhit = false, dead_ray = false, plain = false;
+  const DPrimSet *P = nullptr;
+  uint32_t cur = TRAV_DONE;
+  uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
+  int sp = 0;
+
+  for (;;) {
+    // ---- refill idle lanes from the wave's slice
+    const unsigned long long idle = __ballot(!have);
+    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
+      base = __shfl(base, 0);
+      if (base >= n) head_live = false;
+      else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
+    }
+    if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
+      if (!have) {
+        const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
+        if (my < range_end) {
+          RayIn r;
+          r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
+          have = pol.fetch(my, &r);
+          idx = my;
+          o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          if (kMotion) rtime = r.time;
+          const DGroup G = S.groups[r.group];
+          gfirst = G.first; gcount = G.count; gi = 0;
+          gsb = S.groups[r.group].sbounds;
+          best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+          cur = TRAV_DONE; sp = 0;
+          dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
+          winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
+          plain = plain_dir(d);
+        }
+      }
+      next += (uint32_t) __popcll(idle);
+      if (__ballot(have) == 0ull) {
+        if (next >= range_end && !head_live) break;
+        continue;               // only padding slots were fetched / slice exhausted: claim more
+      }
+    }
+
+    // ---- lanes between instances: enter the next instance or retire the ray
+    if (have && cur == TRAV_DONE) {
+      bool found = false;
+      while (!dead_ray && gi < gcount) {
+        ii = S.group_instances[gfirst + gi];
+        gi++;
+        const DInstance *I = &S.instances[ii];
+        if (kCount) lc->insts++;
+        double tn;
+        const double tfar = anyhit ? tmax : fmin(tmax, best.t);
+        // the reference's own (possibly non-enclosing) instance box, full ray range
+        if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+        if (kMotion && I->xform >= 0) {
+          // ObjectInstance::RayIntersect evaluates a time-sampled transform at the ray's time
+          double tm[12], tmi[12];
+          xform_at(&S.xforms[I->xform], rtime, tm, tmi);
+          oo = xpoint(tmi, o);
+          od = xvector(tmi, d);
+        } else {
+          oo = xpoint(I->Minv, o);
+          od = xvector(I->Minv, d);
+        }
+        if (has_negative_zero(od)) continue;
+        inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+        P = &S.primsets[I->primset];
+        if (P->n_prims == 0) continue;
+        if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+        found = true;
+        break;
+      }
+      if (found) { cur = P->root; sp = 0; last_curve = 0xffffffffu; }
+      else { pol.finish(idx, best); have = false; }
+    }
+
+    // ---- inner nodes: a few steps for every lane that holds one
+    for (int step = 0; step < TRAV_STEPS; step++) {
+      const bool inner = have && !(cur & FJ_LEAF_FLAG);
+      if (__ballot(inner) == 0ull) break;
+      if (inner) {
+        const float4 *nd = reinterpret_cast<const float4 *>(&P->nodes[cur]);
+        if (kCount) lc->nodes++;
+        // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
+        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
+        const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+        const float b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+        const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
+        double t0, t1, t2, t3;
+        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv, tmin, tf2, &t0);                          // slot 0 always exists
+        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv, tmin, tf2, &t1);                          // slot 1 always exists
+        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv, tmin, tf2, &t2);
+        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv, tmin, tf2, &t3);
+        // near-to-far order is a heuristic only: f32 keys, misses sort last
+        float k0 = h0 ? fminf((float) t0, FLT_MAX) : INFINITY, k1 = h1 ? fminf((float) t1, FLT_MAX) : INFINITY;
+        float k2 = h2 ? fminf((float) t2, FLT_MAX) : INFINITY, k3 = h3 ? fminf((float) t3, FLT_MAX) : INFINITY;
+        uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
+#define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
+        FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)
+#undef FJ_CSWAP
+        const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
+        if (nh == 0) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+        else {
+          cur = r0;
+          if (nh > 3) stk.push(sp, r3);
+          if (nh > 2) stk.push(sp, r2);
+          if (nh > 1) stk.push(sp, r1);
+        }
+      }
+    }
+
+    // ---- leaves: FP64 Moller-Trumbore on the pre-gathered triangles
+    if (have && (cur & FJ_LEAF_FLAG) && cur != TRAV_DONE) {
+      const uint32_t first = (cur & 0x7fffffffu) >> 3;
+      const uint32_t cnt = (cur & 7u) + 1;
+      bool stop = false;
+      const bool is_curve = kCurves && P->type == FJ_PRIMSET_CURVE;
+      for (uint32_t k = 0; k < cnt; k++) {
+        double t, u = 0, v = 0;
+        if (kCount && !(kCurves && is_curve)) lc->prims++;
+        if (kCurves && is_curve) {
+          // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch).
+          // BLAS entries are sub-segments of curves: the full ribbon test of a curve runs
+          // once, not once per piece entered (same ray, same instance: same result)
+          const size_t sl = first + k;
+          const uint32_t cid = P->prim_ids[sl];
+          if (cid == last_curve) continue;
+          last_curve = cid;
+          if (kCount) lc->prims++;
+          if (!curve_ray(P->curve_cp + sl * 12, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
+                         (int) P->curve_depth[sl], oo, od, &t, &u)) continue;
+          if (!curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
+          v = (double) sl;
+        } else {
+          V3 v0, v1, v2;
+          load_tri(P->tri_verts, P->tri_verts32, first + k, &v0, &v1, &v2);
+          if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
+            const double *w = P->tri_vel + (size_t) (first + k) * 9;
+            v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
+          }
+          if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
+        }
+        if (!(tmin <= t && t <= tmax)) continue;
+        const int pid = (int) P->prim_ids[first + k];
+        if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+          best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
+          if (anyhit) { stop = true; break; }
+        }
+      }
+      if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
+      else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_trace
+struct ClosestPolicy {
+  const DScene *S;
+  const DRay *rays;
+  const DPath *paths;
+  DHit *hits;
+  int default_group;
+  __device__ bool fetch(uint32_t i, RayIn *r) const
+  {
+    const DRay q = rays[i];
+    r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
+    r->tmin = q.tmin; r->tmax = q.tmax;
+    r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].uid & 0xfffffu) : 0.;   // fjgpu_trace: time 0
+    r->group = paths ? paths[i].group : default_group;
+    r->anyhit = false;
+    return true;
+  }
+  __device__ void finish(uint32_t i, const Best &b) const
+  {
+    DHit h;
+    h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
+    hits[i] = h;
+  }
+};
+
+#ifndef FJ_CURVE_MINB
+#define FJ_CURVE_MINB 2
+#endif
+#ifndef FJ_CLOSEST_MINB
+#define FJ_CLOSEST_MINB 3
+#endif
+#ifndef FJ_SHADOW_MINB
+#define FJ_SHADOW_MINB 1
+#endif
+template <bool kCurves, bool kCount, bool kMotion>
+__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+    DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
+{
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  ClosestPolicy pol;
+  pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
+  LocalCounters lc = {0, 0, 0};
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  if (kCount) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
+  }
+}
+
+#endif
