@@ -240,6 +240,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
       e |= M.upload(h.curve_width.data(), h.curve_width.size(), &d.curve_width);
       e |= M.upload(h.curve_Cd.data(), h.curve_Cd.size(), &d.curve_Cd);
       e |= M.upload(h.curve_depth.data(), h.curve_depth.size(), &d.curve_depth);
+      e |= M.upload(h.curve_vel.data(), h.curve_vel.size(), &d.curve_vel);
     }
   }
   std::vector<DTexture> dtex(desc->n_textures);
@@ -261,7 +262,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   S.cam_xform = nullptr;
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
-  for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
+  for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
   S.pad_ = 0;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   S.lrec_hair = nullptr;

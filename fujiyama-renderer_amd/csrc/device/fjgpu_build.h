@@ -30,6 +30,7 @@ struct HostPrimSet {
   std::vector<double> curve_width;    // [n][2]
   std::vector<float> curve_Cd;        // [n][6]
   std::vector<int8_t> curve_depth;    // [n]
+  std::vector<double> curve_vel;      // [n][12] or empty
   uint32_t root;
   double bounds[6];
   double grid_cell[3];

@@ -38,7 +38,6 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   ps->f32_exact = false;
   ps->mesh = nullptr;
   ps->curve = &c;
-  if (c.velocity) { *err = "curve velocity (motion blur) is not on the device path yet"; return FJGPU_EUNSUPPORTED; }
   if (!c.width || !c.P || !c.indices) { *err = "curve set without positions / widths / indices"; return FJGPU_EINVAL; }
   const double ACC_PADDING = .0001;
   for (int k = 0; k < 3; k++) { ps->bounds[k] = c.bounds[k] - ACC_PADDING; ps->bounds[3 + k] = c.bounds[3 + k] + ACC_PADDING; }
@@ -72,23 +71,34 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
     if (i0 < 0 || i0 + 3 >= c.n_points) { *err = "curve index out of range"; return FJGPU_EINVAL; }
     const double w0 = c.width[i0], w1 = c.width[i0 + 3];
     const double radius = .5 * (w0 > w1 ? w0 : w1);
-    // pieces by repeated midpoint subdivision (control polygons; hull property)
-    std::vector<double> pieces((size_t) S * 12);
-    for (int k = 0; k < 12; k++) pieces[k] = c.P[3 * i0 + k];
-    for (int d = 0, cnt = 1; d < seg_depth; d++, cnt *= 2)
-      for (int q = cnt - 1; q >= 0; q--) {
-        double b[12], l[12], r[12];
-        for (int k = 0; k < 12; k++) b[k] = pieces[(size_t) q * 12 + k];
-        for (int a = 0; a < 3; a++) {
-          const double p0 = b[a], p1 = b[3 + a], p2 = b[6 + a], p3 = b[9 + a];
-          const double q0 = .5 * (p0 + p1), q1 = .5 * (p1 + p2), q2 = .5 * (p2 + p3);
-          const double r0 = .5 * (q0 + q1), r1 = .5 * (q1 + q2);
-          const double m = .5 * (r0 + r1);
-          l[a] = p0; l[3 + a] = q0; l[6 + a] = r0; l[9 + a] = m;
-          r[a] = m; r[3 + a] = r1; r[6 + a] = q2; r[9 + a] = p3;
+    // pieces by repeated midpoint subdivision (control polygons; hull property).  With vertex
+    // velocities the same subdivision of the end-of-shutter curve (P + velocity) bounds the
+    // piece at time 1; positions are linear in time, so the two hulls bound the whole sweep.
+    auto subdivide = [&](const double *cp12, std::vector<double> &pieces) {
+      pieces.assign((size_t) S * 12, 0.);
+      for (int k = 0; k < 12; k++) pieces[k] = cp12[k];
+      for (int d = 0, cnt = 1; d < seg_depth; d++, cnt *= 2)
+        for (int q = cnt - 1; q >= 0; q--) {
+          double b[12], l[12], r[12];
+          for (int k = 0; k < 12; k++) b[k] = pieces[(size_t) q * 12 + k];
+          for (int a = 0; a < 3; a++) {
+            const double p0 = b[a], p1 = b[3 + a], p2 = b[6 + a], p3 = b[9 + a];
+            const double q0 = .5 * (p0 + p1), q1 = .5 * (p1 + p2), q2 = .5 * (p2 + p3);
+            const double r0 = .5 * (q0 + q1), r1 = .5 * (q1 + q2);
+            const double m = .5 * (r0 + r1);
+            l[a] = p0; l[3 + a] = q0; l[6 + a] = r0; l[9 + a] = m;
+            r[a] = m; r[3 + a] = r1; r[6 + a] = q2; r[9 + a] = p3;
+          }
+          for (int k = 0; k < 12; k++) { pieces[(size_t) (2 * q) * 12 + k] = l[k]; pieces[(size_t) (2 * q + 1) * 12 + k] = r[k]; }
         }
-        for (int k = 0; k < 12; k++) { pieces[(size_t) (2 * q) * 12 + k] = l[k]; pieces[(size_t) (2 * q + 1) * 12 + k] = r[k]; }
-      }
+    };
+    std::vector<double> pieces, pieces_end;
+    subdivide(&c.P[3 * i0], pieces);
+    if (c.velocity) {
+      double endcp[12];
+      for (int k = 0; k < 12; k++) endcp[k] = c.P[3 * i0 + k] + c.velocity[3 * i0 + k];
+      subdivide(endcp, pieces_end);
+    }
     for (int sgm = 0; sgm < S; sgm++) {
       double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
       for (int k = 0; k < 4; k++)
@@ -96,6 +106,11 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
           const double p = pieces[(size_t) sgm * 12 + 3 * k + a];
           mn[a] = std::min(mn[a], p);
           mx[a] = std::max(mx[a], p);
+          if (c.velocity) {
+            const double pe = pieces_end[(size_t) sgm * 12 + 3 * k + a];
+            mn[a] = std::min(mn[a], pe);
+            mx[a] = std::max(mx[a], pe);
+          }
         }
       PrimRef &r = refs[(size_t) i * S + sgm];
       for (int a = 0; a < 3; a++) {
@@ -121,9 +136,11 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   ps->curve_width.resize((size_t) n * 2);
   ps->curve_Cd.assign((size_t) n * 6, 0.f);
   ps->curve_depth.resize(n);
+  if (c.velocity) ps->curve_vel.resize((size_t) n * 12);
   for (int s = 0; s < n; s++) {
     const int i0 = c.indices[ps->prim_ids[s]];
     for (int k = 0; k < 12; k++) ps->curve_cp[(size_t) s * 12 + k] = c.P[3 * i0 + k];
+    if (c.velocity) for (int k = 0; k < 12; k++) ps->curve_vel[(size_t) s * 12 + k] = c.velocity[3 * i0 + k];
     const double w0 = c.width[i0], w1 = c.width[i0 + 3];
     ps->curve_width[2 * (size_t) s] = w0;
     ps->curve_width[2 * (size_t) s + 1] = w1;

@@ -30,7 +30,7 @@ __device__ __forceinline__ double dmax(double x, double y) { return x > y ? x : 
 __device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : y; }
 __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
 
-__device__ bool curve_ray(const double *cpw, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+__device__ bool curve_ray(const double *cpw, const double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
 {
   // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
   const double ray_scale = sqrt(dot(od, od));
@@ -51,7 +51,8 @@ __device__ bool curve_ray(const double *cpw, double w0, double w1, int depth, V3
   {
     V3 p[4];
     for (int k = 0; k < 4; k++) {
-      const V3 q = ld3(cpw + 3 * k);
+      V3 q = ld3(cpw + 3 * k);
+      if (velw) q = q + time * ld3(velw + 3 * k);       // time_sample, src/fj_curve.cc:392-397
       p[k] = mk(r0.x * q.x + r0.y * q.y + r0.z * q.z + m03,
                 r1.x * q.x + r1.y * q.y + r1.z * q.z + m13,
                 r2.x * q.x + r2.y * q.y + r2.z * q.z + m23);
@@ -135,6 +136,77 @@ __device__ bool curve_ray(const double *cpw, double w0, double w1, int depth, V3
 // the ribbon radius.  A ribbon hit whose ray point falls in a neighbouring cell that
 // does not list the curve is therefore rejected by the reference.  The same rule is
 // applied here so the two renderers see the same fur.
+// The same predicate for a curve with vertex velocities: box_bezier3_recursive
+// (src/fj_curve.cc:428-462) splits the curve at shutter open and at shutter close alike, gives
+// each half the velocity "close half - open half", and at depth 0 tests the box of the four
+// control points and of the four points moved by that velocity (box_bezier3, N_STEPS = 1).
+// Inner levels are pruned with the hull of both polygons widened by 1e-12 (relative): the
+// leaf's "cp + (end - cp)" differs from "end" by rounding only.
+__device__ bool curve_listed_in_cell_of_moving(const DPrimSet *P, const double *cpw, const double *velw, V3 hitp)
+{
+  double cmin[3], cmax[3];
+  const double hp[3] = {hitp.x, hitp.y, hitp.z};
+  for (int a = 0; a < 3; a++) {
+    int c = (int) floor((hp[a] - P->bounds[a]) / P->grid_cell[a]);
+    c = c < 0 ? 0 : (c > P->grid_n[a] - 1 ? P->grid_n[a] - 1 : c);
+    cmin[a] = P->bounds[a] + (double) c * P->grid_cell[a];
+    cmax[a] = cmin[a] + P->grid_cell[a];
+    if (hp[a] < cmin[a] || cmax[a] < hp[a]) return false;
+  }
+  const V3 r0 = ld3(cpw), r1 = ld3(cpw + 3), r2 = ld3(cpw + 6), r3 = ld3(cpw + 9);
+  const V3 w0 = ld3(velw), w1 = ld3(velw + 3), w2 = ld3(velw + 6), w3 = ld3(velw + 9);
+  const uint32_t depth = 5, nleaf = 32;
+  uint32_t j = 0;
+  while (j < nleaf) {
+    V3 c0 = r0, c1 = r1, c2 = r2, c3 = r3;      // control points at shutter open
+    V3 v0 = w0, v1 = w1, v2 = w2, v3 = w3;      // velocity of this (sub)curve
+    bool pruned = false;
+    for (uint32_t L = 0;; L++) {
+      // the curve at shutter close: time_sample(&end, 1) = cp + 1 * vel; also the moved
+      // points of box_bezier3 (cp + vel / N_STEPS, N_STEPS = 1)
+      const V3 m0 = c0 + 1. * v0, m1 = c1 + 1. * v1, m2 = c2 + 1. * v2, m3 = c3 + 1. * v3;
+      double mn[3] = {dmin(dmin(dmin(c0.x, c1.x), c2.x), c3.x), dmin(dmin(dmin(c0.y, c1.y), c2.y), c3.y), dmin(dmin(dmin(c0.z, c1.z), c2.z), c3.z)};
+      double mx[3] = {dmax(dmax(dmax(c0.x, c1.x), c2.x), c3.x), dmax(dmax(dmax(c0.y, c1.y), c2.y), c3.y), dmax(dmax(dmax(c0.z, c1.z), c2.z), c3.z)};
+      const double en[3] = {dmin(dmin(dmin(m0.x, m1.x), m2.x), m3.x), dmin(dmin(dmin(m0.y, m1.y), m2.y), m3.y), dmin(dmin(dmin(m0.z, m1.z), m2.z), m3.z)};
+      const double ex[3] = {dmax(dmax(dmax(m0.x, m1.x), m2.x), m3.x), dmax(dmax(dmax(m0.y, m1.y), m2.y), m3.y), dmax(dmax(dmax(m0.z, m1.z), m2.z), m3.z)};
+      for (int a = 0; a < 3; a++) { mn[a] = dmin(mn[a], en[a]); mx[a] = dmax(mx[a], ex[a]); }
+      if (L < depth) {                     // inner level: pruning only, slightly widened
+        for (int a = 0; a < 3; a++) { const double pad = 1e-12 * (fabs(mn[a]) + fabs(mx[a])) + 1e-300; mn[a] -= pad; mx[a] += pad; }
+      }
+      const bool overlap = !(mx[0] < cmin[0] || mn[0] > cmax[0] || mx[1] < cmin[1] || mn[1] > cmax[1] || mx[2] < cmin[2] || mn[2] > cmax[2]);
+      if (!overlap) {
+        const uint32_t span = 1u << (depth - L);
+        j = ((j / span) + 1) * span;
+        pruned = true;
+        break;
+      }
+      if (L == depth) return true;
+      // split_bezier3 of the open and of the close curve; keep the half selected by j and
+      // give it the velocity "close half - open half"
+      Bz b, eb;
+      b.c0 = c0; b.c1 = c1; b.c2 = c2; b.c3 = c3; b.w0 = b.w1 = 0;
+      eb.c0 = m0; eb.c1 = m1; eb.c2 = m2; eb.c3 = m3; eb.w0 = eb.w1 = 0;
+      const V3 midP = bez_eval(b, .5), emidP = bez_eval(eb, .5);
+      const V3 midCP = mid_point(c1, c2), emidCP = mid_point(m1, m2);
+      V3 e0, e1, e2, e3;
+      if (((j >> (depth - L - 1)) & 1u) == 0) {
+        const V3 l1 = mid_point(c0, c1), el1 = mid_point(m0, m1);
+        const V3 l2 = mid_point(l1, midCP), el2 = mid_point(el1, emidCP);
+        c1 = l1; c2 = l2; c3 = midP;
+        e0 = m0; e1 = el1; e2 = el2; e3 = emidP;
+      } else {
+        const V3 q2 = mid_point(c3, c2), eq2 = mid_point(m3, m2);
+        const V3 q1 = mid_point(q2, midCP), eq1 = mid_point(eq2, emidCP);
+        c0 = midP; c1 = q1; c2 = q2;
+        e0 = emidP; e1 = eq1; e2 = eq2; e3 = m3;
+      }
+      v0 = e0 - c0; v1 = e1 - c1; v2 = e2 - c2; v3 = e3 - c3;
+    }
+    if (!pruned) j++;
+  }
+  return false;
+}
+
 __device__ bool curve_listed_in_cell_of(const DPrimSet *P, const double *cpw, V3 hitp)
 {
   int ci[3];

@@ -308,7 +308,12 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
       const size_t sl = (size_t) h.v;
       const double vhit = h.u;
       const double *cp = P->curve_cp + sl * 12;
-      const V3 c0 = ld3(cp), c1 = ld3(cp + 3), c2 = ld3(cp + 6), c3 = ld3(cp + 9);
+      V3 c0 = ld3(cp), c1 = ld3(cp + 3), c2 = ld3(cp + 6), c3 = ld3(cp + 9);
+      if (kMotion && P->curve_vel) {          // time_sample (src/fj_curve.cc:392-397): cp += time * velocity
+        const double tm_ = sample_time(S, p.uid & 0xfffffu);
+        const double *w = P->curve_vel + sl * 12;
+        c0 = c0 + tm_ * ld3(w); c1 = c1 + tm_ * ld3(w + 3); c2 = c2 + tm_ * ld3(w + 6); c3 = c3 + tm_ * ld3(w + 9);
+      }
       const double uu = 1 - vhit;
       const double da = 2 * uu * uu, db = 4 * uu * vhit, dc = 2 * vhit * vhit;
       dPdv = da * (c1 - c0) + db * (c2 - c1) + dc * (c3 - c2);   // derivative_bezier3, :474-486

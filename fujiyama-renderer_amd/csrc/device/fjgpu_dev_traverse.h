@@ -221,9 +221,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           if (cid == last_curve) continue;
           last_curve = cid;
           if (kCount) lc->prims++;
-          if (!curve_ray(P->curve_cp + sl * 12, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
+          const double *cvel = (kMotion && P->curve_vel) ? P->curve_vel + sl * 12 : nullptr;
+          if (!curve_ray(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
                          (int) P->curve_depth[sl], oo, od, &t, &u)) continue;
-          if (!curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
+          if (cvel ? !curve_listed_in_cell_of_moving(P, P->curve_cp + sl * 12, cvel, oo + t * od)
+                   : !curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
           v = (double) sl;
         } else {
           V3 v0, v1, v2;

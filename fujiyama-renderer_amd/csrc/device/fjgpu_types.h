@@ -50,6 +50,8 @@ struct DPrimSet {
   const double *curve_width;   // [n_curves][2]  end widths (BLAS order)
   const float *curve_Cd;       // [n_curves][6]  end colours (BLAS order)
   const int8_t *curve_depth;   // [n_curves]     cached split depth (BLAS order)
+  const double *curve_vel;     // [n_curves][12] control-point velocities (BLAS order) or null: Curve::ray_intersect
+                               //                moves each control point by time * velocity
   double bounds[6];            // Accelerator::bounds_ = primset bounds + 1e-4 (object space)
   // curves only: geometry of the reference's uniform grid (origin = bounds min, cell size,
   // cell counts); needed to reproduce its "hit point must lie in a cell that lists the

@@ -160,14 +160,117 @@ void Curve::ComputeBounds()
   for (int a = 0; a < 3; a++) { bounds[a] = mn[a] - max_radius; bounds[3 + a] = mx[a] + max_radius; }
 }
 
+// generate_hair (procedures/curve_generator_procedure/curve_generator_procedure.cc:280-452):
+// strands of five chained cubics grown from the upper, front part of the mesh, bent by
+// Perlin noise and a downward pull, with per-vertex velocities (hair_velocity_blur.py).
+// Positions come from ONE default-seeded XorShift (deterministic), unlike the fur mode's rand().
+namespace {
+struct XorShiftHost {
+  uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+  double f01()
+  {
+    const uint32_t t = s[0] ^ (s[0] << 11);
+    s[0] = s[1]; s[1] = s[2]; s[2] = s[3];
+    s[3] = (s[3] ^ (s[3] >> 19)) ^ (t ^ (t >> 8));
+    return (double) s[3] / 4294967295u;
+  }
+};
+}  // namespace
+
+static int GenerateHair(const Mesh &mesh, Curve &curve, std::string *err)
+{
+  const double ymin = mesh.bounds[1], ymax = mesh.bounds[4], zmin = mesh.bounds[2], zmax = mesh.bounds[5];
+  const int FACE_COUNT = mesh.face_count();
+  const int N_CURVES_PER_HAIR = 5;
+  std::vector<int> ncurves_on_face(FACE_COUNT);
+  long total = 0;
+  for (int i = 0; i < FACE_COUNT; i++) {
+    const int32_t *ix = &mesh.indices[3 * i];
+    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
+    const V c = cross(P1 - P0, P2 - P0);
+    const double area = .5 * std::sqrt(dot(c, c));           // TriComputeArea
+    const double ycenter = (P0.y + P1.y + P2.y) / 3.;
+    const double ynml = (ycenter - ymin) / (ymax - ymin);
+    const double zcenter = (P0.z + P1.z + P2.z) / 3.;
+    const double znml = (zcenter - zmin) / (zmax - zmin);
+    ncurves_on_face[i] = 100000 * area;
+    if (ynml < .5 || znml > .78) ncurves_on_face[i] = 0;
+    total += (long) ncurves_on_face[i] * N_CURVES_PER_HAIR;
+  }
+  if (total > 50000000) { *err = "CurveGeneratorProcedure: more than 5e7 curves requested"; return -1; }
+  const int total_ncurves = (int) total;
+  const int total_ncps = 4 * total_ncurves;
+  curve.P.assign((size_t) total_ncps * 3, 0.);
+  curve.width.assign(total_ncps, 0.);
+  curve.Cd.assign((size_t) total_ncps * 3, 0.f);
+  curve.velocity.assign((size_t) total_ncps * 3, 0.);
+  curve.indices.assign(total_ncurves, 0);
+  curve.uv.clear();
+
+  XorShiftHost rng;
+  const bool has_N = !mesh.N.empty();
+  int curve_id = 0, cp_id = 0;
+  for (int i = 0; i < FACE_COUNT; i++) {
+    const int32_t *ix = &mesh.indices[3 * i];
+    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
+    const V zero{0, 0, 0};
+    const V N0 = has_N ? at(mesh.N, ix[0]) : zero, N1 = has_N ? at(mesh.N, ix[1]) : zero, N2 = has_N ? at(mesh.N, ix[2]) : zero;
+    for (int j = 0; j < ncurves_on_face[i]; j++) {
+      const double u = rng.f01();
+      const double v = (1 - u) * rng.f01();
+      const double t = 1 - u - v;
+      const V src_P = t * P0 + u * P1 + v * P2;
+      V src_N = normalize(t * N0 + u * N1 + v * N2);
+      src_N.y = src_N.y < .1 ? src_N.y : .1;                 // Min(src_N.y, .1)
+      if (src_N.x < .1 && src_N.z < .1) {
+        src_N.x /= src_N.x;                                   // (sic) 1, or NaN for 0
+        src_N.z /= src_N.z;
+        src_N.x *= .5;
+        src_N.z *= .5;
+      }
+      src_N = normalize(src_N);
+      V next_P = src_P, next_N = src_N;
+      for (int k = 0; k < N_CURVES_PER_HAIR; k++) {
+        curve.indices[curve_id] = cp_id;
+        for (int vtx = 0; vtx < 4; vtx++) {
+          const double w[4] = {1, .5, .2, .05};
+          curve.P[3 * cp_id] = next_P.x; curve.P[3 * cp_id + 1] = next_P.y; curve.P[3 * cp_id + 2] = next_P.z;
+          curve.Cd[3 * cp_id] = .9f; curve.Cd[3 * cp_id + 1] = .8f; curve.Cd[3 * cp_id + 2] = .5f;
+          curve.width[cp_id] = (k == N_CURVES_PER_HAIR - 1) ? .0005 * w[vtx] : .0005;
+          const V curr_P = next_P;
+          if (vtx != 3) {
+            const double amp = .002 * .1, freq = 100, segment_len = .01;
+            const V Q = mulv(curr_P, V{freq, 2, freq});
+            const V noise_vec = perlin_noise3d(Q, 2, .5, 2);
+            next_P = next_P + (segment_len * next_N + mulv(V{amp, 0, amp}, noise_vec));
+            next_N = normalize(next_P - curr_P);
+            next_N.y += -.5;
+            next_N = normalize(next_N);
+          }
+          {
+            const double amp = .01, freq = 1;
+            const V Q = freq * curr_P + V{0, 5, 0};
+            const V noise_vec = perlin_noise3d(Q, 2, .5, 2);
+            const double vmult = smooth_step(1, N_CURVES_PER_HAIR, k);
+            const V curr_v = (vmult * amp) * noise_vec;
+            curve.velocity[3 * cp_id] = curr_v.x; curve.velocity[3 * cp_id + 1] = curr_v.y; curve.velocity[3 * cp_id + 2] = curr_v.z;
+          }
+          cp_id++;
+        }
+        curve_id++;
+      }
+    }
+  }
+  curve.ComputeBounds();
+  return 0;
+}
+
 int RunCurveGenerator(Scene *sc, Procedure *proc, std::string *err)
 {
   if (proc->mesh < 0 || proc->curve < 0) { *err = "CurveGeneratorProcedure: mesh and curve must be assigned"; return -1; }
   auto hair = proc->numbers.find("is_hair");
-  if (hair != proc->numbers.end() && !hair->second.empty() && hair->second[0] > 0) {
-    *err = "CurveGeneratorProcedure: is_hair mode is not built in";
-    return -1;
-  }
+  if (hair != proc->numbers.end() && !hair->second.empty() && hair->second[0] > 0)
+    return GenerateHair(*sc->meshes[proc->mesh], *sc->curves[proc->curve], err);
   const Mesh &mesh = *sc->meshes[proc->mesh];
   Curve &curve = *sc->curves[proc->curve];
   const int FACE_COUNT = mesh.face_count();

@@ -263,7 +263,7 @@ def arealights(asset_dir, res=(640, 480), spp=(6, 6), mesh="small", kind="grid",
     return si.text()
 
 
-def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=()):
+def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=(), hair=False):
     """C5: fur (cubic Bezier curves + HairShader) grown on a mesh by
     CurveGeneratorProcedure; plastic mesh and floor without reflection (furry_bunny.scn)."""
     a = synth.ensure_assets(asset_dir, (mesh,))
@@ -286,6 +286,9 @@ def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, 
     si.NewProcedure("bunny_hair_gen", "curve_generator_procedure")
     si.AssignMesh("bunny_hair_gen", "mesh", "bunny_mesh")
     si.AssignCurve("bunny_hair_gen", "curve", "curve_data")
+    if hair:
+        # strands of five chained cubics with per-vertex velocities (scenes/hair_velocity_blur.py)
+        si.SetProperty1("bunny_hair_gen", "is_hair", 1)
     si.RunProcedure("bunny_hair_gen")
     si.NewObjectInstance("bunny1", "bunny_mesh")
     si.AssignShader("bunny1", "DEFAULT_SHADING_GROUP", "bunny_shader")
