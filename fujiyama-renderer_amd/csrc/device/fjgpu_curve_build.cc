@@ -125,10 +125,10 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
       r.id = (uint32_t) i;
     }
   }
-  // a ribbon test costs tens of node steps: small leaves, splits almost always pay
-  int leaf = 1;
+  // a ribbon test costs tens of node steps: ONE curve per leaf (the traversal's two-stage
+  // ribbon test relies on it), splits almost always pay
+  const int leaf = 1;
   float tc = .05f;
-  if (const char *e = getenv("FJGPU_CURVE_LEAF")) leaf = atoi(e);
   if (const char *e = getenv("FJGPU_CURVE_TRAVCOST")) tc = (float) atof(e);
   BuildBlas(ps, refs, leaf, tc);
   const int n = ps->n_prims;

@@ -30,7 +30,8 @@ __device__ __forceinline__ double dmax(double x, double y) { return x > y ? x : 
 __device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : y; }
 __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
 
-__device__ bool curve_ray(const double *cpw, const double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+// The curve (moved to the ray's time) in ray space: origin at the ray origin, +z along the ray
+__device__ __forceinline__ Bz curve_to_ray_space(const double *cpw, const double *velw, double time, double w0, double w1, V3 oo, V3 od, double *ray_scale_out)
 {
   // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
   const double ray_scale = sqrt(dot(od, od));
@@ -48,18 +49,46 @@ __device__ bool curve_ray(const double *cpw, const double *velw, double time, do
   const double m13 = r1.x * nox + r1.y * noy + r1.z * noz;
   const double m23 = r2.x * nox + r2.y * noy + r2.z * noz;
   Bz root;
-  {
-    V3 p[4];
-    for (int k = 0; k < 4; k++) {
-      V3 q = ld3(cpw + 3 * k);
-      if (velw) q = q + time * ld3(velw + 3 * k);       // time_sample, src/fj_curve.cc:392-397
-      p[k] = mk(r0.x * q.x + r0.y * q.y + r0.z * q.z + m03,
-                r1.x * q.x + r1.y * q.y + r1.z * q.z + m13,
-                r2.x * q.x + r2.y * q.y + r2.z * q.z + m23);
-    }
-    root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
-    root.w0 = w0; root.w1 = w1;
+  V3 p[4];
+  for (int k = 0; k < 4; k++) {
+    V3 q = ld3(cpw + 3 * k);
+    if (velw) q = q + time * ld3(velw + 3 * k);       // time_sample, src/fj_curve.cc:392-397
+    p[k] = mk(r0.x * q.x + r0.y * q.y + r0.z * q.z + m03,
+              r1.x * q.x + r1.y * q.y + r1.z * q.z + m13,
+              r2.x * q.x + r2.y * q.y + r2.z * q.z + m23);
   }
+  root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
+  root.w0 = w0; root.w1 = w1;
+  *ray_scale_out = ray_scale;
+  return root;
+}
+
+// converge_bezier3's entry test (get_bezier3_bounds: control points +- max radius) against
+// the ray axis
+__device__ __forceinline__ bool bz_misses_ray(const Bz &b)
+{
+  const double radius = .5 * dmax(b.w0, b.w1);
+  const double mnx = dmin(dmin(dmin(b.c0.x, b.c1.x), b.c2.x), b.c3.x) - radius;
+  const double mxx = dmax(dmax(dmax(b.c0.x, b.c1.x), b.c2.x), b.c3.x) + radius;
+  const double mny = dmin(dmin(dmin(b.c0.y, b.c1.y), b.c2.y), b.c3.y) - radius;
+  const double mxy = dmax(dmax(dmax(b.c0.y, b.c1.y), b.c2.y), b.c3.y) + radius;
+  const double mxz = dmax(dmax(dmax(b.c0.z, b.c1.z), b.c2.z), b.c3.z) + radius;
+  return mnx >= radius || mxx <= -radius || mny >= radius || mxy <= -radius || mxz <= 1e-6;
+}
+
+// first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
+// (exactly the test curve_ray starts with: a curve rejected here is rejected there)
+__device__ bool curve_may_hit(const double *cpw, const double *velw, double time, double w0, double w1, V3 oo, V3 od)
+{
+  double rs;
+  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &rs);
+  return !bz_misses_ray(root);
+}
+
+__device__ bool curve_ray(const double *cpw, const double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+{
+  double ray_scale;
+  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &ray_scale);
   double best_z = DBL_MAX, best_v = DBL_MAX;
   bool any = false;
   const uint32_t nleaf = 1u << depth;
@@ -69,14 +98,7 @@ __device__ bool curve_ray(const double *cpw, const double *velw, double time, do
     double v0 = 0, vn = 1;
     bool pruned = false;
     for (int L = 0;; L++) {
-      // converge_bezier3 entry test: get_bezier3_bounds (cp bounds +- max radius)
-      const double radius = .5 * dmax(b.w0, b.w1);
-      const double mnx = dmin(dmin(dmin(b.c0.x, b.c1.x), b.c2.x), b.c3.x) - radius;
-      const double mxx = dmax(dmax(dmax(b.c0.x, b.c1.x), b.c2.x), b.c3.x) + radius;
-      const double mny = dmin(dmin(dmin(b.c0.y, b.c1.y), b.c2.y), b.c3.y) - radius;
-      const double mxy = dmax(dmax(dmax(b.c0.y, b.c1.y), b.c2.y), b.c3.y) + radius;
-      const double mxz = dmax(dmax(dmax(b.c0.z, b.c1.z), b.c2.z), b.c3.z) + radius;
-      if (mnx >= radius || mxx <= -radius || mny >= radius || mxy <= -radius || mxz <= 1e-6) {
+      if (bz_misses_ray(b)) {
         const uint32_t span = 1u << (depth - L);
         j = ((j / span) + 1) * span;
         pruned = true;

@@ -22,7 +22,7 @@
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
 // tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
-struct TravTune { uint32_t refill, steps, grab; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
@@ -89,6 +89,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   int gfirst = 0, gcount = 0, gi = 0, ii = -1;
   const double *gsb = nullptr;
   bool anyhit = false, dead_ray = false, plain = false;
+  bool deep = false;                       // holding a curve whose ribbon test awaits its second stage
   const DPrimSet *P = nullptr;
   uint32_t cur = TRAV_DONE;
   uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
@@ -203,31 +204,28 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       }
     }
 
-    // ---- leaves: FP64 Moller-Trumbore on the pre-gathered triangles
-    if (have && (cur & FJ_LEAF_FLAG) && cur != TRAV_DONE) {
+    // ---- leaves: FP64 Moller-Trumbore on the pre-gathered triangles; curve leaves (always a
+    // single curve, fjgpu_curve_build.cc) only take the first stage of the ribbon test here --
+    // does the curve's ray-space box reach the ray? -- and wait for the second stage below
+    if (have && !deep && (cur & FJ_LEAF_FLAG) && cur != TRAV_DONE) {
       const uint32_t first = (cur & 0x7fffffffu) >> 3;
       const uint32_t cnt = (cur & 7u) + 1;
       bool stop = false;
-      const bool is_curve = kCurves && P->type == FJ_PRIMSET_CURVE;
-      for (uint32_t k = 0; k < cnt; k++) {
-        double t, u = 0, v = 0;
-        if (kCount && !(kCurves && is_curve)) lc->prims++;
-        if (kCurves && is_curve) {
-          // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch).
-          // BLAS entries are sub-segments of curves: the full ribbon test of a curve runs
-          // once, not once per piece entered (same ray, same instance: same result)
-          const size_t sl = first + k;
-          const uint32_t cid = P->prim_ids[sl];
-          if (cid == last_curve) continue;
+      if (kCurves && P->type == FJ_PRIMSET_CURVE) {
+        // BLAS entries are sub-segments of curves: the ribbon test of a curve runs once, not
+        // once per piece entered (same ray, same instance: same result)
+        const size_t sl = first;
+        const uint32_t cid = P->prim_ids[sl];
+        if (cid != last_curve) {
           last_curve = cid;
           if (kCount) lc->prims++;
           const double *cvel = (kMotion && P->curve_vel) ? P->curve_vel + sl * 12 : nullptr;
-          if (!curve_ray(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
-                         (int) P->curve_depth[sl], oo, od, &t, &u)) continue;
-          if (cvel ? !curve_listed_in_cell_of_moving(P, P->curve_cp + sl * 12, cvel, oo + t * od)
-                   : !curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) continue;
-          v = (double) sl;
-        } else {
+          deep = curve_may_hit(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1], oo, od);
+        }
+      } else {
+        for (uint32_t k = 0; k < cnt; k++) {
+          double t, u = 0, v = 0;
+          if (kCount) lc->prims++;
           V3 v0, v1, v2;
           load_tri(P->tri_verts, P->tri_verts32, first + k, &v0, &v1, &v2);
           if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
@@ -235,16 +233,49 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
             v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
           }
           if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
-        }
-        if (!(tmin <= t && t <= tmax)) continue;
-        const int pid = (int) P->prim_ids[first + k];
-        if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
-          best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
-          if (anyhit) { stop = true; break; }
+          if (!(tmin <= t && t <= tmax)) continue;
+          const int pid = (int) P->prim_ids[first + k];
+          if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+            best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
+            if (anyhit) { stop = true; break; }
+          }
         }
       }
       if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
-      else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+      else if (!deep) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+    }
+
+    // ---- second stage of the ribbon test (the recursive subdivision, long and divergent:
+    // PMC on C5 showed 8.8 of 64 lanes active per VALU instruction when every lane ran it as
+    // soon as it reached a curve): it waits until enough lanes need it, or nobody can walk on
+    if (kCurves) {
+      const unsigned long long deepm = __ballot(have && deep);
+      if (deepm) {
+        const unsigned long long busym = __ballot(have && !deep && cur != TRAV_DONE);   // walkers and fresh leaves
+        if ((unsigned) __popcll(deepm) >= tune.leaf_wait || busym == 0ull) {
+          if (have && deep) {
+            deep = false;
+            bool stop = false;
+            const size_t sl = (cur & 0x7fffffffu) >> 3;
+            const double *cvel = (kMotion && P->curve_vel) ? P->curve_vel + sl * 12 : nullptr;
+            double t, u = 0;
+            // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
+            if (curve_ray(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
+                          (int) P->curve_depth[sl], oo, od, &t, &u) &&
+                (cvel ? curve_listed_in_cell_of_moving(P, P->curve_cp + sl * 12, cvel, oo + t * od)
+                      : curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) &&
+                (tmin <= t && t <= tmax)) {
+              const int pid = (int) P->prim_ids[sl];
+              if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+                best.t = t; best.u = u; best.v = (double) sl; best.inst = ii; best.prim = pid;
+                stop = anyhit;
+              }
+            }
+            if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
+            else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+          }
+        }
+      }
     }
   }
 }

@@ -110,6 +110,7 @@ static TravTune trav_tune()
     t.refill = env("FJGPU_TRAV_REFILL", 24);
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 128);
+    t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 32);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
     if (t.steps < 1) t.steps = 1;
