@@ -455,7 +455,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   const size_t cap_samples = full_tile_samples * (size_t) bt;
   // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
   // max_children), so a queue never needs more than one entry per sample
-  const size_t cap_rays = cap_samples + 1024;
+  // (small frames get queues of at least 8 M entries: with room for the worst-case fan-out the
+  // scheduler does not have to cut their levels into chunks of a few thousand rays)
+  const size_t cap_rays = std::max<size_t>(cap_samples, std::min<size_t>((size_t) 8 << 20, cap_samples * 16)) + 1024;
   sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
   // one queue per recursion level: camera + every diffuse / reflect / refract bounce
