@@ -60,6 +60,32 @@ def test_libraries_load_and_report_no_device_loudly(asset_dir):
     assert "RenderScene" in str(e2.value) and "no CPU fallback" in str(e2.value)
 
 
+def test_global_options_and_host_build_paths_without_a_device(asset_dir):
+    """process-wide options of the core are validated without a GPU, and scene creation walks
+    the whole host-side preparation (flatten, BLAS build or its device-build bypass, instance
+    boxes, light tables) before it reports the missing device"""
+    gpu.global_option("device_build", 1)
+    gpu.global_option("device_build", 0)
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.global_option("no_such_option", 1)
+    assert "unknown global option" in str(e.value)
+    if HAVE_GPU:
+        return
+    for builder, kw in (("motion", dict(res=(32, 24), spp=(1, 1), mesh="tiny", kind="velocity+object")),
+                        ("arealights", dict(res=(32, 24), spp=(1, 1), mesh="tiny", kind="both")),
+                        ("furry", dict(res=(32, 24), spp=(1, 1), mesh="furball", nlights=2, hair=True))):
+        for dev in (0, 1):
+            gpu.global_option("device_build", dev)
+            try:
+                host.run_scene_text(workloads.BUILDERS[builder](asset_dir, **kw), deferred=True)
+                sp, rd = host.get_desc()
+                with pytest.raises(gpu.GpuError) as e:
+                    gpu.Scene(sp)
+                assert "no CPU fallback" in str(e.value)
+            finally:
+                gpu.global_option("device_build", 0)
+
+
 def test_parser_grammar_and_errors(asset_dir):
     ok = "# comment\n\nNewCamera cam1 PerspectiveCamera\nSetProperty3 cam1 translate 0 1 7\nSetProperty1 cam1 rotate_order ORDER_XYZ\n"
     assert host.run_scene_text(ok, deferred=True) == 0
