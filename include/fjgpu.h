@@ -100,7 +100,8 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
  * a recursion level on its own stream, concurrent with the next level. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
-/* Process-wide options read by fjgpu_scene_create: "device_build" 0/1 -- build the BLAS of
+/* Process-wide options read by fjgpu_scene_create (which stands for the reference's
+ * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" 0/1 -- build the BLAS of
  * meshes on the GPU (LBVH; tens of ms for millions of triangles) instead of the host's
  * binned-SAH build (slower to build, faster to trace: the default).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
