@@ -77,6 +77,7 @@ struct fjgpu_scene {
   struct Level { DRay *rays; DPath *paths; size_t cap; };
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   int max_children;                // most child rays one shading event can emit in this scene
+  bool uses_sample_uid;            // sample times / random streams are keyed by (tile id << 20) + sample index
   DHit *d_hits;
   DLightRec *d_lrecs[2];           // double buffered: the shadow stream consumes one while shading fills the other
   DLightHair *d_lhair[2];          // only when the scene has a HairShader
@@ -309,8 +310,10 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   sc->cam_fov = hs.cam_fov;
   sc->n_light_samples = S.n_light_samples;
   sc->max_children = 0;
+  sc->uses_sample_uid = S.has_motion || S.cam_xform != nullptr || S.has_area;
   for (int i = 0; i < desc->n_shaders; i++) {
     const fj_shader_desc &sh = desc->shaders[i];
+    if (sh.type == FJ_SHADER_PATHTRACING) sc->uses_sample_uid = true;
     auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
     int k = 0;
     if (sh.type == FJ_SHADER_PLASTIC) k = sh.do_reflect ? 1 : 0;
@@ -436,6 +439,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   fjgpu::SamplerMargin(*r, margin);
   const size_t full_tile_samples = (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
 
+  if (sc->uses_sample_uid && full_tile_samples > ((size_t) 1 << 20))
+    return fail(FJGPU_EUNSUPPORTED, "tiles of more than 2^20 samples (tilesize x pixelsamples) are not supported for scenes with "
+        "motion blur, area lights or PathtracingShader: their per-sample times and random streams are keyed by a 20-bit sample index");
   // Batch size.  The persistent traversal kernels pay a tail per launch (ray costs are
   // heavy tailed: the last waves finish long after the average one), so launches should be
   // few and large: about 80 M samples per batch -- half a 1080p / 64 spp frame, ~45 GB of

@@ -273,6 +273,14 @@ def test_unsupported_features_fail_loudly(asset_dir):
         gs.render_frame(rd)
     gs.close()
     assert "fixed grid sampler" in str(e.value)
+    # sample times are keyed by a 20-bit index inside the tile
+    sp, rd = prepare(workloads.motion(asset_dir, res=(640, 640), spp=(2, 2), mesh="tiny", kind="object",
+                                      extra=(("tilesize", (640, 640)),)))
+    gs = gpu.Scene(sp)
+    with pytest.raises(gpu.GpuError) as e:
+        gs.render_frame(rd)
+    gs.close()
+    assert "2^20 samples" in str(e.value)
     with pytest.raises(Exception) as e:
         prepare(base.replace("OpenPlugin plastic_shader PlasticShader.so", "OpenPlugin plastic_shader VolumeShader.so"))
     assert "no device implementation" in str(e.value) or "VolumeShader" in str(e.value)
