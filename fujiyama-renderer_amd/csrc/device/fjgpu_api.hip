@@ -457,6 +457,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
   bt = std::min<long>(bt, (long) ids.size());
+  bt = std::min<long>(bt, (long) (((size_t) 1 << 31) / full_tile_samples));   // sample slots are 32-bit
   if (bt < 1) bt = 1;
   const size_t cap_samples = full_tile_samples * (size_t) bt;
   // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
