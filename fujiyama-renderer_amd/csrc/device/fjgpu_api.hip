@@ -257,7 +257,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   e |= M.upload(dps.data(), dps.size(), &S.primsets);
   e |= M.upload(hs.instances.data(), hs.instances.size(), &S.instances);
   e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
-  e |= M.upload(hs.group_instances.data(), hs.group_instances.size(), &S.group_instances);
+  e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
   S.cam_xform = nullptr;

@@ -485,6 +485,63 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err, bool de
 
 int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err);   // fjgpu_curve_build.cc
 
+// Instance level of one group (replaces the reference's BVHAccelerator over ObjectInstances,
+// src/fj_bvh_accelerator.cc:79-107,253-334): object-median splits over the instances'
+// reference boxes, flattened depth first with skip links (DTNode).  Small groups stay a list.
+namespace {
+void emit_group_nodes(const std::vector<DInstance> &instances, std::vector<int> &m, int begin, int end, std::vector<DTNode> *out)
+{
+  const int n = end - begin;
+  if (n <= 4) {
+    for (int i = begin; i < end; i++) { DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = m[i]; leaf.skip = 0; out->push_back(leaf); }
+    return;
+  }
+  double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  double cmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, cmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (int i = begin; i < end; i++) {
+    const double *b = instances[m[i]].wbounds;
+    for (int k = 0; k < 3; k++) {
+      mn[k] = std::min(mn[k], b[k]); mx[k] = std::max(mx[k], b[3 + k]);
+      const double c = .5 * (b[k] + b[3 + k]);
+      cmn[k] = std::min(cmn[k], c); cmx[k] = std::max(cmx[k], c);
+    }
+  }
+  int axis = 0;
+  for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+  const int mid = begin + n / 2;
+  std::nth_element(m.begin() + begin, m.begin() + mid, m.begin() + end, [&](int a, int b) {
+    const double *ba = instances[a].wbounds, *bb = instances[b].wbounds;
+    return ba[axis] + ba[3 + axis] < bb[axis] + bb[3 + axis];
+  });
+  const size_t me = out->size();
+  DTNode inner;
+  std::memset(&inner, 0, sizeof(inner));
+  inner.inst = -1;
+  for (int k = 0; k < 3; k++) {
+    // widened: the walk tests inner boxes with approximate reciprocals (culling only)
+    const double pad = 1e-9 * (std::fabs(mn[k]) + std::fabs(mx[k])) + 1e-12;
+    inner.box[k] = mn[k] - pad; inner.box[3 + k] = mx[k] + pad;
+  }
+  out->push_back(inner);
+  // each half gets its own inner node only if it is worth one
+  for (int half = 0; half < 2; half++) {
+    const int b = half ? mid : begin, e = half ? end : mid;
+    emit_group_nodes(instances, m, b, e, out);
+  }
+  (*out)[me].skip = (int) out->size();
+}
+}  // namespace
+
+void BuildGroupNodes(const std::vector<DInstance> &instances, const std::vector<int> &members, std::vector<DTNode> *out)
+{
+  std::vector<int> m = members;
+  if (m.size() <= 8) {          // a plain list in group order: the walk is the linear scan
+    for (int inst : m) { DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = inst; out->push_back(leaf); }
+    return;
+  }
+  emit_group_nodes(instances, m, 0, (int) m.size(), out);
+}
+
 int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, bool device_mesh_build)
 {
   if (!d) { *err = "null scene description"; return FJGPU_EINVAL; }
@@ -573,18 +630,18 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, boo
   }
 
   out->groups.resize(d->n_groups);
-  out->group_instances.clear();
+  out->group_nodes.clear();
   for (int g = 0; g < d->n_groups; g++) {
     DGroup &G = out->groups[g];
-    G.first = (int) out->group_instances.size();
-    G.count = d->groups[g].n_instances;
+    G.first = (int) out->group_nodes.size();
+    G.n_instances = d->groups[g].n_instances;
     G.all_opaque = 1;
-    G.pad = 0;
     for (int k = 0; k < 6; k++) G.sbounds[k] = 0;
-    for (int k = 0; k < G.count; k++) {
+    std::vector<int> members;
+    for (int k = 0; k < G.n_instances; k++) {
       const int inst = d->groups[g].instances[k];
       if (inst < 0 || inst >= d->n_instances) { *err = "group instance index out of range"; return FJGPU_EINVAL; }
-      out->group_instances.push_back(inst);
+      members.push_back(inst);
       // occluder opacity: only PlasticShader has a settable Os (plastic_shader.cc:177-178)
       const DInstance &I = out->instances[inst];
       for (int s = 0; s < I.n_shaders && s < FJ_MAX_SHADING_GROUPS; s++) {
@@ -592,15 +649,15 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, boo
         if (sid >= 0 && d->shaders[sid].type == FJ_SHADER_PLASTIC && d->shaders[sid].opacity < 1.f) G.all_opaque = 0;
       }
     }
-  }
-  // Accelerator::ComputeBounds of a group: ObjectSet bounds + PADDING.  Only needed for
-  // single-instance groups, where the instance BVH's root is the leaf and the group box is
-  // the only world-space test the reference makes.
-  for (int g = 0; g < d->n_groups; g++) {
-    DGroup &G = out->groups[g];
-    if (G.count != 1) continue;
-    const DInstance &I = out->instances[out->group_instances[G.first]];
-    for (int k = 0; k < 3; k++) { G.sbounds[k] = I.wbounds[k] - ACC_PADDING; G.sbounds[3 + k] = I.wbounds[3 + k] + ACC_PADDING; }
+    BuildGroupNodes(out->instances, members, &out->group_nodes);
+    G.count = (int) out->group_nodes.size() - G.first;
+    // Accelerator::ComputeBounds of a group: ObjectSet bounds + PADDING.  Only needed for
+    // single-instance groups, where the instance BVH's root is the leaf and the group box is
+    // the only world-space test the reference makes.
+    if (G.n_instances == 1) {
+      const DInstance &I = out->instances[members[0]];
+      for (int k = 0; k < 3; k++) { G.sbounds[k] = I.wbounds[k] - ACC_PADDING; G.sbounds[3 + k] = I.wbounds[3 + k] + ACC_PADDING; }
+    }
   }
   if (d->target_group < 0 || d->target_group >= d->n_groups) { *err = "renderer target group out of range"; return FJGPU_EINVAL; }
   out->target_group = d->target_group;

@@ -48,7 +48,7 @@ struct HostScene {
   std::vector<HostPrimSet> primsets;          // meshes first, then curve sets
   std::vector<DInstance> instances;
   std::vector<DGroup> groups;
-  std::vector<int32_t> group_instances;
+  std::vector<DTNode> group_nodes;            // threaded instance BVH of every group (DGroup.first / count)
   std::vector<fj_shader_desc> shaders;
   std::vector<fj_xform_desc> xforms;          // time-sampled instance transforms (DInstance.xform)
   fj_xform_desc cam_xform;                    // valid when cam_static is false
@@ -66,6 +66,9 @@ struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
 void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float trav_cost);
 float RoundDown2(double v);   // f64 -> f32 toward -inf, one more ulp outward
 float RoundUp2(double v);
+
+// threaded instance BVH of one group, appended to *out (fjgpu_build.cc)
+void BuildGroupNodes(const std::vector<DInstance> &instances, const std::vector<int> &members, std::vector<DTNode> *out);
 
 // returns 0 or a negative FJGPU_E* code with *err set
 int BuildHostScene(const fj_scene_desc *desc, HostScene *out, std::string *err, bool device_mesh_build = false);

@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     XS xs = {0, 0, 0, 0};
     V3 Ps = mk(0, 0, 0), axis = Ps, nml_axis = Ps;
     int g_first = 0, g_count = 0;
+    bool g_single = false;
     const double *g_sbounds = nullptr;     // stays a global-memory pointer (a by-value DGroup lands in scratch)
     double cos_limit = 0;
     if (active) {
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
       W[0] = R.W[0]; W[1] = R.W[1]; W[2] = R.W[2];
       cos_limit = (!kHair || R.kind == 0) ? sp.cos_half_pi : sp.cos_pi;
       g_first = S.groups[R.group].first; g_count = S.groups[R.group].count;
+      g_single = S.groups[R.group].n_instances == 1;
       g_sbounds = S.groups[R.group].sbounds;
     }
     for (uint32_t it = 0; it < iters; it++) {
@@ -149,9 +151,16 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             if (!has_negative_zero(Ln)) {
               const V3 winv = mk(filter_rcp(Ln.x), filter_rcp(Ln.y), filter_rcp(Ln.z));
               const bool plain = plain_dir(Ln);
-              for (int gi = 0; gi < g_count; gi++) {
-                const DInstance *I = &S.instances[S.group_instances[g_first + gi]];
-                if (box_ray_ref_fast(g_count == 1 ? g_sbounds : I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
+              for (int ti = g_first; ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
+                const DTNode *tn_ = &S.group_nodes[ti];
+                if (tn_->inst < 0) {
+                  double tq;
+                  ti = slab(tn_->box, tn_->box + 3, Ps, winv, .0001, distance, &tq) ? ti + 1 : tn_->skip;
+                  continue;
+                }
+                ti++;
+                const DInstance *I = &S.instances[tn_->inst];
+                if (box_ray_ref_fast(g_single ? g_sbounds : I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
                 c_insts++;
               }
             }
@@ -394,10 +403,16 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
           const bool plain = plain_dir(d);
           const DGroup *G = &S.groups[q->group];
-          const bool single = G->count == 1;
+          const bool single = G->n_instances == 1;
           while (gi < gend) {
-            const DInstance *I = &S.instances[S.group_instances[gi]];
+            const DTNode *tn_ = &S.group_nodes[gi];
+            if (tn_->inst < 0) {           // inner node of the instance BVH
+              double tq;
+              gi = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? gi + 1 : tn_->skip;
+              continue;
+            }
             gi++;
+            const DInstance *I = &S.instances[tn_->inst];
             if (kCount) lc->insts++;
             if (!box_ray_ref_fast(single ? G->sbounds : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
             oo = xpoint(I->Minv, o);

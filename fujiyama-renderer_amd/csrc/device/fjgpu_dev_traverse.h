@@ -86,7 +86,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   double tmin = 0, tmax = 0, rtime = 0;
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
-  int gfirst = 0, gcount = 0, gi = 0, ii = -1;
+  int ti = 0, tend = 0, ii = -1;           // cursor in the group's threaded instance BVH
+  bool single = false;                     // the group has one instance (its padded box is the test)
   const double *gsb = nullptr;
   bool anyhit = false, dead_ray = false, plain = false;
   bool deep = false;                       // holding a curve whose ribbon test awaits its second stage
@@ -116,7 +117,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           if (kMotion) rtime = r.time;
           const DGroup G = S.groups[r.group];
-          gfirst = G.first; gcount = G.count; gi = 0;
+          ti = G.first; tend = G.first + G.count; single = G.n_instances == 1;
           gsb = S.groups[r.group].sbounds;
           best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
           cur = TRAV_DONE; sp = 0;
@@ -135,15 +136,21 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     // ---- lanes between instances: enter the next instance or retire the ray
     if (have && cur == TRAV_DONE) {
       bool found = false;
-      while (!dead_ray && gi < gcount) {
-        ii = S.group_instances[gfirst + gi];
-        gi++;
+      while (!dead_ray && ti < tend) {
+        const DTNode *tn_ = &S.group_nodes[ti];
+        if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
+          double tq;
+          ti = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? ti + 1 : tn_->skip;
+          continue;
+        }
+        ii = tn_->inst;
+        ti++;
         const DInstance *I = &S.instances[ii];
         if (kCount) lc->insts++;
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
         // the reference's own (possibly non-enclosing) instance box, full ray range
-        if (!box_ray_ref_fast(gcount == 1 ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+        if (!box_ray_ref_fast(single ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
         if (kMotion && I->xform >= 0) {
           // ObjectInstance::RayIntersect evaluates a time-sampled transform at the ray's time
           double tm[12], tmi[12];

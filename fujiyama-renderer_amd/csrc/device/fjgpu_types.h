@@ -80,10 +80,21 @@ struct DInstance {
   int32_t pad[2];
 };
 
+// Instance level of a group: a THREADED bounding-volume hierarchy (depth-first node list with
+// skip links, no stack).  Walk: i = first; a leaf (inst >= 0) is a candidate instance, go to
+// i + 1; an inner node whose box the ray misses jumps to `skip`, else go to i + 1.  Groups of
+// up to 8 instances are stored as a plain list of leaves in group order (the walk then is the
+// linear scan).  Inner boxes are unions of the instances' reference boxes, slightly widened.
+struct DTNode {
+  double box[6];               // inner nodes only
+  int32_t inst;                // instance index, or -1 for an inner node
+  int32_t skip;                // inner nodes: index of the node after this subtree
+};
+
 struct DGroup {
-  int32_t first, count;        // slice of the group-instance index array
+  int32_t first, count;        // slice of the DTNode array (count = nodes, not instances)
   int32_t all_opaque;          // every shader reachable in the group has Os == 1 -> any-hit shadows
-  int32_t pad;
+  int32_t n_instances;
   double sbounds[6];           // single-instance group: its instance's bounds + 1e-4 (the group accelerator's box)
 };
 
@@ -117,7 +128,7 @@ struct DScene {
   const DPrimSet *primsets;
   const DInstance *instances;
   const DGroup *groups;
-  const int32_t *group_instances;
+  const DTNode *group_nodes;
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;

@@ -7,6 +7,7 @@ object transforms, shader assignments, shadow groups, 32 point lights of
 intensity 1/32 at y = 12 -- but with the seeded synthetic assets of synth.py in
 place of the downloadable scans / HDR maps.
 """
+import math
 import os
 
 import numpy as np
@@ -263,6 +264,47 @@ def arealights(asset_dir, res=(640, 480), spp=(6, 6), mesh="small", kind="grid",
     return si.text()
 
 
+def crowd(asset_dir, res=(640, 480), spp=(3, 3), mesh="tiny", n=64, nlights=4, extra=()):
+    """Many instances of one mesh on a floor (n x-z grid positions, varied rotation and scale):
+    exercises the instance level -- the reference's BVH over ObjectInstances -- beyond the
+    3-18 instances of the shipped scenes."""
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    si = SceneInterface(parse_args=False)
+    si.OpenPlugin("plastic_shader", "PlasticShader")
+    si.OpenPlugin("constant_shader", "ConstantShader")
+    si.OpenPlugin("stanfordply_procedure", "StanfordPlyProcedure")
+    si.NewCamera("cam1", "PerspectiveCamera")
+    si.SetProperty3("cam1", "translate", 0, 6, 12)
+    si.SetProperty3("cam1", "rotate", -25, 0, 0)
+    point_lights(si, nlights)
+    si.NewShader("obj_shader0", "plastic_shader")
+    si.SetProperty3("obj_shader0", "diffuse", .7, .4, .2)
+    si.NewShader("obj_shader1", "plastic_shader")
+    si.SetProperty3("obj_shader1", "diffuse", .2, .5, .7)
+    si.SetProperty3("obj_shader1", "reflect", 0, 0, 0)
+    _ply(si, "obj_mesh", a[mesh])
+    side = int(math.ceil(math.sqrt(n)))
+    names = []
+    for k in range(n):
+        ix, iz = k % side, k // side
+        name = "obj%d" % k
+        si.NewObjectInstance(name, "obj_mesh")
+        sc = .25 + .15 * ((k * 7) % 5) / 4.
+        si.SetProperty3(name, "scale", sc, sc * (1.2 if k % 3 else .8), sc)
+        si.SetProperty3(name, "rotate", 0, (k * 37) % 360, (k * 11) % 30)
+        si.SetProperty3(name, "translate", (ix - .5 * (side - 1)) * 1.3, 0, (iz - .5 * (side - 1)) * 1.3)
+        si.AssignShader(name, "DEFAULT_SHADING_GROUP", "obj_shader%d" % (k % 2))
+        names.append(name)
+    _stage(si, a, dome_rotate=(0, 180, 0))
+    si.NewObjectGroup("group1")
+    for name in names:
+        si.AddObjectToGroup("group1", name)
+    for name in names + ["floor1"]:
+        si.AssignObjectGroup(name, "shadow_target", "group1")
+    _renderer(si, res, spp, extra)
+    return si.text()
+
+
 def furry(asset_dir, res=(1920, 1080), spp=(8, 8), mesh="furbunny", nlights=32, extra=(), hair=False):
     """C5: fur (cubic Bezier curves + HairShader) grown on a mesh by
     CurveGeneratorProcedure; plastic mesh and floor without reflection (furry_bunny.scn)."""
@@ -441,7 +483,7 @@ def cornell(asset_dir, res=(1920, 1080), spp=(16, 16), mesh="bunny", extra=(), o
 
 
 BUILDERS = {"teapot": teapot, "buddhas": buddhas, "dragon": dragon, "furry": furry, "ibl": ibl, "cornell": cornell,
-            "motion": motion, "arealights": arealights}
+            "motion": motion, "arealights": arealights, "crowd": crowd}
 
 
 def default_asset_dir():

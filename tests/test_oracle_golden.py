@@ -265,6 +265,8 @@ FRAME_CASES = {
     "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
     "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
     "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
+    "crowd_40_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=40)),
+    "crowd_150_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=150)),
     "c5_hair_vertex_velocity_64x48_2spp": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4, hair=True)),
     "motion_object_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="object")),
     "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
