@@ -7,9 +7,8 @@
 // Closest-hit results do not depend on the culling structure; the
 // triangle test itself is the reference's FP64 Moller-Trumbore.
 //
-// The instance level (BVHAccelerator over ObjectInstances, src/fj_object_group.cc:27)
-// has at most a few dozen entries and is kept as a flat per-group list with
-// world-space AABBs.
+// The instance level (BVHAccelerator over ObjectInstances, src/fj_object_group.cc:27) is a
+// threaded BVH per group (BuildGroupNodes): a plain list for the usual handful of instances.
 #include "fjgpu_build.h"
 #include "fjgpu_xform_math.h"
 #include "fjgpu.h"
