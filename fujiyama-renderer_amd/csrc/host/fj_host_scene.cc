@@ -237,6 +237,8 @@ static void renderer_defaults(Renderer *r)
   r->d.time_start = 0; r->d.time_end = 1;
   r->d.max_diffuse_depth = 3; r->d.max_reflect_depth = 3; r->d.max_refract_depth = 3;
   r->d.sampler_type = 0;
+  r->d.adaptive_max_subdivision = 1;
+  r->d.adaptive_subdivision_threshold = .05f;
   r->camera = r->framebuffer = -1;
   r->use_max_thread = true;
   r->thread_count = 8;
@@ -267,7 +269,9 @@ static int set_renderer_property(Renderer *r, const std::string &name, int n, co
     if (name == "raymarch_step" || name == "raymarch_shadow_step" || name == "raymarch_diffuse_step" ||
         name == "raymarch_reflect_step" || name == "raymarch_refract_step") return 0;   // volumes are out of scope
     if (name == "sampler_type") { const int t = (int) v[0]; d.sampler_type = (t == 0 || t == 1) ? t : 0; return 0; }
-    if (name == "adaptive_max_subdivision" || name == "adaptive_subdivision_threshold") return 0;
+    // Renderer::SetMaxSubdivision / SetSubdivisionThreshold (src/fj_renderer.cc:508-518; asserts there)
+    if (name == "adaptive_max_subdivision") { if ((int) v[0] < 0) return -1; d.adaptive_max_subdivision = (int) v[0]; return 0; }
+    if (name == "adaptive_subdivision_threshold") { if (v[0] < 0) return -1; d.adaptive_subdivision_threshold = (float) v[0]; return 0; }
     if (name == "use_max_thread") { r->use_max_thread = ((int) v[0]) != 0; return 0; }
     if (name == "thread_count") { r->thread_count = (int) v[0] < 1 ? 1 : (int) v[0]; return 0; }
   } else if (n == 2) {
@@ -898,7 +902,8 @@ const PropertyInfo *SiGetPropertyList(const char *type_name)
   static const PropertyInfo renderer_props[] = {
     {"sample_jitter", 1, {1}}, {"cast_shadow", 1, {1}}, {"max_diffuse_depth", 1, {3}}, {"max_reflect_depth", 1, {3}},
     {"max_refract_depth", 1, {3}}, {"sample_time_range", 2, {0, 1}}, {"resolution", 2, {320, 240}}, {"tilesize", 2, {32, 32}},
-    {"filterwidth", 2, {2, 2}}, {"sampler_type", 1, {0}}, {"pixelsamples", 2, {3, 3}}, {"render_region", 4, {0, 0, 320, 240}},
+    {"filterwidth", 2, {2, 2}}, {"sampler_type", 1, {0}}, {"adaptive_max_subdivision", 1, {1}},
+    {"adaptive_subdivision_threshold", 1, {.05}}, {"pixelsamples", 2, {3, 3}}, {"render_region", 4, {0, 0, 320, 240}},
     {"use_max_thread", 1, {1}}, {"thread_count", 1, {8}}, {nullptr, 0, {0}}};
   static const PropertyInfo object_props[] = {
     {"transform_order", 1, {0}}, {"rotate_order", 1, {10}}, {"translate", 3, {0, 0, 0}}, {"rotate", 3, {0, 0, 0}},

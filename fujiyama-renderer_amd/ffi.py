@@ -27,6 +27,8 @@ class RenderDesc(C.Structure):         # fj_render_desc
         ("time_start", C.c_double), ("time_end", C.c_double),
         ("max_diffuse_depth", C.c_int32), ("max_reflect_depth", C.c_int32), ("max_refract_depth", C.c_int32),
         ("sampler_type", C.c_int32),
+        ("adaptive_max_subdivision", C.c_int32), ("adaptive_subdivision_threshold", C.c_float),
+        ("_pad_render", C.c_int32),
     ]
 
     def copy(self):

@@ -179,7 +179,10 @@ typedef struct fj_render_desc {
   int32_t cast_shadow;
   double  time_start, time_end;  /* sample_time_range */
   int32_t max_diffuse_depth, max_reflect_depth, max_refract_depth;
-  int32_t sampler_type;          /* 0 fixed grid (only one supported) */
+  int32_t sampler_type;          /* 0 fixed grid, 1 adaptive grid (src/fj_renderer.cc:487-499) */
+  int32_t adaptive_max_subdivision;       /* Renderer::SetMaxSubdivision, default 1 */
+  float   adaptive_subdivision_threshold; /* Renderer::SetSubdivisionThreshold, default .05 */
+  int32_t _pad_render;
 } fj_render_desc;
 
 typedef struct fj_scene_desc {

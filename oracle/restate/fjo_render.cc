@@ -81,6 +81,128 @@ void GenerateSamples(const fj_render_desc &r, const Tile &tile, std::vector<Samp
     }
 }
 
+// =================================================== adaptive grid sampler (a5')
+// src/fj_adaptive_grid_sampler.cc.  Samples sit on the corners of a lattice of
+// 2^max_subdivision cells per pixel (so neighbouring cells share samples); the rectangles
+// of the lattice are taken from a LIFO stack, their four corners are traced if nothing has
+// written them yet, and the rectangle is either split in four (corner values differ by more
+// than the threshold in some channel) or filled by bilinear interpolation, overwriting
+// whatever its border samples held.
+struct AdaptiveGrid {
+  struct Rect { int x0, y0, x1, y1; };
+  std::vector<Sample> samples;
+  std::vector<signed char> state;      // subd_flag_: < 0 until traced or interpolated
+  std::vector<Rect> stack;
+  int nx = 0, ny = 0, div = 1, corner = 0;
+  int margin[2] = {0, 0};
+  double threshold = 0;
+
+  // count_samples_in_margin / compute_num_pixel_division / count_samples_in_region, :195-222
+  static void Counts(const fj_render_desc &r, int *div, int margin[2])
+  {
+    *div = static_cast<int>(std::pow(2, r.adaptive_max_subdivision));
+    margin[0] = static_cast<int>(std::ceil((double) r.filter_w - 1));
+    margin[1] = static_cast<int>(std::ceil((double) r.filter_h - 1));
+  }
+
+  void Generate(const fj_render_desc &r, const Tile &tile)         // generate_samples, :35-110
+  {
+    Counts(r, &div, margin);
+    threshold = (double) r.adaptive_subdivision_threshold;          // float member of the Renderer -> Real
+    const int tw = tile.xmax - tile.xmin + 2 * margin[0], th = tile.ymax - tile.ymin + 2 * margin[1];
+    nx = div * tw + 1;
+    ny = div * th + 1;
+    samples.assign(static_cast<size_t>(nx) * ny, Sample());
+    state.assign(samples.size(), -1);
+    XorShift rng, rng_time;
+    const double jitter = r.jitter;
+    const double udelta = 1. / (div * r.xres), vdelta = 1. / (div * r.yres);
+    const int xoffset = (tile.xmin - margin[0]) * div, yoffset = (tile.ymin - margin[1]) * div;
+    Sample *s = samples.data();
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++, s++) {
+        s->uv[0] = (x + xoffset) * udelta;                         // lattice corners: no half-cell offset
+        s->uv[1] = 1 - (y + yoffset) * vdelta;
+        if (jitter > 0) {
+          const double uj = rng.NextFloat01() * jitter;
+          const double vj = rng.NextFloat01() * jitter;
+          s->uv[0] += udelta * (uj - .5);
+          s->uv[1] += vdelta * (vj - .5);
+        }
+        s->time = Fit(rng_time.NextFloat01(), 0, 1, r.time_start, r.time_end);
+        s->data[0] = s->data[1] = s->data[2] = s->data[3] = 0;
+      }
+    stack.clear();
+    corner = 0;
+    for (int y = 0; y < th; y++)
+      for (int x = 0; x < tw; x++) stack.push_back(Rect{x * div, y * div, (x + 1) * div, (y + 1) * div});
+  }
+
+  size_t At(int x, int y) const { return static_cast<size_t>(y) * nx + x; }
+
+  // get_next_sample, :124-170: index of the next sample to trace, or -1 when the tile is done
+  long Next()
+  {
+    while (!stack.empty()) {
+      const Rect q = stack.back();
+      if (corner == 4) {
+        corner = 0;
+        stack.pop_back();
+        if (NeedsSplit(q)) Split(q); else Fill(q);
+        continue;
+      }
+      const int c = corner++;
+      const size_t k = At((c & 1) ? q.x1 : q.x0, (c & 2) ? q.y1 : q.y0);   // corner order: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+      if (state[k] < 0) { state[k] = 1; return (long) k; }
+    }
+    return -1;
+  }
+
+  bool NeedsSplit(const Rect &q) const                            // compare_corners, :224-262
+  {
+    if (q.x1 - q.x0 < 2 || q.y1 - q.y0 < 2) return false;
+    const double *d[4] = {samples[At(q.x0, q.y0)].data, samples[At(q.x1, q.y0)].data,
+                          samples[At(q.x0, q.y1)].data, samples[At(q.x1, q.y1)].data};
+    for (int c = 0; c < 4; c++) {
+      double lo = d[0][c], hi = d[0][c];
+      for (int i = 1; i < 4; i++) { lo = Min(lo, d[i][c]); hi = Max(hi, d[i][c]); }
+      if (hi - lo > threshold) return true;
+    }
+    return false;
+  }
+
+  void Split(const Rect &q)                                       // subdivide_rect, :264-302
+  {
+    const int xm = (q.x0 + q.x1) / 2, ym = (q.y0 + q.y1) / 2;
+    stack.push_back(Rect{q.x0, q.y0, xm, ym});
+    stack.push_back(Rect{xm, q.y0, q.x1, ym});
+    stack.push_back(Rect{q.x0, ym, xm, q.y1});
+    stack.push_back(Rect{xm, ym, q.x1, q.y1});
+  }
+
+  void Fill(const Rect &q)                                        // interpolate_rect, :304-330
+  {
+    double c00[4], c10[4], c01[4], c11[4];
+    for (int c = 0; c < 4; c++) {
+      c00[c] = samples[At(q.x0, q.y0)].data[c]; c10[c] = samples[At(q.x1, q.y0)].data[c];
+      c01[c] = samples[At(q.x0, q.y1)].data[c]; c11[c] = samples[At(q.x1, q.y1)].data[c];
+    }
+    for (int y = q.y0; y <= q.y1; y++) {
+      const double ty = 1. * (y - q.y0) / (q.y1 - q.y0);
+      for (int x = q.x0; x <= q.x1; x++) {
+        const double tx = 1. * (x - q.x0) / (q.x1 - q.x0);
+        const size_t k = At(x, y);
+        for (int c = 0; c < 4; c++) {
+          const double left = (1 - ty) * c00[c] + ty * c01[c];     // Lerp(Vector4), src/fj_vector.h:515-518
+          const double right = (1 - ty) * c10[c] + ty * c11[c];
+          samples[k].data[c] = (1 - tx) * left + tx * right;
+        }
+        if (state[k] < 0) state[k] = 0;
+      }
+    }
+  }
+};
+
 // ============================================================== camera (a7)
 // src/fj_camera.cc:79-110
 void CameraGetRay(const CameraState &cam, const double uv[2], double time, Ray *ray)
@@ -710,11 +832,12 @@ static int build_light_samples(Scene *sc)
 
 // ================================================================ tile loop
 static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraState &cam,
-    const Tile &tile, float *fb, std::vector<Sample> *samples)
+    const Tile &tile, float *fb, std::vector<Sample> *samples, AdaptiveGrid *grid)
 {
+  const bool adaptive = r.sampler_type == 1;
   int ns[2], margin[2];
-  GenerateSamples(r, tile, samples, ns);
-  SamplerMargin(r, margin);
+  if (adaptive) grid->Generate(r, tile);
+  else GenerateSamples(r, tile, samples, ns);
 
   // integrate_samples, src/fj_renderer.cc:1061-1096
   Cxt cxt;                                 // SlCameraContext + init_worker overrides
@@ -726,9 +849,8 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
   cxt.cast_shadow = r.cast_shadow;
   cxt.opacity_threshold = .995f;
   cxt.trace_target = rs->sc->d->target_group;
-  uint32_t sample_k = 0;
-  for (Sample &s : *samples) {
-    cxt.sample_uid = ((uint32_t) tile.id << 20) + sample_k++;
+  auto integrate = [&](Sample &s, uint32_t index_in_tile) {
+    cxt.sample_uid = ((uint32_t) tile.id << 20) + index_in_tile;
     cxt.path_key = 0;
     Ray ray;
     CameraGetRay(cam, s.uv, s.time, &ray);
@@ -738,14 +860,31 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
     const int hit = SlTrace(rs, cxt, ray.orig, ray.dir, ray.tmin, ray.tmax, &C, &t_hit);
     if (hit) { s.data[0] = C.r; s.data[1] = C.g; s.data[2] = C.b; s.data[3] = C.a; }
     else { s.data[0] = s.data[1] = s.data[2] = s.data[3] = 0; }
+  };
+  // window of one pixel in the sample array: get_sampleset_in_pixel of either sampler
+  int npx[2], step[2];
+  const Sample *all;
+  if (adaptive) {
+    for (long k; (k = grid->Next()) >= 0; ) integrate(grid->samples[(size_t) k], (uint32_t) k);
+    ns[0] = grid->nx; ns[1] = grid->ny;
+    step[0] = step[1] = grid->div;         // src/fj_adaptive_grid_sampler.cc:172-193,210-213
+    npx[0] = grid->div * (1 + 2 * grid->margin[0]) + 1;
+    npx[1] = grid->div * (1 + 2 * grid->margin[1]) + 1;
+    all = grid->samples.data();
+  } else {
+    uint32_t sample_k = 0;
+    for (Sample &s : *samples) integrate(s, sample_k++);
+    SamplerMargin(r, margin);
+    step[0] = r.rate_x; step[1] = r.rate_y;
+    npx[0] = r.rate_x + 2 * margin[0]; npx[1] = r.rate_y + 2 * margin[1];
+    all = samples->data();
   }
 
   // reconstruct_image + apply_pixel_filter, src/fj_renderer.cc:939-995
-  const int npx[2] = {r.rate_x + 2 * margin[0], r.rate_y + 2 * margin[1]};
   const double fw = (double) r.filter_w, fh = (double) r.filter_h;
   for (int y = tile.ymin; y < tile.ymax; y++)
     for (int x = tile.xmin; x < tile.xmax; x++) {
-      const Sample *src = samples->data() + static_cast<size_t>(y - tile.ymin) * r.rate_y * ns[0] + (x - tile.xmin) * r.rate_x;
+      const Sample *src = all + static_cast<size_t>(y - tile.ymin) * step[1] * ns[0] + (x - tile.xmin) * step[0];
       float px[4] = {0, 0, 0, 0};
       float wgt_sum = 0.f;
       for (int sy = 0; sy < npx[1]; sy++)
@@ -769,7 +908,8 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
 int RenderTiles(Scene *sc, const fj_render_desc &r, const int32_t *tile_ids, int n_tiles,
     float *fb, int nthreads, fj_ray_counts *counts_out)
 {
-  if (r.sampler_type != 0) return -2;
+  if (r.sampler_type != 0 && r.sampler_type != 1) return -2;
+  if (r.sampler_type == 1 && (r.adaptive_max_subdivision < 0 || r.adaptive_max_subdivision > 8)) return -2;
   if (build_light_samples(sc)) return -3;
   std::vector<Tile> tiles;
   GenerateTiles(r, &tiles);
@@ -791,10 +931,11 @@ int RenderTiles(Scene *sc, const fj_render_desc &r, const int32_t *tile_ids, int
     rs.cos_half_pi = std::cos(PI / 2.);
     rs.cos_pi = std::cos(PI);
     std::vector<Sample> samples;
+    AdaptiveGrid grid;
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= ids.size()) break;
-      render_tile(&rs, r, cam, tiles[ids[k]], fb, &samples);
+      render_tile(&rs, r, cam, tiles[ids[k]], fb, &samples, &grid);
     }
     counts[tid] = rs.counts;
   };

@@ -15,6 +15,7 @@ import pytest
 
 import golden_io
 import oracle_ffi
+from frame_cases import FRAMES as FRAME_CASES
 from fujiyama_renderer_amd import ffi, gpu, host, workloads
 
 pytestmark = pytest.mark.timeout(600) if hasattr(pytest.mark, "timeout") else []
@@ -256,28 +257,6 @@ def test_grid_accelerator_mesh_trace(vec, golden_dir, asset_dir):
     n_ref = n_ref * (1. / np.sqrt((n_ref * n_ref).sum(1)))[:, None]
     assert np.allclose(attr[hit, :3], n_ref, rtol=0, atol=1e-15)
     assert np.array_equal(attr[hit, 5:8], vec["grid_attr"][hit, 3:6])
-
-
-FRAME_CASES = {
-    "c1_teapot_256_1spp": ("teapot", dict(res=(256, 256), spp=(1, 1))),
-    "teapot_64_2spp": ("teapot", dict(res=(64, 64), spp=(2, 2))),
-    "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
-    "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
-    "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
-    "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
-    "crowd_40_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=40)),
-    "crowd_150_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=150)),
-    "c5_hair_vertex_velocity_64x48_2spp": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4, hair=True)),
-    "motion_object_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="object")),
-    "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
-    "motion_both_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
-    "motion_scale_3samples_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="scale")),
-    "motion_vertex_velocity_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="velocity")),
-    "motion_velocity_and_object_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="velocity+object")),
-    "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
-                                  extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
-                                         ("filterwidth", (3, 2.5))))),
-}
 
 
 @pytest.mark.parametrize("name", sorted(FRAME_CASES))
