@@ -74,6 +74,11 @@ struct fjgpu_scene {
   size_t work_samples, work_rays;
   double *d_suv;
   float *d_accum;
+  // adaptive grid sampler (allocated on first use, in the `work` arena)
+  double *d_aseen = nullptr, *d_afinal = nullptr;
+  uint8_t *d_apstate = nullptr, *d_acells = nullptr;
+  const void *a_owner = nullptr;
+  size_t a_samples = 0, a_cell_bytes = 0;
   struct Level { DRay *rays; DPath *paths; size_t cap; };
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   int max_children;                // most child rays one shading event can emit in this scene
@@ -402,6 +407,20 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
   return 0;
 }
 
+// AdaptiveGridSampler buffers: per sample the value its users see when it holds an earlier
+// leaf's interpolation, the final (filtered) value, a state byte; per lattice cell a verdict
+int ensure_adaptive(fjgpu_scene *sc, size_t samples, size_t cell_bytes)
+{
+  // (the work buffers were just sized by ensure_work: these live in the same arena, which is
+  // replaced as a whole when it grows)
+  if (sc->a_owner == sc->work.get() && samples <= sc->a_samples && cell_bytes <= sc->a_cell_bytes) return 0;
+  DeviceBuffers &W = *sc->work;
+  if (W.alloc(samples * 4, &sc->d_aseen) || W.alloc(samples * 4, &sc->d_afinal) || W.alloc(samples, &sc->d_apstate) ||
+      W.alloc(cell_bytes, &sc->d_acells)) { sc->a_owner = nullptr; return -1; }
+  sc->a_owner = sc->work.get(); sc->a_samples = samples; sc->a_cell_bytes = cell_bytes;
+  return 0;
+}
+
 int ensure_level(fjgpu_scene *sc, int level, size_t cap)
 {
   fjgpu_scene::Level &L = sc->levels[level];
@@ -422,7 +441,10 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     float *d_fb, void *hip_stream, fjgpu_stats *stats)
 {
   if (!sc || !r || !d_fb) return fail(FJGPU_EINVAL, "null argument");
-  if (r->sampler_type != 0) return fail(FJGPU_EUNSUPPORTED, "only the fixed grid sampler is on the device path");
+  const bool adaptive = r->sampler_type == 1;          // Renderer::SetSamplerType, src/fj_renderer.cc:487-499
+  if (r->sampler_type != 0 && !adaptive) return fail(FJGPU_EINVAL, "unknown sampler_type");
+  if (adaptive && (r->adaptive_max_subdivision < 0 || r->adaptive_max_subdivision > 8 || !(r->adaptive_subdivision_threshold >= 0)))
+    return fail(FJGPU_EINVAL, "adaptive_max_subdivision must be in [0, 8] and adaptive_subdivision_threshold >= 0");
   if (r->xres <= 0 || r->yres <= 0 || r->tile_w <= 0 || r->tile_h <= 0 || r->rate_x <= 0 || r->rate_y <= 0)
     return fail(FJGPU_EINVAL, "bad render settings");
   HIP_TRY(hipSetDevice(sc->device));
@@ -435,9 +457,19 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   else for (size_t i = 0; i < all.size(); i++) ids.push_back((int) i);
   for (int id : ids) if (id < 0 || id >= (int) all.size()) return fail(FJGPU_EINVAL, "tile id out of range");
 
+  // samples of a tile: rate x rate per pixel plus the filter margin (fixed grid), or the
+  // corners of a lattice of 2^max_subdivision cells per pixel, margin in whole pixels (adaptive
+  // grid: count_samples_in_region / count_samples_in_margin, src/fj_adaptive_grid_sampler.cc:195-216)
   int margin[2];
   fjgpu::SamplerMargin(*r, margin);
-  const size_t full_tile_samples = (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
+  const int a_div = adaptive ? 1 << r->adaptive_max_subdivision : 1;
+  if (adaptive) {
+    margin[0] = (int) std::ceil((double) r->filter_w - 1);
+    margin[1] = (int) std::ceil((double) r->filter_h - 1);
+  }
+  const size_t full_tile_samples = adaptive
+      ? (size_t) (a_div * (r->tile_w + 2 * margin[0]) + 1) * (size_t) (a_div * (r->tile_h + 2 * margin[1]) + 1)
+      : (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
 
   if (sc->uses_sample_uid && full_tile_samples > ((size_t) 1 << 20))
     return fail(FJGPU_EUNSUPPORTED, "tiles of more than 2^20 samples (tilesize x pixelsamples) are not supported for scenes with "
@@ -452,7 +484,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
   long bt = sc->batch_tiles;
   if (bt <= 0) {
-    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec);
+    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
     const size_t target = std::min<size_t>((size_t) 80 << 20, (size_t) (.4 * (double) free_now) / per_sample);
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
@@ -474,6 +506,12 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   }
   if (ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) || ensure_level(sc, 0, cap_rays))
     return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
+  // adaptive grid: split / leaf byte per lattice cell of every level (4/3 of the finest level)
+  const size_t a_cells0_cap = adaptive ? (size_t) bt * (size_t) (r->tile_w + 2 * margin[0]) * (size_t) (r->tile_h + 2 * margin[1]) : 0;
+  const size_t a_cell_bytes = a_cells0_cap * (((((size_t) 1) << (2 * (r->adaptive_max_subdivision + 1))) - 1) / 3);
+  if (adaptive && a_cells0_cap >= ((size_t) 1 << 32)) return fail(FJGPU_EINVAL, "too many lattice cells per batch: lower the batch_tiles option");
+  if (adaptive && ensure_adaptive(sc, cap_samples, a_cell_bytes))
+    return fail(FJGPU_ENOMEM, "device allocation failed for the adaptive sampler's buffers");
 
   // camera (Renderer::preprocess_camera + Camera::compute_uv_size)
   DScene S = sc->S;
@@ -505,6 +543,22 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   ResolveParams rp;
   rp.xres = r->xres; rp.yres = r->yres; rp.rate_x = r->rate_x; rp.rate_y = r->rate_y;
   rp.npx_x = r->rate_x + 2 * margin[0]; rp.npx_y = r->rate_y + 2 * margin[1];
+  AdaptiveParams ap;
+  std::memset(&ap, 0, sizeof(ap));
+  if (adaptive) {
+    ap.D = r->adaptive_max_subdivision; ap.div = a_div;
+    ap.margin_x = margin[0]; ap.margin_y = margin[1];
+    ap.udelta = 1. / (a_div * r->xres);
+    ap.vdelta = 1. / (a_div * r->yres);
+    ap.jitter = r->jitter;
+    ap.jittered = r->jitter > 0 ? 1 : 0;
+    ap.threshold = (double) r->adaptive_subdivision_threshold;
+    ap.ray_capacity = (uint32_t) cap_rays;
+    // get_sampleset_in_pixel (src/fj_adaptive_grid_sampler.cc:172-193): a pixel's window starts
+    // div samples after its neighbour's and is div * (1 + 2 margin) + 1 samples wide
+    rp.rate_x = rp.rate_y = a_div;
+    rp.npx_x = a_div * (1 + 2 * margin[0]) + 1; rp.npx_y = a_div * (1 + 2 * margin[1]) + 1;
+  }
   rp.fw = (double) r->filter_w; rp.fh = (double) r->filter_h;
 
   fjgpu_stats acc;
@@ -544,14 +598,21 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   for (size_t b0 = 0; b0 < ids.size() && rc == 0; b0 += (size_t) bt) {
     const int nb = (int) std::min<size_t>((size_t) bt, ids.size() - b0);
     std::vector<TileDesc> td(nb);
-    uint32_t off = 0, max_ts = 0;
-    int max_px = 0;
+    uint32_t off = 0, max_ts = 0, cell_off = 0;
+    int max_px = 0, max_w0 = 0, max_h0 = 0;
     for (int k = 0; k < nb; k++) {
       const fjgpu::TileRect &t = all[ids[b0 + k]];
       TileDesc &d = td[k];
       d.xmin = t.xmin; d.ymin = t.ymin; d.xmax = t.xmax; d.ymax = t.ymax; d.id = t.id;
       d.nx = r->rate_x * (t.xmax - t.xmin) + 2 * margin[0];
       d.ny = r->rate_y * (t.ymax - t.ymin) + 2 * margin[1];
+      d.cell_offset = cell_off; d.pad = 0;
+      if (adaptive) {
+        const int w0 = t.xmax - t.xmin + 2 * margin[0], h0 = t.ymax - t.ymin + 2 * margin[1];
+        d.nx = a_div * w0 + 1; d.ny = a_div * h0 + 1;
+        cell_off += (uint32_t) w0 * (uint32_t) h0;
+        max_w0 = std::max(max_w0, w0); max_h0 = std::max(max_h0, h0);
+      }
       d.sample_offset = off;
       off += (uint32_t) d.nx * (uint32_t) d.ny;
       max_ts = std::max(max_ts, (uint32_t) d.nx * (uint32_t) d.ny);
@@ -562,11 +623,13 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     (void) hipMemsetAsync(sc->d_accum, 0, sizeof(float) * 4 * (size_t) n_samples, st);
     (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
 
-    rc = timed(st, &acc.gen_ms, [&]() {
-      return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->levels[0].rays, sc->levels[0].paths);
-    });
-    if (rc) break;
-    acc.rays.camera += n_samples;
+    if (!adaptive) {
+      rc = timed(st, &acc.gen_ms, [&]() {
+        return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->levels[0].rays, sc->levels[0].paths);
+      });
+      if (rc) break;
+      acc.rays.camera += n_samples;
+    }
 
     // Depth-first wavefront schedule: the rays of one recursion level live in that
     // level's queue; a level is consumed in chunks small enough that the children a
@@ -664,15 +727,58 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
       }
       return 0;
     };
-    rc = process(0, n_samples);
-    if (rc) break;
-
-    // the filter needs every shadow contribution of the batch
-    { DScene Sf = S; Sf.lrec_hair = nullptr; rc = flush_shadow(Sf); if (rc) break;
-      if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[0], sst); shadow_pending[0] = true; } }
-    for (int k = 0; k < 2; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
+    // the filter (and the adaptive sampler's decisions) need every shadow contribution so far
+    auto finish_shadow = [&]() -> int {
+      DScene Sf = S; Sf.lrec_hair = nullptr;
+      const int fe = flush_shadow(Sf);
+      if (fe) return fe;
+      if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[0], sst); shadow_pending[0] = true; }
+      for (int k = 0; k < 2; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
+      return 0;
+    };
+    if (!adaptive) {
+      rc = process(0, n_samples);
+      if (rc) break;
+      rc = finish_shadow();
+      if (rc) break;
+    } else {
+      // AdaptiveGridSampler level by level (fjgpu_dev_adaptive.h): points -> wavefront -> decisions
+      ap.cells0 = cell_off;
+      (void) hipMemsetAsync(sc->d_apstate, 0, (size_t) n_samples, st);
+      (void) hipMemsetAsync(sc->d_acells, 0, (size_t) cell_off * (((((size_t) 1) << (2 * (ap.D + 1))) - 1) / 3), st);
+      rc = timed(st, &acc.gen_ms, [&]() { return launch_adaptive_uv(st, ap, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_suv); });
+      for (int level = 0; level <= ap.D && rc == 0; level++) {
+        ap.level = level;
+        (void) hipMemsetAsync(&sc->d_cnt->cam_count, 0, sizeof(uint32_t), st);
+        const uint32_t max_pts = (uint32_t) ((max_w0 << level) + 1) * (uint32_t) ((max_h0 << level) + 1);
+        rc = timed(st, &acc.gen_ms, [&]() {
+          return launch_adaptive_points(st, S, ap, sc->d_tiles, nb, max_pts, sc->d_acells, sc->d_suv, sc->d_accum, sc->d_apstate,
+              sc->d_aseen, sc->levels[0].rays, sc->levels[0].paths, sc->d_cnt);
+        });
+        if (rc) break;
+        DCounters hc;
+        if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
+        if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "camera ray queue overflow in the adaptive sampler"); break; }
+        acc.rays.camera += hc.cam_count;
+        if (hc.cam_count) {
+          rc = process(0, hc.cam_count);
+          if (rc) break;
+          rc = finish_shadow();
+          if (rc) break;
+        }
+        rc = timed(st, &acc.resolve_ms, [&]() {
+          return launch_adaptive_decide(st, ap, sc->d_tiles, nb, (uint32_t) (max_w0 << level) * (uint32_t) (max_h0 << level),
+              sc->d_acells, sc->d_accum, sc->d_apstate, sc->d_aseen);
+        });
+      }
+      if (rc) break;
+      rc = timed(st, &acc.resolve_ms, [&]() {
+        return launch_adaptive_fill(st, ap, sc->d_tiles, nb, max_ts, sc->d_acells, sc->d_accum, sc->d_apstate, sc->d_aseen, sc->d_afinal);
+      });
+      if (rc) break;
+    }
     rc = timed(st, &acc.resolve_ms, [&]() {
-      return launch_resolve(st, rp, sc->d_tiles, nb, max_px, sc->d_suv, sc->d_accum, d_fb);
+      return launch_resolve(st, rp, sc->d_tiles, nb, max_px, sc->d_suv, sc->d_accum, adaptive ? sc->d_afinal : nullptr, d_fb);
     });
     if (rc) break;
     DCounters hc;

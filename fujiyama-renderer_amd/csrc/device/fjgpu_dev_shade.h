@@ -4,6 +4,36 @@
 #ifndef FJGPU_DEV_SHADE_H
 #define FJGPU_DEV_SHADE_H
 
+// Camera::GetRay (src/fj_camera.cc:79-110): a time-sampled camera is evaluated at the
+// sample's time, a static one uses the host-built matrix.  k = index of the sample in its
+// tile (time stream, sample uid), slot = its place in the batch's sample arrays.
+template <bool kMovingCamera>
+__device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, int32_t tile_id, uint32_t k, uint32_t slot,
+    DRay *ray_out, DPath *path_out)
+{
+  const double *cam = S.cam_M;
+  double cm[12], cmi[12];
+  if (kMovingCamera) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
+  const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
+  const V3 tw = xpoint(cam, target);
+  const V3 eye = mk(cam[3], cam[7], cam[11]);
+  const V3 dir = normalize(tw - eye);
+
+  DRay r;
+  r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
+  r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
+  r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
+  *ray_out = r;
+  DPath p;
+  p.sample = slot;
+  p.T[0] = p.T[1] = p.T[2] = 1.f;
+  p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
+  p.group = S.target_group;
+  p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
+  p.flags = 0; p.rng = 0; p.uid = ((uint32_t) tile_id << 20) + k;
+  *path_out = p;
+}
+
 // --------------------------------------------------------------- k_gen_camera
 // FixedGridSampler::generate_samples (src/fj_fixed_grid_sampler.cc:33-84) with the
 // per-tile XorShift streams read from host-built tables (the stream restarts
@@ -34,29 +64,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   s_uv[2 * (size_t) slot + 1] = v;
   (void) time_tab;   // (the same table as S.time_tab)
 
-  // Camera::GetRay (src/fj_camera.cc:79-110): a time-sampled camera is evaluated at the
-  // sample's time, a static one uses the host-built matrix
-  const double *cam = S.cam_M;
-  double cm[12], cmi[12];
-  if (kMovingCamera) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
-  const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
-  const V3 tw = xpoint(cam, target);
-  const V3 eye = mk(cam[3], cam[7], cam[11]);
-  const V3 dir = normalize(tw - eye);
-
-  DRay r;
-  r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
-  r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
-  r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
-  rays[slot] = r;
-  DPath p;
-  p.sample = slot;
-  p.T[0] = p.T[1] = p.T[2] = 1.f;
-  p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
-  p.group = S.target_group;
-  p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
-  p.flags = 0; p.rng = 0; p.uid = ((uint32_t) T.id << 20) + k;
-  paths[slot] = p;
+  camera_ray<kMovingCamera>(S, u, v, T.id, k, slot, rays + slot, paths + slot);
 }
 
 // -------------------------------------------------------------------- shading

@@ -10,12 +10,23 @@ struct TileDesc {              // one tile of the current batch
   int32_t nx, ny;              // samples incl. filter margin: rate * size + 2 * margin
   uint32_t sample_offset;      // first sample slot of this tile in the batch arrays
   int32_t id;
+  uint32_t cell_offset;        // adaptive sampler: first level-0 lattice cell of this tile in the batch
+  int32_t pad;
 };
 
 struct GenParams {
   int32_t rate_x, rate_y, margin_x, margin_y;
   double udelta, vdelta, jitter;
   int32_t jittered, pad;
+};
+
+struct AdaptiveParams {       // AdaptiveGridSampler, src/fj_adaptive_grid_sampler.cc
+  int32_t D, div;              // adaptive_max_subdivision, 2^D lattice cells per pixel
+  int32_t margin_x, margin_y;  // filter margin in PIXELS: ceil(filterwidth - 1)
+  double udelta, vdelta, jitter, threshold;
+  int32_t jittered, level;
+  uint32_t cells0;             // level-0 lattice cells of the whole batch
+  uint32_t ray_capacity;
 };
 
 struct ShadeParams {
@@ -50,7 +61,19 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 // threads of the largest persistent grid (sizes per-thread scratch such as the stack overflow area)
 size_t persistent_threads();
 
+// sample values: f32 RGBA as accumulated (fixed grid) or f64 RGBA (adaptive grid: interpolated samples)
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
-    const double *s_uv, const float *s_accum, float *fb);
+    const double *s_uv, const float *s_accum, const double *s_data64, float *fb);
+
+// adaptive grid sampler (fjgpu_dev_adaptive.h)
+int launch_adaptive_uv(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_samples,
+    const double *jit, double *s_uv);
+int launch_adaptive_points(hipStream_t st, const DScene &S, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles,
+    uint32_t max_tile_points, const uint8_t *cells, const double *s_uv, const float *s_accum, uint8_t *pstate, double *seen,
+    DRay *rays, DPath *paths, DCounters *cnt);
+int launch_adaptive_decide(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_cells,
+    uint8_t *cells, const float *s_accum, const uint8_t *pstate, const double *seen);
+int launch_adaptive_fill(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_samples,
+    const uint8_t *cells, const float *s_accum, const uint8_t *pstate, const double *seen, double *final_data);
 
 #endif

@@ -31,6 +31,7 @@
 #include "fjgpu_dev_traverse.h"
 #include "fjgpu_dev_shade.h"
 #include "fjgpu_dev_shadow.h"
+#include "fjgpu_dev_adaptive.h"
 
 // ------------------------------------------------------------------ k_resolve
 // reconstruct_image + apply_pixel_filter (src/fj_renderer.cc:939-995) with
@@ -41,8 +42,9 @@
 // requests, this one is bandwidth bound).  The weighted sums are reduced in f64 by a
 // butterfly and rounded to f32 once; the reference adds the same f64 products into f32
 // accumulators one by one -- the difference is the accumulators' rounding (~1e-7).
+template <typename TData4>       // float4: samples as traced; double4: the adaptive sampler's interpolated samples
 __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileDesc *tiles,
-    const double *s_uv, const float *s_accum, float *fb)
+    const double *s_uv, const TData4 *s_data, float *fb)
 {
   const TileDesc T = tiles[blockIdx.y];
   const int tw = T.xmax - T.xmin, th = T.ymax - T.ymin;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileD
     const int sy = w / rp.npx_x, sx = w - sy * rp.npx_x;
     const size_t s = base + (size_t) sy * T.nx + sx;
     const double2 uv = reinterpret_cast<const double2 *>(s_uv)[s];
-    const float4 d = reinterpret_cast<const float4 *>(s_accum)[s];
+    const TData4 d = s_data[s];
     const double filtx = rp.xres * uv.x - (px + .5);
     const double filty = rp.yres * (1 - uv.y) - (py + .5);
     const double xx = 2 * filtx / rp.fw;
@@ -211,14 +213,52 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 }
 
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,
-    const double *s_uv, const float *s_accum, float *fb)
+    const double *s_uv, const float *s_accum, const double *s_data64, float *fb)
 {
-  dim3 grid((max_tile_pixels + (BLOCK / 64) - 1) / (BLOCK / 64), n_tiles);   // one wave per pixel
-  hipLaunchKernelGGL(k_resolve, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, s_accum, fb);
+  const dim3 grid((max_tile_pixels + BLOCK / 64 - 1) / (BLOCK / 64), n_tiles);
+  if (s_data64)
+    hipLaunchKernelGGL(k_resolve<double4>, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, reinterpret_cast<const double4 *>(s_data64), fb);
+  else
+    hipLaunchKernelGGL(k_resolve<float4>, grid, dim3(BLOCK), 0, st, rp, d_tiles, s_uv, reinterpret_cast<const float4 *>(s_accum), fb);
   LAUNCH_CHECK();
-#ifdef FJ_EXP_SLAB_VALIDATE
-  { unsigned long long v[3] = {0, 0, 0}; (void) hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_slab_lost), 8); (void) hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_slab_extra), 8); (void) hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(g_slab_tests), 8);
-    fprintf(stderr, "slab32 validate: lost %llu extra %llu of %llu box tests\n", v[0], v[1], v[2]); }
-#endif
+  return 0;
+}
+
+int launch_adaptive_uv(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_samples,
+    const double *jit, double *s_uv)
+{
+  hipLaunchKernelGGL(k_adaptive_uv, dim3((max_tile_samples + BLOCK - 1) / BLOCK, n_tiles), dim3(BLOCK), 0, st, ap, d_tiles, jit, s_uv);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adaptive_points(hipStream_t st, const DScene &S, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles,
+    uint32_t max_tile_points, const uint8_t *cells, const double *s_uv, const float *s_accum, uint8_t *pstate, double *seen,
+    DRay *rays, DPath *paths, DCounters *cnt)
+{
+  const dim3 grid((max_tile_points + BLOCK - 1) / BLOCK, n_tiles);
+  if (S.cam_xform)
+    hipLaunchKernelGGL(k_adaptive_points<true>, grid, dim3(BLOCK), 0, st, S, ap, d_tiles, cells, s_uv, s_accum, pstate, seen, rays, paths, cnt);
+  else
+    hipLaunchKernelGGL(k_adaptive_points<false>, grid, dim3(BLOCK), 0, st, S, ap, d_tiles, cells, s_uv, s_accum, pstate, seen, rays, paths, cnt);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adaptive_decide(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_cells,
+    uint8_t *cells, const float *s_accum, const uint8_t *pstate, const double *seen)
+{
+  hipLaunchKernelGGL(k_adaptive_decide, dim3((max_tile_cells + BLOCK - 1) / BLOCK, n_tiles), dim3(BLOCK), 0, st, ap, d_tiles, cells,
+      s_accum, pstate, seen);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adaptive_fill(hipStream_t st, const AdaptiveParams &ap, const TileDesc *d_tiles, int n_tiles, uint32_t max_tile_samples,
+    const uint8_t *cells, const float *s_accum, const uint8_t *pstate, const double *seen, double *final_data)
+{
+  hipLaunchKernelGGL(k_adaptive_fill, dim3((max_tile_samples + BLOCK - 1) / BLOCK, n_tiles), dim3(BLOCK), 0, st, ap, d_tiles, cells,
+      s_accum, pstate, seen, final_data);
+  LAUNCH_CHECK();
   return 0;
 }

@@ -214,7 +214,8 @@ struct DCounters {
   uint32_t shadow_count;       // slots reserved in the shadow-ray queue
   uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
   uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (path stream)
-  uint32_t pad_[2];
+  uint32_t cam_count;          // adaptive sampler: camera rays queued by the current level
+  uint32_t pad_;
 };
 
 #endif

@@ -49,26 +49,7 @@ def render_both(text, threads=None):
     return fb, st, ref, rc
 
 
-CASES = {
-    "c1_teapot_256_1spp": ("teapot", dict(res=(256, 256), spp=(1, 1))),
-    "teapot_64_2spp": ("teapot", dict(res=(64, 64), spp=(2, 2))),
-    "c2_buddhas_96x54_2spp_bunny": ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
-    "c3_dragon_96x54_3spp_small": ("dragon", dict(res=(96, 54), spp=(3, 3), mesh="small")),
-    "c5_furry_64x48_2spp_furball": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),
-    "c6_ibl_dome_light_64x48_2spp": ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48)),
-    "crowd_40_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=40)),
-    "crowd_150_instances_64x48_2spp": ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=150)),
-    "c5_hair_vertex_velocity_64x48_2spp": ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4, hair=True)),
-    "motion_object_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="object")),
-    "motion_camera_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="camera")),
-    "motion_both_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
-    "motion_scale_3samples_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="scale")),
-    "motion_vertex_velocity_64x48_3spp": ("motion", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="velocity")),
-    "motion_velocity_and_object_64x48_2spp": ("motion", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="velocity+object")),
-    "dragon_region_tilesize16": ("dragon", dict(res=(80, 48), spp=(2, 2), mesh="tiny",
-                                  extra=(("tilesize", (16, 16)), ("render_region", (16, 16, 64, 48)),
-                                         ("filterwidth", (3, 2.5))))),
-}
+from frame_cases import FRAMES as CASES  # noqa: E402  (incl. the adaptive grid sampler's frames)
 
 
 @pytest.mark.parametrize("kw", [dict(res=(64, 48), spp=(3, 3), mesh="tiny"),
@@ -180,6 +161,64 @@ def test_curve_trace_bit_exact_against_oracle(asset_dir):
     osc.close()
 
 
+ADAPTIVE = (("sampler_type", (1,)), ("adaptive_max_subdivision", (2,)), ("adaptive_subdivision_threshold", (.03,)))
+
+
+@pytest.mark.parametrize("builder,kw", [
+    ("cornell", dict(res=(48, 32), spp=(2, 2), mesh="tiny", extra=ADAPTIVE)),
+    ("arealights", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="both", extra=ADAPTIVE)),
+    ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4, extra=ADAPTIVE)),
+    ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48, extra=ADAPTIVE)),
+], ids=["pathtracing", "area_lights", "curves", "dome_light"])
+def test_adaptive_sampler_with_every_shading_path(builder, kw, asset_dir):
+    """AdaptiveGridSampler (sampler_type 1) as a level-synchronous wavefront: the same samples
+    are traced as by the reference's stack walk (camera-ray counts equal the oracle's, whose
+    walk is pinned bit-exactly against the reference), the same pixels come out.  Here with
+    the shading paths whose random streams are keyed by the sample's index in its tile."""
+    fb, st, ref, rc = render_both(workloads.BUILDERS[builder](asset_dir, **kw))
+    assert st.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
+def test_adaptive_sampler_batches_and_subdivision_depths(asset_dir):
+    """tiles stay independent under the adaptive sampler (any batch split: same pixels), a
+    threshold nothing exceeds traces only the pixel corners, threshold 0 traces the lattice of
+    every pixel whose corners differ at all, and depth 0 has nothing to subdivide"""
+    def scene(depth, threshold, res=(96, 64)):
+        return workloads.dragon(asset_dir, res=res, spp=(2, 2), mesh="tiny", extra=(
+            ("sampler_type", (1,)), ("adaptive_max_subdivision", (depth,)), ("adaptive_subdivision_threshold", (threshold,))))
+    sp, rd = prepare(scene(3, .04))
+    gs = gpu.Scene(sp)
+    full, st_full = gs.render_frame(rd)
+    for bt in (1, 2, 5):
+        gs.set_option("batch_tiles", bt)
+        fb, st = gs.render_frame(rd)
+        assert st.batches == -(-gpu.tile_count(rd) // bt)
+        assert st.rays.as_dict() == st_full.rays.as_dict()
+        assert float(rel_err(fb, full).max()) <= 1e-6
+    gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    assert st_full.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(full, ref).max()) <= REL_TOL
+    corners = sum((gpu.tile_rect(rd, t)[2] - gpu.tile_rect(rd, t)[0] + 3) * (gpu.tile_rect(rd, t)[3] - gpu.tile_rect(rd, t)[1] + 3)
+                  for t in range(gpu.tile_count(rd)))        # (tile + 2 margin pixels + 1)^2 lattice corners
+    lattice = sum((8 * (gpu.tile_rect(rd, t)[2] - gpu.tile_rect(rd, t)[0] + 2) + 1) * (8 * (gpu.tile_rect(rd, t)[3] - gpu.tile_rect(rd, t)[1] + 2) + 1)
+                  for t in range(gpu.tile_count(rd)))
+    assert corners < rc.camera < lattice
+    osc.close()
+    for depth, threshold, expect in ((3, 1e9, corners), (0, 0., corners)):
+        sp, rd = prepare(scene(depth, threshold))
+        gs = gpu.Scene(sp)
+        fb, st = gs.render_frame(rd)
+        gs.close()
+        osc = oracle_ffi.OracleScene(sp)
+        ref, rc = osc.render(rd)
+        osc.close()
+        assert st.rays.camera == rc.camera == expect
+        assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
 def test_tile_subsets_and_batching_are_consistent(asset_dir):
     """tiles are independent units: any subset / batch split gives the same pixels, and
     pixels of tiles that were not listed stay untouched"""
@@ -268,13 +307,13 @@ def test_unsupported_features_fail_loudly(asset_dir):
     """features outside the device path: explicit error naming the feature, never a silent
     approximation or a CPU fallback"""
     base = _custom_scene(asset_dir, lights=1)
-    adaptive = base.replace("RenderScene ren1", "SetProperty1 ren1 sampler_type 1\nRenderScene ren1")
-    sp, rd = prepare(adaptive)
+    deep = base.replace("RenderScene ren1", "SetProperty1 ren1 sampler_type 1\nSetProperty1 ren1 adaptive_max_subdivision 9\nRenderScene ren1")
+    sp, rd = prepare(deep)
     gs = gpu.Scene(sp)
     with pytest.raises(gpu.GpuError) as e:
         gs.render_frame(rd)
     gs.close()
-    assert "fixed grid sampler" in str(e.value)
+    assert "adaptive_max_subdivision" in str(e.value)
     # sample times are keyed by a 20-bit index inside the tile
     sp, rd = prepare(workloads.motion(asset_dir, res=(640, 640), spp=(2, 2), mesh="tiny", kind="object",
                                       extra=(("tilesize", (640, 640)),)))
