@@ -158,6 +158,8 @@ def main():
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
+    if os.environ.get("FJGPU_OVERLAP"):            # experiment switch: light loop + shadow walk on a second stream
+        gs.set_option("overlap_shadow", int(os.environ["FJGPU_OVERLAP"]))
     prep_seconds = time.perf_counter() - t_prep
 
     n_tiles = gpu.tile_count(render)

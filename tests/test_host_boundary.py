@@ -121,6 +121,16 @@ def test_renderer_defaults_and_property_semantics():
     assert (rd.filter_w, rd.filter_h, rd.jitter, rd.cast_shadow) == (2.0, 2.0, 1.0, 1)
     assert (rd.max_diffuse_depth, rd.max_reflect_depth, rd.max_refract_depth) == (3, 3, 3)
     assert tuple(rd.region) == (0, 0, 320, 240) and (rd.time_start, rd.time_end) == (0.0, 1.0)
+    assert (rd.sampler_type, rd.adaptive_max_subdivision) == (0, 1) and abs(rd.adaptive_subdivision_threshold - .05) < 1e-8
+    # sampler selection (Renderer::SetSamplerType: unknown types fall back to the fixed grid)
+    host.run_scene_text(text % ("SetProperty1 ren1 sampler_type 1\nSetProperty1 ren1 adaptive_max_subdivision 3\n"
+                                "SetProperty1 ren1 adaptive_subdivision_threshold 0.02\n"), deferred=True)
+    _, rd = host.get_desc()
+    assert (rd.sampler_type, rd.adaptive_max_subdivision) == (1, 3) and abs(rd.adaptive_subdivision_threshold - .02) < 1e-8
+    host.run_scene_text(text % "SetProperty1 ren1 sampler_type 7\n", deferred=True)
+    assert host.get_desc()[1].sampler_type == 0
+    with pytest.raises(Exception):
+        host.run_scene_text(text % "SetProperty1 ren1 adaptive_max_subdivision -1\n", deferred=True)
     # resolution resets the render region; a later render_region sticks
     host.run_scene_text(text % "SetProperty4 ren1 render_region 1 2 3 4\nSetProperty2 ren1 resolution 64 48\n", deferred=True)
     _, rd = host.get_desc()
