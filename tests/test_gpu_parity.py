@@ -367,3 +367,32 @@ def test_full_size_headline_properties(asset_dir):
     for t in pick:
         x0, yy0, x1, y1 = gpu.tile_rect(rd, t)
         assert float(rel_err(c[yy0:y1, x0:x1], ref[yy0:y1, x0:x1]).max()) <= REL_TOL
+
+
+@pytest.mark.parametrize("builder,expect,tiles", [
+    ("buddhas", (1280, 720, 4, 4), (9 * 40 + 12, 12 * 40 + 20)),          # C2: glass + plastic, 1.09 M triangles x 3
+    ("cornell", (1920, 1080, 16, 16), (16 * 60 + 22, 20 * 60 + 30)),      # C4: pathtracing, 256 spp
+    ("furry", (1920, 1080, 8, 8), (14 * 60 + 28, 17 * 60 + 33)),          # C5: fur curves + hair shader
+    ("ibl", (1920, 1080, 8, 8), (15 * 60 + 25, 18 * 60 + 31)),            # C6: dome light, 256 samples
+], ids=["c2_buddhas", "c4_pathtracing", "c5_furry", "c6_ibl"])
+def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, tiles, asset_dir):
+    """the other BASELINE.json configurations at their FULL size: two whole tiles each against
+    the oracle (reference accelerators, reference recursion) -- same rays per context, same pixels"""
+    import torch
+    sp, rd = prepare(workloads.BUILDERS[builder](asset_dir))
+    assert (rd.xres, rd.yres, rd.rate_x, rd.rate_y) == expect
+    pick = list(tiles)
+    gs = gpu.Scene(sp)
+    fb = torch.zeros((rd.yres, rd.xres, 4), dtype=torch.float32, device="cuda")
+    st = gs.render_tiles(rd, pick, fb.data_ptr())
+    out = fb.cpu().numpy()
+    gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd, tile_ids=pick)
+    osc.close()
+    assert st.rays.as_dict() == rc.as_dict()
+    assert rc.total() > 20 * rc.camera or builder == "cornell"
+    for t in pick:
+        x0, y0, x1, y1 = gpu.tile_rect(rd, t)
+        assert out[y0:y1, x0:x1].any()
+        assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL
