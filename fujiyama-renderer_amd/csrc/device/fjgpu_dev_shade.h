@@ -206,21 +206,31 @@ __device__ V3 bump_mapping(const DTexture &bump, V3 dPdu, V3 dPdv, float tu, flo
   return normalize(nb);
 }
 
-// wave-aggregated append: one atomic per wave, slots by ballot prefix count.
-// `tally` (optional) receives the number of appended entries, also once per wave.
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter, unsigned long long *tally)
+// block-aggregated append: slots by ballot prefix count inside the wave, wave offsets through
+// LDS, ONE global atomic per block and queue.  (Every wave of a frame adding to the same
+// counters -- which share one cache line -- serialises in L2: 10 M same-line atomics per C3
+// frame were most of the shading kernel's time.)  Every thread of the block must call it.
+// `tally` (optional) receives the number of appended entries, also once per block.
+__device__ __forceinline__ uint32_t block_append(bool want, uint32_t *counter, unsigned long long *tally, uint32_t *s_tmp)
 {
   const unsigned long long mask = __ballot(want);
-  if (!want) return 0xffffffffu;
-  const unsigned lane = __lane_id();
-  const unsigned leader = (unsigned) __ffsll((long long) mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) {
-    base = atomicAdd(counter, (uint32_t) __popcll(mask));
-    if (tally) atomicAdd(tally, (unsigned long long) __popcll(mask));
+  const unsigned lane = __lane_id(), w = threadIdx.x >> 6;
+  if (lane == 0) s_tmp[w] = (uint32_t) __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < BLOCK / 64; k++) { const uint32_t c = s_tmp[k]; s_tmp[k] = total; total += c; }
+    uint32_t base = 0;
+    if (total) {
+      base = atomicAdd(counter, total);
+      if (tally) atomicAdd(tally, (unsigned long long) total);
+    }
+    s_tmp[BLOCK / 64] = base;
   }
-  base = __shfl(base, leader);
-  return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+  __syncthreads();
+  const uint32_t slot = s_tmp[BLOCK / 64] + s_tmp[w] + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+  __syncthreads();          // s_tmp is reused by the next call
+  return want ? slot : 0xffffffffu;
 }
 
 struct ChildRay {
@@ -235,11 +245,11 @@ struct ChildRay {
 };
 
 // `cxt` is uniform per call site (reflect / refract / diffuse children are
-// emitted by separate calls), so the per-context ray count is one atomic per wave
+// emitted by separate calls), so the per-context ray count is one atomic per block
 __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t key,
-    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity)
+    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, uint32_t *s_tmp)
 {
-  const uint32_t slot = wave_append(c.want, &cnt->next_count, &cnt->rays[cxt]);
+  const uint32_t slot = block_append(c.want, &cnt->next_count, &cnt->rays[cxt], s_tmp);
   if (!c.want) return;
   if (slot >= capacity) { cnt->overflow = 1; return; }
   DRay r;
@@ -262,8 +272,11 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
 // the reference is linear in the radiance returned by its child SlTrace calls,
 // so `Cs = local + sum_k w_k * C_child_k` unrolls into per-path products
 // (DESIGN.md 6).
+#ifndef FJ_SHADE_MINB
+#define FJ_SHADE_MINB 1           // resident blocks per CU the register budget is cut for
+#endif
 template <bool kMotion>
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,
+__global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths,
     DLightRec *lrecs, DCounters *cnt)
 {
@@ -575,8 +588,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     if (p.cxt == CXT_CAMERA_RAY) acc[3] = Os;   // one camera ray per sample
   }
 
-  // ---- compaction: ballot + prefix count, one atomic per wave and queue
-  const uint32_t lslot = wave_append(want_light, &cnt->light_count, nullptr);
+  // ---- compaction: ballot + prefix count, one atomic per block and queue
+  __shared__ uint32_t s_tmp[BLOCK / 64 + 1];
+  const uint32_t lslot = block_append(want_light, &cnt->light_count, nullptr, s_tmp);
   if (want_light) {
     if (lslot < sp.light_capacity) {
       lrecs[lslot] = lr;
@@ -584,9 +598,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene S, ShadeParams sp, const
     }
     else cnt->overflow = 1;
   }
-  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity);
-  emit_child(c0, CXT_REFLECT_RAY, sample, uid, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity);
-  emit_child(c1, CXT_REFRACT_RAY, sample, uid, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity);
+  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c0, CXT_REFLECT_RAY, sample, uid, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c1, CXT_REFRACT_RAY, sample, uid, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
 }
 
 #endif

@@ -18,7 +18,9 @@
 // k_shadow_trace: the compact queue only, so every lane of a wave is
 // traversing (no lanes idling while a neighbour walks the BLAS).  Adds
 // c * (1 - Os_occluder) to the sample, or c when the ray reaches the light.
-#define SQ_CHUNK 256u          // shadow-queue slots a wave reserves per global atomic
+#ifndef SQ_CHUNK
+#define SQ_CHUNK 512u          // shadow-queue slots a wave reserves per global atomic
+#endif
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
 
 template <bool kHair, bool kArea>
@@ -35,7 +37,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
   const uint32_t recs_per_iter = 64u / sp.lanes;
   const uint32_t slice_begin = (uint32_t) ((unsigned long long) n * wave / n_waves);
   const uint32_t slice_end = (uint32_t) ((unsigned long long) n * (wave + 1) / n_waves);
-  // queue space is reserved SQ_CHUNK slots at a time: one atomic per 1024 rays
+  // queue space is reserved SQ_CHUNK slots at a time: one atomic per 512 rays
   // instead of one per wave iteration (a single-address atomic per iteration
   // serialised the whole kernel in L2)
   uint32_t chunk_base = 0, chunk_used = SQ_CHUNK;   // wave-uniform; "used == CHUNK" = no chunk yet

@@ -111,7 +111,7 @@ static TravTune trav_tune()
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 24);
     t.steps = env("FJGPU_TRAV_STEPS", 3);
-    t.grab = env("FJGPU_TRAV_GRAB", 128);
+    t.grab = env("FJGPU_TRAV_GRAB", 256);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 32);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;

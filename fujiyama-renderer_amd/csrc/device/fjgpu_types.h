@@ -206,16 +206,21 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
 };
 
 struct DCounters {
+  // Counters that many waves add to at the same time sit on their own 128-byte lines:
+  // same-line atomics serialise in L2 (and a queue's slot counter must not wait behind tallies).
   unsigned long long rays[5];  // per context (fj_ray_counts order: camera shadow diffuse reflect refract)
   unsigned long long nodes, prims, insts, traced, squeued;
-  uint32_t next_count;         // entries appended to the next ray queue
+  unsigned long long pad0_[6];
+  uint32_t next_count;         // entries appended to the next ray queue                      (line 1)
   uint32_t light_count;        // entries appended to the light-record queue
   uint32_t overflow;
-  uint32_t shadow_count;       // slots reserved in the shadow-ray queue
-  uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
-  uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (path stream)
   uint32_t cam_count;          // adaptive sampler: camera rays queued by the current level
-  uint32_t pad_;
+  uint32_t pad1_[28];
+  uint32_t shadow_count;       // slots reserved in the shadow-ray queue                      (line 2)
+  uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
+  uint32_t pad2_[30];
+  uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (line 3)
+  uint32_t pad3_[31];
 };
 
 #endif
