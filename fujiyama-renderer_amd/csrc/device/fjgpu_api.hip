@@ -431,7 +431,6 @@ int ensure_level(fjgpu_scene *sc, int level, size_t cap)
   return 0;
 }
 
-uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 }  // namespace
 
@@ -535,9 +534,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   ShadowParams swp;
   swp.cos_half_pi = std::cos(3.14159265358979323846 / 2.);
   swp.cos_pi = std::cos(3.14159265358979323846);
-  swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, sc->n_light_samples)));
-  swp.lanes = 1;
-  if (const char *e = getenv("FJGPU_CULL_LANES")) swp.lanes = std::min<uint32_t>(64, next_pow2((uint32_t) std::max(1, atoi(e))));
+  swp.pad = 0;
   swp.cast_shadow = r->cast_shadow;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
   ResolveParams rp;

@@ -7,13 +7,12 @@
 // ------------------------------------------------------------------- k_shadow
 // SlIlluminance (src/fj_shading.cc:296-359) in two wavefront stages.
 //
-// k_shadow_cull: every (light record, light sample) pair.  `lanes` consecutive
-// lanes (a power of two <= 64) serve one record and stride over the light
-// samples.  A pair is tested against the world AABBs of the shadow group's
-// instances: if it misses all of them the light is unoccluded and Kd * Cl goes
-// into the per-record sum (butterfly reduction inside the lane segment, one
-// lane adds W * sum to the sample); otherwise the ray is appended -- ballot +
-// prefix count, one atomic per wave -- to the compact shadow-ray queue.
+// k_shadow_cull: every (light record, light sample) pair.  One record per lane,
+// every lane loops over the light samples (wave-uniform index).  A pair is tested
+// against the world AABBs of the shadow group's instances: if it misses all of them
+// the light is unoccluded and Kd * Cl goes into the lane's per-record sum (W * sum is
+// added to the sample at the end); otherwise the ray is appended -- ballot + prefix
+// count into a chunk the wave reserved -- to the compact shadow-ray queue.
 //
 // k_shadow_trace: the compact queue only, so every lane of a wave is
 // traversing (no lanes idling while a neighbour walks the BLAS).  Adds
@@ -23,35 +22,44 @@
 #endif
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
 
+#ifndef FJ_CULL_MINB
+#define FJ_CULL_MINB 1
+#endif
 template <bool kHair, bool kArea>
-__global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
+__global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   unsigned long long c_insts = 0, c_shadow = 0;
   const unsigned lane = __lane_id();
   const uint32_t n = rec_end - rec_begin;
-  // each wave owns a contiguous slice of the records, so the rays it emits --
-  // and the shadow-queue chunks it fills -- stay spatially coherent
-  const unsigned long long wave = ((unsigned long long) blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const unsigned long long n_waves = ((unsigned long long) gridDim.x * BLOCK) >> 6;
-  const uint32_t recs_per_iter = 64u / sp.lanes;
-  const uint32_t slice_begin = (uint32_t) ((unsigned long long) n * wave / n_waves);
-  const uint32_t slice_end = (uint32_t) ((unsigned long long) n * (wave + 1) / n_waves);
+  // waves claim contiguous runs of records (so the rays a wave emits -- and the shadow-queue
+  // chunks it fills -- stay spatially coherent) from a global head: equal static slices left
+  // the kernel waiting for the waves whose records face the lights, and assumed that every
+  // block of the grid is resident
+  const uint32_t n_waves = (gridDim.x * BLOCK) >> 6;
+  uint32_t claim = (n / (n_waves * 4u)) & ~63u;
+  claim = claim < 64u ? 64u : (claim > 1024u ? 1024u : claim);
   // queue space is reserved SQ_CHUNK slots at a time: one atomic per 512 rays
   // instead of one per wave iteration (a single-address atomic per iteration
   // serialised the whole kernel in L2)
   uint32_t chunk_base = 0, chunk_used = SQ_CHUNK;   // wave-uniform; "used == CHUNK" = no chunk yet
 
-  for (uint32_t r0 = slice_begin; r0 < slice_end; r0 += recs_per_iter) {
-    const uint32_t rec = rec_begin + r0 + lane / sp.lanes;
-    const uint32_t sub = lane % sp.lanes;
-    const bool active = (r0 + lane / sp.lanes) < slice_end;
+  uint32_t slice_end = 0, r0 = 0;
+  for (;; r0 += 64u) {
+    if (r0 >= slice_end) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&cnt->cull_head, claim);
+      r0 = __shfl(base, 0);
+      if (r0 >= n) break;
+      slice_end = r0 + claim < n ? r0 + claim : n;
+    }
+    const uint32_t rec = rec_begin + r0 + lane;           // one record per lane
+    const bool active = (r0 + lane) < slice_end;
 
     float sum[3] = {0.f, 0.f, 0.f};
     uint32_t r_sample = 0;
     float W[3] = {0.f, 0.f, 0.f};
     const uint32_t nl = (uint32_t) S.n_light_samples;
-    const uint32_t iters = (nl + sp.lanes - 1) / sp.lanes;     // uniform trip count: ballots stay convergent
     DLightRec R;
     DLightHair H;
     for (int q = 0; q < 6; q++) H.aux[q] = 0;
@@ -62,6 +70,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
     int g_first = 0, g_count = 0;
     bool g_single = false;
     const double *g_sbounds = nullptr;     // stays a global-memory pointer (a by-value DGroup lands in scratch)
+    double sb[6] = {0, 0, 0, 0, 0, 0};
     double cos_limit = 0;
     if (active) {
       R = lrecs[rec];
@@ -75,12 +84,16 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
       g_first = S.groups[R.group].first; g_count = S.groups[R.group].count;
       g_single = S.groups[R.group].n_instances == 1;
       g_sbounds = S.groups[R.group].sbounds;
+      // a single-instance group's box is the same for every light of the record: read it once
+      // (per pair it cost two dependent loads -- node, then box -- before any arithmetic)
+      if (g_single) for (int q = 0; q < 6; q++) sb[q] = g_sbounds[q];
     }
-    for (uint32_t it = 0; it < iters; it++) {
-      const uint32_t l = sub + it * sp.lanes;
+    // the light index is wave-uniform: the sample's 72 bytes come through the scalar cache into
+    // SGPRs instead of 64 identical vector loads
+    for (uint32_t l = 0; l < nl; l++) {
       bool emit = false;
       DShadowRay q;
-      if (active && l < nl) {
+      if (active) {
         const DLightSample LS = S.light_samples[l];
         V3 Pl = mk(LS.P[0], LS.P[1], LS.P[2]);
         float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
@@ -119,13 +132,22 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
           Cl[0] = k * A->color[0]; Cl[1] = k * A->color[1]; Cl[2] = k * A->color[2];
         }
         V3 Ln = mk(Pl.x - Ps.x, Pl.y - Ps.y, Pl.z - Ps.z);
-        const double distance = sqrt(dot(Ln, Ln));
-        if (distance > 0) {
-          const double inv = 1. / distance;
-          Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
+        // lights clearly behind the surface (half of all pairs) skip the f64 sqrt and division:
+        // when the unnormalised dot product is negative by 1e-12 of its terms' magnitude, the
+        // normalised one (each factor rounded to 2^-53) is negative too, hence below cos(PI/2.)
+        const double behind = nml_axis.x * Ln.x + nml_axis.y * Ln.y + nml_axis.z * Ln.z;
+        const double terms = fabs(nml_axis.x * Ln.x) + fabs(nml_axis.y * Ln.y) + fabs(nml_axis.z * Ln.z);
+        const bool surely_behind = cos_limit >= 0 && behind < -1e-12 * terms;
+        double distance = 0, cosangle = -1;
+        if (!surely_behind) {
+          distance = sqrt(dot(Ln, Ln));
+          if (distance > 0) {
+            const double inv = 1. / distance;
+            Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
+          }
+          cosangle = dot(nml_axis, Ln);
         }
-        const double cosangle = dot(nml_axis, Ln);
-        const bool lit = !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
+        const bool lit = !surely_behind && !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
         if (lit) {
           float k[3] = {0.f, 0.f, 0.f};
           if (!kHair || R.kind == 0) {   // plastic_shader.cc:131-137
@@ -153,7 +175,11 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
             if (!has_negative_zero(Ln)) {
               const V3 winv = mk(filter_rcp(Ln.x), filter_rcp(Ln.y), filter_rcp(Ln.z));
               const bool plain = plain_dir(Ln);
-              for (int ti = g_first; ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
+              if (g_single) {
+                maybe_occluded = box_ray_ref_fast(sb, Ps, Ln, winv, plain, .0001, distance);
+                if (!maybe_occluded) c_insts++;
+              }
+              for (int ti = g_first; !g_single && ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
                 const DTNode *tn_ = &S.group_nodes[ti];
                 if (tn_->inst < 0) {
                   double tq;
@@ -162,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
                 }
                 ti++;
                 const DInstance *I = &S.instances[tn_->inst];
-                if (box_ray_ref_fast(g_single ? g_sbounds : I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
+                if (box_ray_ref_fast(I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
                 c_insts++;
               }
             }
@@ -201,13 +227,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_cull(DScene S, ShadowParams sp
         chunk_used += need;
       }
     }
-    // butterfly reduction inside the lane segment (all 64 lanes participate)
-    for (uint32_t off = sp.lanes >> 1; off > 0; off >>= 1) {
-      sum[0] += __shfl_xor(sum[0], (int) off);
-      sum[1] += __shfl_xor(sum[1], (int) off);
-      sum[2] += __shfl_xor(sum[2], (int) off);
-    }
-    if (active && sub == 0) {
+    if (active) {
       float *acc = s_accum + 4 * (size_t) r_sample;
       const float r0v = W[0] * sum[0], r1v = W[1] * sum[1], r2v = W[2] * sum[2];
       if (r0v != 0.f) atomicAdd(acc + 0, r0v);

@@ -37,7 +37,7 @@ struct ShadeParams {
 
 struct ShadowParams {
   double cos_half_pi, cos_pi;  // cos(PI/2.), cos(PI) evaluated by the host libm
-  uint32_t lanes;              // lanes per light record: power of two <= 64
+  uint32_t pad;
   uint32_t queue_capacity;     // entries of the shadow-ray queue
   int32_t cast_shadow;
 };

@@ -184,7 +184,8 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   if (e <= b) return 0;
-  const unsigned long long threads = (unsigned long long) (e - b) * sp.lanes;
+  const unsigned long long threads = (unsigned long long) (e - b);       // one light record per lane
+  (void) hipMemsetAsync(&cnt->cull_head, 0, sizeof(uint32_t), st);
 #define FJ_LAUNCH_CULL(HAIR, AREA) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
   if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation
   else if (S.has_hair) FJ_LAUNCH_CULL(true, false);

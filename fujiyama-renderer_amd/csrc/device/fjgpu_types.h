@@ -220,7 +220,8 @@ struct DCounters {
   uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
   uint32_t pad2_[30];
   uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (line 3)
-  uint32_t pad3_[31];
+  uint32_t cull_head;          // light loop: next unclaimed light record of the current launch
+  uint32_t pad3_[30];
 };
 
 #endif
