@@ -92,6 +92,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   bool anyhit = false, dead_ray = false, plain = false;
   bool deep = false;                       // holding a curve whose ribbon test awaits its second stage
   const DPrimSet *P = nullptr;
+  const DNode *nodes = nullptr;            // P->nodes, kept in registers: re-reading it through P put a
+                                           // dependent load in front of every node fetch
   uint32_t cur = TRAV_DONE;
   uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
   int sp = 0;
@@ -164,6 +166,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (has_negative_zero(od)) continue;
         inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
         P = &S.primsets[I->primset];
+        nodes = P->nodes;
         if (P->n_prims == 0) continue;
         if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
         found = true;
@@ -178,7 +181,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
       if (__ballot(inner) == 0ull) break;
       if (inner) {
-        const float4 *nd = reinterpret_cast<const float4 *>(&P->nodes[cur]);
+        const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
         if (kCount) lc->nodes++;
         // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
         const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
