@@ -3,7 +3,7 @@
 for w in teapot buddhas dragon furry ibl cornell motion arealights; do
   extra=""
   [ "$w" = cornell ] && extra="--spp 6 6"
-  timeout 600 python bench.py --workload $w --steps 1 --warmup 0 --cpu-tiles 0 $extra 2>gpurun_out/all_$w.err | tail -1 | python -c "
+  timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --cpu-tiles 0 $extra 2>gpurun_out/all_$w.err | tail -1 | python -c "
 import json,sys
 try:
     d=json.load(sys.stdin); print('$w', round(d['value'],1), 'Mray/s', round(d['ms_per_step'],1), 'ms', d['config']['rays_per_frame_rank0'], 'prep', round(d['config']['prepare_seconds'],2))
