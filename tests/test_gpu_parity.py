@@ -169,7 +169,11 @@ ADAPTIVE = (("sampler_type", (1,)), ("adaptive_max_subdivision", (2,)), ("adapti
     ("arealights", dict(res=(64, 48), spp=(3, 3), mesh="tiny", kind="both", extra=ADAPTIVE)),
     ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4, extra=ADAPTIVE)),
     ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48, extra=ADAPTIVE)),
-], ids=["pathtracing", "area_lights", "curves", "dome_light"])
+    # no filter margin (width 1 -> ceil(0) pixels), no jitter, ragged 20x20 tiles
+    ("teapot", dict(res=(70, 50), spp=(1, 1), extra=ADAPTIVE + (("filterwidth", (1, 1)), ("sample_jitter", (0,)), ("tilesize", (20, 20))))),
+    ("teapot", dict(res=(64, 64), spp=(1, 1), extra=(("sampler_type", (1,)), ("adaptive_max_subdivision", (4,)),
+                                                      ("adaptive_subdivision_threshold", (.1,)), ("filterwidth", (2.5, 4))))),
+], ids=["pathtracing", "area_lights", "curves", "dome_light", "no_margin_no_jitter", "depth4_wide_filter"])
 def test_adaptive_sampler_with_every_shading_path(builder, kw, asset_dir):
     """AdaptiveGridSampler (sampler_type 1) as a level-synchronous wavefront: the same samples
     are traced as by the reference's stack walk (camera-ray counts equal the oracle's, whose
