@@ -472,9 +472,10 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
     }
 
     // ---- inner nodes
-    for (int step = 0; step < TRAV_STEPS; step++) {
+    for (int step = 0; step < (int) tune.anyhit_steps; step++) {
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
-      if (__ballot(inner) == 0ull) break;
+      const unsigned long long im = __ballot(inner);
+      if (im == 0ull || (step > 0 && (uint32_t) __popcll(im) < tune.min_inner)) break;
       if (inner) {
         const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
         if (kCount) lc->nodes++;

@@ -22,7 +22,7 @@
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
 // tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
-struct TravTune { uint32_t refill, steps, grab, leaf_wait; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic

@@ -106,12 +106,17 @@ size_t persistent_threads() { return (size_t) persistent_grid(~0ull) * BLOCK; }
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 24);
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 256);
+    // lean any-hit walk: up to `anyhit_steps` inner steps per iteration, the 2nd and later ones only
+    // while at least `min_inner` lanes are at inner nodes (C3 -4.5 ms, C6 -30 ms; the general walk
+    // keeps the fixed 3: incoherent rays (C4) and curve leaves (C5) lost 2-7 % with it)
+    t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 6);
+    t.min_inner = env("FJGPU_TRAV_MININNER", 32);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 32);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
