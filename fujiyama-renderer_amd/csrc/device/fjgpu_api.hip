@@ -475,16 +475,17 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         "motion blur, area lights or PathtracingShader: their per-sample times and random streams are keyed by a 20-bit sample index");
   // Batch size.  The persistent traversal kernels pay a tail per launch (ray costs are
   // heavy tailed: the last waves finish long after the average one), so launches should be
-  // few and large: about 80 M samples per batch -- half a 1080p / 64 spp frame, ~45 GB of
+  // few and large: up to 160 M samples per batch -- a whole 1080p / 64 spp frame, ~80 GB of
   // queues plus the shadow queue -- bounded by 40 % of the free HBM, unless told otherwise.
-  // Measured on C3: 4 M samples per batch 473 ms/frame, 80 M 392 ms, whole frame 390 ms.
+  // Measured on C3: 4 M samples per batch 473 ms/frame, 80 M 392 ms, whole frame 390 ms; later,
+  // with a 196 ms frame: two batches 195.8 ms, one 192.9 ms.
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
   const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
   long bt = sc->batch_tiles;
   if (bt <= 0) {
     const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
-    const size_t target = std::min<size_t>((size_t) 80 << 20, (size_t) (.4 * (double) free_now) / per_sample);
+    const size_t target = std::min<size_t>((size_t) 160 << 20, (size_t) (.4 * (double) free_now) / per_sample);
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
   bt = std::min<long>(bt, (long) ids.size());
