@@ -31,7 +31,7 @@ __device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : 
 __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
 
 // The curve (moved to the ray's time) in ray space: origin at the ray origin, +z along the ray
-__device__ __forceinline__ Bz curve_to_ray_space(const double *cpw, const double *velw, double time, double w0, double w1, V3 oo, V3 od, double *ray_scale_out)
+__device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, V3 oo, V3 od, double *ray_scale_out)
 {
   // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
   const double ray_scale = sqrt(dot(od, od));
@@ -78,14 +78,14 @@ __device__ __forceinline__ bool bz_misses_ray(const Bz &b)
 
 // first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
 // (exactly the test curve_ray starts with: a curve rejected here is rejected there)
-__device__ bool curve_may_hit(const double *cpw, const double *velw, double time, double w0, double w1, V3 oo, V3 od)
+__device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, V3 oo, V3 od)
 {
   double rs;
   const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &rs);
   return !bz_misses_ray(root);
 }
 
-__device__ bool curve_ray(const double *cpw, const double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+__device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
 {
   double ray_scale;
   const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &ray_scale);
@@ -164,7 +164,7 @@ __device__ bool curve_ray(const double *cpw, const double *velw, double time, do
 // control points and of the four points moved by that velocity (box_bezier3, N_STEPS = 1).
 // Inner levels are pruned with the hull of both polygons widened by 1e-12 (relative): the
 // leaf's "cp + (end - cp)" differs from "end" by rounding only.
-__device__ bool curve_listed_in_cell_of_moving(const DPrimSet *P, const double *cpw, const double *velw, V3 hitp)
+__device__ bool curve_listed_in_cell_of_moving(const DPrimSet *P, const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, V3 hitp)
 {
   double cmin[3], cmax[3];
   const double hp[3] = {hitp.x, hitp.y, hitp.z};
@@ -229,7 +229,7 @@ __device__ bool curve_listed_in_cell_of_moving(const DPrimSet *P, const double *
   return false;
 }
 
-__device__ bool curve_listed_in_cell_of(const DPrimSet *P, const double *cpw, V3 hitp)
+__device__ bool curve_listed_in_cell_of(const DPrimSet *P, const FJ_GLOBAL double *cpw, V3 hitp)
 {
   int ci[3];
   double cmin[3], cmax[3];

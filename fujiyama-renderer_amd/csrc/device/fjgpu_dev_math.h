@@ -21,7 +21,17 @@ __device__ __forceinline__ V3 normalize(V3 a)
   const double inv = 1. / len;
   return a * inv;
 }
+// A pointer read from a record in memory is "generic" to the compiler, which then emits FLAT
+// loads: they count against the LDS (LGKM) counter as well, so every wait for the LDS traversal
+// stack also waits for the node or triangle fetch in flight.  These arrays are global memory.
+#define FJ_GLOBAL __attribute__((address_space(1)))
+typedef float fj_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t fj_v4u __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 ld3(const FJ_GLOBAL double *p) { return mk(p[0], p[1], p[2]); }
+// the same array as the compiler should see it: global memory
+#define FJ_G(T, ptr) ((const FJ_GLOBAL T *) (ptr))
 // MatTransformPoint / MatTransformVector, reference src/fj_matrix.cc:208-222
 __device__ __forceinline__ V3 xpoint(const double *m, V3 p)
 {
@@ -154,13 +164,13 @@ __device__ __forceinline__ double filter_rcp(double x)
 __device__ __forceinline__ void load_tri(const double *t64, const float *t32, uint32_t i, V3 *v0, V3 *v1, V3 *v2)
 {
   if (t32) {
-    const float *p = t32 + (size_t) i * 9;
+    const FJ_GLOBAL float *p = (const FJ_GLOBAL float *) t32 + (size_t) i * 9;
     *v0 = mk((double) p[0], (double) p[1], (double) p[2]);
     *v1 = mk((double) p[3], (double) p[4], (double) p[5]);
     *v2 = mk((double) p[6], (double) p[7], (double) p[8]);
   } else {
-    const double *p = t64 + (size_t) i * 9;
-    *v0 = ld3(p); *v1 = ld3(p + 3); *v2 = ld3(p + 6);
+    const FJ_GLOBAL double *p = (const FJ_GLOBAL double *) t64 + (size_t) i * 9;
+    *v0 = mk(p[0], p[1], p[2]); *v1 = mk(p[3], p[4], p[5]); *v2 = mk(p[6], p[7], p[8]);
   }
 }
 

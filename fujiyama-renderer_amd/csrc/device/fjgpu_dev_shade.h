@@ -328,38 +328,38 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       // derivative at v_hit, Cd = lerp of the end colours; N / uv / dPdu stay zero
       const size_t sl = (size_t) h.v;
       const double vhit = h.u;
-      const double *cp = P->curve_cp + sl * 12;
+      const FJ_GLOBAL double *cp = FJ_G(double, P->curve_cp) + sl * 12;
       V3 c0 = ld3(cp), c1 = ld3(cp + 3), c2 = ld3(cp + 6), c3 = ld3(cp + 9);
       if (kMotion && P->curve_vel) {          // time_sample (src/fj_curve.cc:392-397): cp += time * velocity
         const double tm_ = sample_time(S, p.uid & 0xfffffu);
-        const double *w = P->curve_vel + sl * 12;
+        const FJ_GLOBAL double *w = FJ_G(double, P->curve_vel) + sl * 12;
         c0 = c0 + tm_ * ld3(w); c1 = c1 + tm_ * ld3(w + 3); c2 = c2 + tm_ * ld3(w + 6); c3 = c3 + tm_ * ld3(w + 9);
       }
       const double uu = 1 - vhit;
       const double da = 2 * uu * uu, db = 4 * uu * vhit, dc = 2 * vhit * vhit;
       dPdv = da * (c1 - c0) + db * (c2 - c1) + dc * (c3 - c2);   // derivative_bezier3, :474-486
       const float tl = (float) vhit;
-      const float *cd = P->curve_Cd + sl * 6;
+      const FJ_GLOBAL float *cd = FJ_G(float, P->curve_Cd) + sl * 6;
       Cd[0] = (1 - tl) * cd[0] + tl * cd[3];
       Cd[1] = (1 - tl) * cd[1] + tl * cd[4];
       Cd[2] = (1 - tl) * cd[2] + tl * cd[5];
     } else {
       // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
-      const int32_t *ix = P->indices + 3 * (size_t) h.prim;
+      const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, P->indices) + 3 * (size_t) h.prim;
       i0 = ix[0]; i1 = ix[1]; i2 = ix[2];
       V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
-      if (P->N) { n0 = ld3(P->N + 3 * (size_t) i0); n1 = ld3(P->N + 3 * (size_t) i1); n2 = ld3(P->N + 3 * (size_t) i2); }
+      if (P->N) { n0 = ld3(FJ_G(double, P->N) + 3 * (size_t) i0); n1 = ld3(FJ_G(double, P->N) + 3 * (size_t) i1); n2 = ld3(FJ_G(double, P->N) + 3 * (size_t) i2); }
       N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;            // TriComputeNormal, src/fj_triangle.cc:44-49
       has_uv = P->uv != nullptr;
       if (has_uv) {
-        t0u = P->uv[2 * (size_t) i0]; t0v = P->uv[2 * (size_t) i0 + 1];
-        t1u = P->uv[2 * (size_t) i1]; t1v = P->uv[2 * (size_t) i1 + 1];
-        t2u = P->uv[2 * (size_t) i2]; t2v = P->uv[2 * (size_t) i2 + 1];
+        t0u = FJ_G(float, P->uv)[2 * (size_t) i0]; t0v = FJ_G(float, P->uv)[2 * (size_t) i0 + 1];
+        t1u = FJ_G(float, P->uv)[2 * (size_t) i1]; t1v = FJ_G(float, P->uv)[2 * (size_t) i1 + 1];
+        t2u = FJ_G(float, P->uv)[2 * (size_t) i2]; t2v = FJ_G(float, P->uv)[2 * (size_t) i2 + 1];
         const float tt = (float) (1 - h.u - h.v);                  // f32 barycentric, src/fj_mesh.cc:285
         tu = (float) (tt * t0u + h.u * t1u + h.v * t2u);
         tv = (float) (tt * t0v + h.u * t1v + h.v * t2v);
       }
-      sg = P->face_group ? P->face_group[h.prim] : 0;
+      sg = P->face_group ? FJ_G(int32_t, P->face_group)[h.prim] : 0;
     }
     V3 Pw = oo + h.t * od;                                        // RayPointAt in object space
     // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)
@@ -401,12 +401,12 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           if (has_uv) {
             // TriComputeDerivatives (src/fj_triangle.cc:51-74) on the object-space
             // vertices, then the instance's M as a vector transform
-            V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            V3 p0 = ld3(FJ_G(double, P->P) + 3 * (size_t) i0), p1 = ld3(FJ_G(double, P->P) + 3 * (size_t) i1), p2 = ld3(FJ_G(double, P->P) + 3 * (size_t) i2);
             if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
               const double tm_ = sample_time(S, p.uid & 0xfffffu);
-              p0 = p0 + tm_ * ld3(P->velocity + 3 * (size_t) i0);
-              p1 = p1 + tm_ * ld3(P->velocity + 3 * (size_t) i1);
-              p2 = p2 + tm_ * ld3(P->velocity + 3 * (size_t) i2);
+              p0 = p0 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i0);
+              p1 = p1 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i1);
+              p2 = p2 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i2);
             }
             const V3 dP1 = p1 - p0, dP2 = p2 - p0;
             const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;
@@ -506,12 +506,12 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
         }
         if (sh->bump_map >= 0) {
           if (has_uv) {
-            V3 p0 = ld3(P->P + 3 * (size_t) i0), p1 = ld3(P->P + 3 * (size_t) i1), p2 = ld3(P->P + 3 * (size_t) i2);
+            V3 p0 = ld3(FJ_G(double, P->P) + 3 * (size_t) i0), p1 = ld3(FJ_G(double, P->P) + 3 * (size_t) i1), p2 = ld3(FJ_G(double, P->P) + 3 * (size_t) i2);
             if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
               const double tm_ = sample_time(S, p.uid & 0xfffffu);
-              p0 = p0 + tm_ * ld3(P->velocity + 3 * (size_t) i0);
-              p1 = p1 + tm_ * ld3(P->velocity + 3 * (size_t) i1);
-              p2 = p2 + tm_ * ld3(P->velocity + 3 * (size_t) i2);
+              p0 = p0 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i0);
+              p1 = p1 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i1);
+              p2 = p2 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i2);
             }
             const V3 dP1 = p1 - p0, dP2 = p2 - p0;
             const float du1 = t1u - t0u, du2 = t2u - t0u, dv1 = t1v - t0v, dv2 = t2v - t0v;

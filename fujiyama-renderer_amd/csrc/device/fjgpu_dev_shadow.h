@@ -477,10 +477,10 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       const unsigned long long im = __ballot(inner);
       if (im == 0ull || (step > 0 && (uint32_t) __popcll(im) < tune.min_inner)) break;
       if (inner) {
-        const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
+        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
         if (kCount) lc->nodes++;
-        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
-        const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
+        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
         const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
         const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
         const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};

@@ -181,11 +181,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
       if (__ballot(inner) == 0ull) break;
       if (inner) {
-        const float4 *nd = reinterpret_cast<const float4 *>(&nodes[cur]);
+        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
         if (kCount) lc->nodes++;
         // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
-        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
-        const uint4 e = reinterpret_cast<const uint4 *>(nd)[6];
+        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
         const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
         const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
         const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
@@ -225,12 +225,12 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         // BLAS entries are sub-segments of curves: the ribbon test of a curve runs once, not
         // once per piece entered (same ray, same instance: same result)
         const size_t sl = first;
-        const uint32_t cid = P->prim_ids[sl];
+        const uint32_t cid = FJ_G(uint32_t, P->prim_ids)[sl];
         if (cid != last_curve) {
           last_curve = cid;
           if (kCount) lc->prims++;
-          const double *cvel = (kMotion && P->curve_vel) ? P->curve_vel + sl * 12 : nullptr;
-          deep = curve_may_hit(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1], oo, od);
+          const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
+          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], oo, od);
         }
       } else {
         for (uint32_t k = 0; k < cnt; k++) {
@@ -239,12 +239,12 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           V3 v0, v1, v2;
           load_tri(P->tri_verts, P->tri_verts32, first + k, &v0, &v1, &v2);
           if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
-            const double *w = P->tri_vel + (size_t) (first + k) * 9;
+            const FJ_GLOBAL double *w = FJ_G(double, P->tri_vel) + (size_t) (first + k) * 9;
             v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
           }
           if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
           if (!(tmin <= t && t <= tmax)) continue;
-          const int pid = (int) P->prim_ids[first + k];
+          const int pid = (int) FJ_G(uint32_t, P->prim_ids)[first + k];
           if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
             best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
             if (anyhit) { stop = true; break; }
@@ -267,15 +267,15 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
             deep = false;
             bool stop = false;
             const size_t sl = (cur & 0x7fffffffu) >> 3;
-            const double *cvel = (kMotion && P->curve_vel) ? P->curve_vel + sl * 12 : nullptr;
+            const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
             double t, u = 0;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
-            if (curve_ray(P->curve_cp + sl * 12, cvel, rtime, P->curve_width[2 * sl], P->curve_width[2 * sl + 1],
-                          (int) P->curve_depth[sl], oo, od, &t, &u) &&
-                (cvel ? curve_listed_in_cell_of_moving(P, P->curve_cp + sl * 12, cvel, oo + t * od)
-                      : curve_listed_in_cell_of(P, P->curve_cp + sl * 12, oo + t * od)) &&
+            if (curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
+                          (int) FJ_G(int8_t, P->curve_depth)[sl], oo, od, &t, &u) &&
+                (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
+                      : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {
-              const int pid = (int) P->prim_ids[sl];
+              const int pid = (int) FJ_G(uint32_t, P->prim_ids)[sl];
               if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
                 best.t = t; best.u = u; best.v = (double) sl; best.inst = ii; best.prim = pid;
                 stop = anyhit;
