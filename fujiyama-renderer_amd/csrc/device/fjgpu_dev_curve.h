@@ -30,24 +30,47 @@ __device__ __forceinline__ double dmax(double x, double y) { return x > y ? x : 
 __device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : y; }
 __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
 
-// The curve (moved to the ray's time) in ray space: origin at the ray origin, +z along the ray
-__device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, V3 oo, V3 od, double *ray_scale_out)
+// Ray space of one (ray, instance): origin at the ray origin, +z along the ray
+// (compute_world_to_ray_matrix, src/fj_curve.cc:268-295: dst = rotate * translate).  The
+// reference rebuilds it in every Curve::ray_intersect call; it depends on the ray only, so the
+// walk builds it ONCE when the ray enters a curve set and keeps its 12 numbers in LDS
+// ([k][thread], lane consecutive) -- two square roots and two divisions less per curve tested,
+// more than half of the first-stage test.
+#define FJ_RAYSPACE_DOUBLES 12
+struct RaySpace {
+  double *lds;          // s_rayspace + threadIdx.x
+  __device__ __forceinline__ void set(V3 oo, V3 od) const
+  {
+    // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
+    const double ray_scale = sqrt(dot(od, od));
+    const double sinv = 1. / ray_scale;
+    const V3 nd = od * sinv;
+    const double lx = nd.x, ly = nd.y, lz = nd.z;
+    const double d = sqrt(lx * lx + lz * lz);
+    const double d_inv = 1. / d;
+    const V3 r0 = mk(lz * d_inv, 0, -lx * d_inv);
+    const V3 r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
+    const V3 r2 = mk(lx, ly, lz);
+    const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
+    lds[0 * BLOCK] = r0.x; lds[1 * BLOCK] = r0.z;                          // r0.y = 0
+    lds[2 * BLOCK] = r1.x; lds[3 * BLOCK] = r1.y; lds[4 * BLOCK] = r1.z;
+    lds[5 * BLOCK] = r2.x; lds[6 * BLOCK] = r2.y; lds[7 * BLOCK] = r2.z;
+    lds[8 * BLOCK] = r0.x * nox + r0.y * noy + r0.z * noz;
+    lds[9 * BLOCK] = r1.x * nox + r1.y * noy + r1.z * noz;
+    lds[10 * BLOCK] = r2.x * nox + r2.y * noy + r2.z * noz;
+    lds[11 * BLOCK] = ray_scale;
+  }
+};
+
+// The curve (moved to the ray's time) in that space
+__device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1,
+    const RaySpace &rsp, double *ray_scale_out)
 {
-  // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
-  const double ray_scale = sqrt(dot(od, od));
-  const double sinv = 1. / ray_scale;
-  const V3 nd = od * sinv;
-  // compute_world_to_ray_matrix, :268-295: dst = rotate * translate
-  const double lx = nd.x, ly = nd.y, lz = nd.z;
-  const double d = sqrt(lx * lx + lz * lz);
-  const double d_inv = 1. / d;
-  const V3 r0 = mk(lz * d_inv, 0, -lx * d_inv);
-  const V3 r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
-  const V3 r2 = mk(lx, ly, lz);
-  const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
-  const double m03 = r0.x * nox + r0.y * noy + r0.z * noz;
-  const double m13 = r1.x * nox + r1.y * noy + r1.z * noz;
-  const double m23 = r2.x * nox + r2.y * noy + r2.z * noz;
+  const double *m = rsp.lds;
+  const V3 r0 = mk(m[0 * BLOCK], 0, m[1 * BLOCK]);
+  const V3 r1 = mk(m[2 * BLOCK], m[3 * BLOCK], m[4 * BLOCK]);
+  const V3 r2 = mk(m[5 * BLOCK], m[6 * BLOCK], m[7 * BLOCK]);
+  const double m03 = m[8 * BLOCK], m13 = m[9 * BLOCK], m23 = m[10 * BLOCK];
   Bz root;
   V3 p[4];
   for (int k = 0; k < 4; k++) {
@@ -59,7 +82,7 @@ __device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, co
   }
   root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
   root.w0 = w0; root.w1 = w1;
-  *ray_scale_out = ray_scale;
+  *ray_scale_out = m[11 * BLOCK];
   return root;
 }
 
@@ -78,17 +101,17 @@ __device__ __forceinline__ bool bz_misses_ray(const Bz &b)
 
 // first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
 // (exactly the test curve_ray starts with: a curve rejected here is rejected there)
-__device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, V3 oo, V3 od)
+__device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, const RaySpace &rsp)
 {
   double rs;
-  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &rs);
+  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, rsp, &rs);
   return !bz_misses_ray(root);
 }
 
-__device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, int depth, V3 oo, V3 od, double *t_out, double *v_out)
+__device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, int depth, const RaySpace &rsp, double *t_out, double *v_out)
 {
   double ray_scale;
-  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, oo, od, &ray_scale);
+  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, rsp, &ray_scale);
   double best_z = DBL_MAX, best_v = DBL_MAX;
   bool any = false;
   const uint32_t nleaf = 1u << depth;

@@ -289,11 +289,12 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : 
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);

@@ -47,6 +47,7 @@ struct TravStack {
   uint32_t *lds;        // s_stack + threadIdx.x
   uint32_t *ovf;        // overflow base + global thread id (null when no tree needs it)
   uint32_t ovf_stride;  // threads in the grid
+  double *rayspace;     // curve scenes: s_rayspace + threadIdx.x (RaySpace), else null
   __device__ __forceinline__ void push(int &sp, uint32_t v) const
   {
     if (sp < FJ_STACK_LDS) lds[sp * BLOCK] = v;
@@ -59,10 +60,11 @@ struct TravStack {
     return sp < FJ_STACK_LDS ? lds[sp * BLOCK] : ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride];
   }
 };
-__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf)
+__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf, double *s_rayspace = nullptr)
 {
   TravStack st;
   st.lds = s_stack + threadIdx.x;
+  st.rayspace = s_rayspace ? s_rayspace + threadIdx.x : nullptr;
   st.ovf_stride = gridDim.x * BLOCK;
   st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
   return st;
@@ -172,7 +174,10 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         found = true;
         break;
       }
-      if (found) { cur = P->root; sp = 0; last_curve = 0xffffffffu; }
+      if (found) {
+        cur = P->root; sp = 0; last_curve = 0xffffffffu;
+        if (kCurves && P->type == FJ_PRIMSET_CURVE) { RaySpace rsp; rsp.lds = stk.rayspace; rsp.set(oo, od); }
+      }
       else { pol.finish(idx, best); have = false; }
     }
 
@@ -230,7 +235,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           last_curve = cid;
           if (kCount) lc->prims++;
           const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
-          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], oo, od);
+          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace});
         }
       } else {
         for (uint32_t k = 0; k < cnt; k++) {
@@ -271,7 +276,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
             double t, u = 0;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
             if (curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
-                          (int) FJ_G(int8_t, P->curve_depth)[sl], oo, od, &t, &u) &&
+                          (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace}, &t, &u) &&
                 (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {
@@ -329,10 +334,11 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : 
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
