@@ -217,29 +217,50 @@ def main():
     if rank == 0:
         s0 = stats[-1]
         per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
-        # roofline of the dominant kernels (k_trace_closest + k_shadow) on rank 0:
-        # algorithmic bytes of all their launches / summed HIP-event durations
-        alg = float(algorithmic_bytes(counted, s_node, s_prim)) * len(stats)
+        # roofline of the DOMINANT KERNEL on rank 0 -- the shadow walk (k_shadow_anyhit, or
+        # k_shadow_trace for scenes with translucent occluders / curves / motion): the algorithmic
+        # bytes of its launches (its own event counts from the counting frame x record sizes) over
+        # the summed HIP-event durations of exactly those launches in the timed frames.
+        nf = len(stats)
+        walk_alg = float(counted.shadow_nodes * s_node + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
+                         counted.shadow_traversed * S_SHADOW) * nf
+        walk_ms = float(sum(s.shadow_walk_ms for s in stats))
+        walk_nl = float(sum(s.shadow_walk_launches for s in stats))
+        achieved = walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        kname = "k_shadow_anyhit" if gs.query("lean_anyhit") else "k_shadow_trace"
+        # ... and of the whole traversal side (closest-hit walk + light loop + shadow walk), as before
+        alg = float(algorithmic_bytes(counted, s_node, s_prim)) * nf
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
-        achieved = alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
         # HBM traffic of the same kernels from the PMC passes committed under profiles/
         # (rocprofv3 cannot run inside this process): per frame, spread over this run's launches
-        traffic, traffic_src = None, None
+        traffic, traffic_all, traffic_src = None, None, None
         tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tp) and args.workload == "dragon" and not (args.mesh or args.res or args.spp) and world == 1:
             with open(tp) as f:
                 tj = json.load(f)
-            traffic = tj["hbm_bytes_per_frame"] * len(stats) / nl if nl else None
+            tk = tj["kernels"].get(kname)
+            if tk and walk_nl:
+                traffic = (2 * tk["fetch_kb_per_frame"] + tk["write_kb_per_frame"]) * 1024.0 * nf / walk_nl
+            traffic_all = tj["hbm_bytes_per_frame"] * nf / nl if nl else None
             traffic_src = "profiles/r01_traffic.json"
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src,
-                "kernel": "k_trace_closest+k_shadow", "launches": int(nl),
-                "avg_launch_ms": tms / nl if nl else None,
-                "algorithmic_bytes_per_launch": alg / nl if nl else None,
-                "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * len(stats)),
-                "record_bytes": {"node": s_node, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW}}
+                "kernel": kname, "launches": int(walk_nl),
+                "avg_launch_ms": walk_ms / walk_nl if walk_nl else None,
+                "algorithmic_bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
+                "share_of_frame": walk_ms / max(1e-9, float(sum(s.total_ms for s in stats))),
+                "bytes_per_ray": walk_alg / max(1.0, float(counted.shadow_traversed) * nf),
+                "record_bytes": {"node": s_node, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW},
+                "kernel_ms_per_frame_rank0": {"k_trace_closest": float(sum(s.closest_ms for s in stats)) / nf,
+                                              "k_shadow_cull": float(sum(s.light_loop_ms for s in stats)) / nf,
+                                              kname: walk_ms / nf},
+                "all_traversal_kernels": {"kernel": "k_trace_closest+k_shadow_cull+" + kname, "launches": int(nl),
+                                          "achieved": alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
+                                          "frac": (alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0) / HBM_PEAK_GBPS,
+                                          "algorithmic_bytes_per_frame": alg / nf, "traffic_per_frame": traffic_all * nl / nf if traffic_all else None,
+                                          "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * nf)}}
         out = {
             "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
             "value": total_rays / elapsed_max / 1e6,

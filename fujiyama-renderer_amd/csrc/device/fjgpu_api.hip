@@ -350,6 +350,8 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
+  // 1: shadow rays are walked by k_shadow_anyhit (every occluder opaque, no curves, no motion), 0: by k_shadow_trace
+  if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion) ? 1 : 0; return 0; }
   return fail(FJGPU_EINVAL, "unknown query " + n);
 }
 
@@ -644,11 +646,11 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     shadow_queue_reset(sst, sc->d_cnt);
     auto flush_shadow = [&](const DScene &Sx) -> int {
       if (sq_dirty) {
-        const int fe = timed(sst, &acc.trace_ms, [&]() {
+        const int fe = timed(sst, &acc.shadow_walk_ms, [&]() {
           return launch_shadow_trace(sst, Sx, sc->d_squeue, sc->d_accum, sc->d_cnt, (int) sc->count_events);
         });
         if (fe) return fe;
-        acc.trace_launches++;
+        acc.trace_launches++; acc.shadow_walk_launches++;
         shadow_queue_reset(sst, sc->d_cnt);
       }
       sq_bound = 0; sq_dirty = false;
@@ -664,11 +666,11 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         const DRay *rays = sc->levels[level].rays + off;
         const DPath *paths = sc->levels[level].paths + off;
         (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
-        int e = timed(st, &acc.trace_ms, [&]() {
+        int e = timed(st, &acc.closest_ms, [&]() {
           return launch_trace_closest(st, S, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
         });
         if (e) return e;
-        acc.trace_launches++;
+        acc.trace_launches++; acc.closest_launches++;
         const unsigned lb = shade_seq++ & 1u;          // light-record buffer of this shading call
         if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
         shadow_pending[lb] = false;
@@ -707,7 +709,8 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
               if (sq_bound > 0) { e = flush_shadow(Sl); if (e) return e; continue; }
               if (can == 0) can = 1;
             }
-            e = timed(sst, &acc.trace_ms, [&]() {
+            acc.light_loop_launches++;
+            e = timed(sst, &acc.light_loop_ms, [&]() {
               return launch_shadow_cull(sst, Sl, swp, sc->d_lrecs[lb], b, b + can, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
             });
             if (e) return e;
@@ -791,6 +794,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     acc.insts_tested += hc.insts;
     acc.rays_traced += hc.traced;
     acc.shadow_traversed += hc.squeued;
+    acc.shadow_nodes += hc.sh_nodes; acc.shadow_prims += hc.sh_prims; acc.shadow_insts += hc.sh_insts;
     acc.batches++;
   }
   (void) hipEventRecord(ev_all[1], st);
@@ -801,6 +805,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     acc.total_ms = ms;
     for (const Span &sp : spans)
       if (hipEventElapsedTime(&ms, sc->ev_pool[sp.a], sc->ev_pool[sp.b]) == hipSuccess) *sp.bucket += ms;
+    acc.trace_ms = acc.closest_ms + acc.light_loop_ms + acc.shadow_walk_ms;
   }
   (void) hipEventDestroy(ev_all[0]); (void) hipEventDestroy(ev_all[1]);
   if (rc > 0 || rc == -1) return fail(FJGPU_ENODEV, std::string("HIP failure in the wavefront loop: ") + hipGetErrorString(hipGetLastError()));

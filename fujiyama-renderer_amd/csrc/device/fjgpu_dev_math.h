@@ -230,4 +230,16 @@ __device__ __forceinline__ void flush_counters(DCounters *cnt, unsigned long lon
   }
 }
 
+// the shadow walk's events, counted a second time on their own (per-kernel roofline)
+__device__ __forceinline__ void flush_shadow_walk_counters(DCounters *cnt, unsigned long long nodes, unsigned long long prims,
+    unsigned long long insts)
+{
+  nodes = wave_sum(nodes); prims = wave_sum(prims); insts = wave_sum(insts);
+  if (__lane_id() == 0) {
+    if (nodes) atomicAdd(&cnt->sh_nodes, nodes);
+    if (prims) atomicAdd(&cnt->sh_prims, prims);
+    if (insts) atomicAdd(&cnt->sh_insts, insts);
+  }
+}
+
 #endif

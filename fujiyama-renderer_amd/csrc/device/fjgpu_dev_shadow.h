@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : 
   traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
   }
 }
@@ -562,6 +563,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene 
   traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->shadow_head, make_stack(s_stack, S.stack_overflow_shadow), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
   }
 }

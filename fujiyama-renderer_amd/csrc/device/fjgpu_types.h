@@ -210,7 +210,8 @@ struct DCounters {
   // same-line atomics serialise in L2 (and a queue's slot counter must not wait behind tallies).
   unsigned long long rays[5];  // per context (fj_ray_counts order: camera shadow diffuse reflect refract)
   unsigned long long nodes, prims, insts, traced, squeued;
-  unsigned long long pad0_[6];
+  unsigned long long sh_nodes, sh_prims, sh_insts;   // the shadow walk's share of nodes / prims / insts
+  unsigned long long pad0_[3];
   uint32_t next_count;         // entries appended to the next ray queue                      (line 1)
   uint32_t light_count;        // entries appended to the light-record queue
   uint32_t overflow;

@@ -45,6 +45,10 @@ class GpuStats(C.Structure):           # fjgpu_stats
         ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("gen_ms", C.c_double),
         ("resolve_ms", C.c_double), ("total_ms", C.c_double),
         ("trace_launches", C.c_uint32), ("batches", C.c_uint32),
+        ("closest_ms", C.c_double), ("light_loop_ms", C.c_double), ("shadow_walk_ms", C.c_double),
+        ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64), ("shadow_insts", C.c_uint64),
+        ("closest_launches", C.c_uint32), ("light_loop_launches", C.c_uint32),
+        ("shadow_walk_launches", C.c_uint32), ("pad_", C.c_uint32),
     ]
 
 

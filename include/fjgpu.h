@@ -59,6 +59,15 @@ typedef struct fjgpu_stats {
   double   total_ms;           /* first launch -> last kernel done */
   uint32_t trace_launches;
   uint32_t batches;
+  /* the traversal side per kernel (trace_ms is their sum), so that one kernel's HIP-event time
+   * can be set against its own algorithmic bytes and against rocprofv3's average for it */
+  double   closest_ms;         /* k_trace_closest launches */
+  double   light_loop_ms;      /* k_shadow_cull launches (SlIlluminance light loop + instance-box cull) */
+  double   shadow_walk_ms;     /* k_shadow_anyhit / k_shadow_trace launches */
+  uint64_t shadow_nodes;       /* BLAS nodes fetched by the shadow walk alone (counting instantiation) */
+  uint64_t shadow_prims;       /* triangle / curve tests of the shadow walk alone */
+  uint64_t shadow_insts;       /* instance boxes tested by the shadow walk alone */
+  uint32_t closest_launches, light_loop_launches, shadow_walk_launches, pad_;
 } fjgpu_stats;
 
 /* Number of visible HIP devices (0 when there is none). */
@@ -108,7 +117,8 @@ int fjgpu_global_option(const char *name, long value);
 
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).
  * "node_record_bytes" (128), "tri_record_bytes" (36 when every mesh is stored as exact f32
- * triangles, else 72), "blas_nodes", "stack_need".  Returns 0 or FJGPU_EINVAL. */
+ * triangles, else 72), "blas_nodes", "stack_need", "lean_anyhit" (1: shadow rays are walked by
+ * k_shadow_anyhit, 0: by the general k_shadow_trace).  Returns 0 or FJGPU_EINVAL. */
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);
 
 /* Diagnostics: the host-side math that feeds geometry to the device (matrices,
