@@ -117,7 +117,7 @@ static TravTune trav_tune()
     // keeps the fixed 3: incoherent rays (C4) and curve leaves (C5) lost 2-7 % with it)
     t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 6);
     t.min_inner = env("FJGPU_TRAV_MININNER", 32);
-    t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 32);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
+    t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
     if (t.steps < 1) t.steps = 1;
