@@ -288,8 +288,12 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;
-    if (need > FJ_STACK_LDS) {
-      const size_t entries = (size_t) (need - FJ_STACK_LDS) * persistent_threads();
+    // (scenes with curve sets run the kernels that keep FJ_STACK_LDS_CURVES entries in LDS)
+    bool any_curves = false;
+    for (const auto &ps : hs.primsets) if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) any_curves = true;
+    const int lds_entries = (any_curves || S.has_motion) ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS;
+    if (need > lds_entries) {
+      const size_t entries = (size_t) (need - lds_entries) * persistent_threads();
       if (M.alloc(entries, &S.stack_overflow) || M.alloc(entries, &S.stack_overflow_shadow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
     sc->stack_need = need;

@@ -36,7 +36,10 @@ __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * 
 // walk builds it ONCE when the ray enters a curve set and keeps its 12 numbers in LDS
 // ([k][thread], lane consecutive) -- two square roots and two divisions less per curve tested,
 // more than half of the first-stage test.
-#define FJ_RAYSPACE_DOUBLES 12
+#define FJ_RAYSPACE_DOUBLES (12 + 14)     // the frame + one cached node of the subdivision (curve_ray)
+#ifndef FJ_CURVE_CACHE_LEVEL
+#define FJ_CURVE_CACHE_LEVEL 1
+#endif
 struct RaySpace {
   double *lds;          // s_rayspace + threadIdx.x
   __device__ __forceinline__ void set(V3 oo, V3 od) const
@@ -115,13 +118,34 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   double best_z = DBL_MAX, best_v = DBL_MAX;
   bool any = false;
   const uint32_t nleaf = 1u << depth;
+  // One node of the subdivision tree -- the level FJ_CURVE_CACHE_LEVEL ancestor of the current
+  // leaf -- is kept in LDS: the leaves (and pruned subtrees) below it start from there instead
+  // of from the root.  Same splits, same operands: only the repetition is gone.  (C5, level of
+  // the cached node 1 / 2 / 3: 5.19 / 5.26 / 5.46 s per frame, 5.41 s without.)
+  const int CL = FJ_CURVE_CACHE_LEVEL;
+  const bool use_cache = depth > CL;
+  double *cache = rsp.lds + 12 * BLOCK;
+  uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
   while (j < nleaf) {
     Bz b = root;
     double v0 = 0, vn = 1;
+    int L0 = 0;
+    const uint32_t pre = use_cache ? j >> (depth - CL) : 0u;
+    if (use_cache && cached == pre) {
+      b.c0 = mk(cache[0 * BLOCK], cache[1 * BLOCK], cache[2 * BLOCK]);
+      b.c1 = mk(cache[3 * BLOCK], cache[4 * BLOCK], cache[5 * BLOCK]);
+      b.c2 = mk(cache[6 * BLOCK], cache[7 * BLOCK], cache[8 * BLOCK]);
+      b.c3 = mk(cache[9 * BLOCK], cache[10 * BLOCK], cache[11 * BLOCK]);
+      b.w0 = cache[12 * BLOCK]; b.w1 = cache[13 * BLOCK];
+      v0 = (double) pre * (1. / (1 << CL));        // the interval of a level-CL node: exact dyadic numbers,
+      vn = (double) (pre + 1) * (1. / (1 << CL));  // as the repeated (v0 + vn) * .5 gives them
+      L0 = CL;
+    }
     bool pruned = false;
-    for (int L = 0;; L++) {
-      if (bz_misses_ray(b)) {
+    for (int L = L0;; L++) {
+      // (a node taken from the cache passed this test when it was stored)
+      if (!(L0 == CL && L == CL && use_cache) && bz_misses_ray(b)) {
         const uint32_t span = 1u << (depth - L);
         j = ((j / span) + 1) * span;
         pruned = true;
@@ -145,6 +169,16 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
         b.c0 = midP; b.c1 = q1; b.c2 = q2;
         b.w0 = wm;
         v0 = vm;
+      }
+      if (use_cache && L + 1 == CL) {
+        // the next iteration tests this node's bounds; if it fails the whole span is skipped
+        // and the entry is never asked for
+        cache[0 * BLOCK] = b.c0.x; cache[1 * BLOCK] = b.c0.y; cache[2 * BLOCK] = b.c0.z;
+        cache[3 * BLOCK] = b.c1.x; cache[4 * BLOCK] = b.c1.y; cache[5 * BLOCK] = b.c1.z;
+        cache[6 * BLOCK] = b.c2.x; cache[7 * BLOCK] = b.c2.y; cache[8 * BLOCK] = b.c2.z;
+        cache[9 * BLOCK] = b.c3.x; cache[10 * BLOCK] = b.c3.y; cache[11 * BLOCK] = b.c3.z;
+        cache[12 * BLOCK] = b.w0; cache[13 * BLOCK] = b.w1;
+        cached = pre;
       }
     }
     if (pruned) continue;

@@ -288,7 +288,7 @@ template <bool kCurves, bool kCount, bool kMotion>
 __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_SHADOW_MINB) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;

@@ -48,22 +48,24 @@ struct TravStack {
   uint32_t *ovf;        // overflow base + global thread id (null when no tree needs it)
   uint32_t ovf_stride;  // threads in the grid
   double *rayspace;     // curve scenes: s_rayspace + threadIdx.x (RaySpace), else null
+  int lds_n;            // entries kept in LDS (FJ_STACK_LDS, or FJ_STACK_LDS_CURVES)
   __device__ __forceinline__ void push(int &sp, uint32_t v) const
   {
-    if (sp < FJ_STACK_LDS) lds[sp * BLOCK] = v;
-    else ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride] = v;
+    if (sp < lds_n) lds[sp * BLOCK] = v;
+    else ovf[(size_t) (sp - lds_n) * ovf_stride] = v;
     sp++;
   }
   __device__ __forceinline__ uint32_t pop(int &sp) const
   {
     --sp;
-    return sp < FJ_STACK_LDS ? lds[sp * BLOCK] : ovf[(size_t) (sp - FJ_STACK_LDS) * ovf_stride];
+    return sp < lds_n ? lds[sp * BLOCK] : ovf[(size_t) (sp - lds_n) * ovf_stride];
   }
 };
 __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf, double *s_rayspace = nullptr)
 {
   TravStack st;
   st.lds = s_stack + threadIdx.x;
+  st.lds_n = s_rayspace ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS;
   st.rayspace = s_rayspace ? s_rayspace + threadIdx.x : nullptr;
   st.ovf_stride = gridDim.x * BLOCK;
   st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
@@ -333,7 +335,7 @@ template <bool kCurves, bool kCount, bool kMotion>
 __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;

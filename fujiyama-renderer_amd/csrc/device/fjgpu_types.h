@@ -28,6 +28,11 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 #define FJ_STACK_LDS 32              // traversal stack entries per lane kept in LDS; deeper
                                      // entries (rare) go to a global overflow area
 #endif
+// kernels instantiated with the ribbon test keep fewer stack entries in LDS: they also hold the
+// ray-space frame and one cached node of the curve subdivision per lane (fjgpu_dev_curve.h)
+#ifndef FJ_STACK_LDS_CURVES
+#define FJ_STACK_LDS_CURVES 24
+#endif
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
