@@ -246,6 +246,7 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
       e |= M.upload(h.curve_width.data(), h.curve_width.size(), &d.curve_width);
       e |= M.upload(h.curve_Cd.data(), h.curve_Cd.size(), &d.curve_Cd);
       e |= M.upload(h.curve_depth.data(), h.curve_depth.size(), &d.curve_depth);
+      e |= M.upload(h.curve_capsule.data(), h.curve_capsule.size(), &d.curve_capsule);
       e |= M.upload(h.curve_vel.data(), h.curve_vel.size(), &d.curve_vel);
     }
   }

@@ -30,6 +30,7 @@ struct HostPrimSet {
   std::vector<double> curve_width;    // [n][2]
   std::vector<float> curve_Cd;        // [n][6]
   std::vector<int8_t> curve_depth;    // [n]
+  std::vector<float> curve_capsule;   // [n][8] per BLAS slot: chord A, chord B, reach of the piece it encloses (static curves)
   std::vector<double> curve_vel;      // [n][12] or empty
   uint32_t root;
   double bounds[6];

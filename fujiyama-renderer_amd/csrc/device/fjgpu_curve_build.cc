@@ -122,7 +122,7 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
         r.bmax[a] = RoundUp2(mx[a] + pad);
         r.c[a] = (float) (.5 * (mn[a] + mx[a]));
       }
-      r.id = (uint32_t) i;
+      r.id = (uint32_t) i * (uint32_t) S + (uint32_t) sgm;      // curve and piece (split again after the build)
     }
   }
   // a ribbon test costs tens of node steps: ONE curve per leaf (the traversal's two-stage
@@ -130,8 +130,62 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   const int leaf = 1;
   float tc = .05f;
   if (const char *e = getenv("FJGPU_CURVE_TRAVCOST")) tc = (float) atof(e);
+  if ((uint64_t) c.n_curves * (uint64_t) S >= (1ull << 32)) { *err = "too many curves"; return FJGPU_EINVAL; }
   BuildBlas(ps, refs, leaf, tc);
   const int n = ps->n_prims;
+  // Per BLAS slot, the capsule of ITS piece: every point of the piece lies in the hull of the
+  // piece's control points, hence within max(dist(p1, AB), dist(p2, AB)) of the chord AB =
+  // (p0, p3) (distance to a segment is convex: its maximum over a hull is at a vertex); a ribbon
+  // hit puts the ray within the ribbon radius of a curve point.  A ray farther than
+  // `reach` from AB cannot hit the curve WITHIN this piece, and a hit in another piece is
+  // found when that piece's box is entered: the walk skips the ribbon test (whose first stage,
+  // the whole curve's box in ray space, lets 80 % of the candidates through).  Static curves
+  // only (reach = inf otherwise).  A and B are stored as f32; their rounding goes into reach.
+  std::vector<int> piece_of(n);
+  for (int s = 0; s < n; s++) { piece_of[s] = (int) (ps->prim_ids[s] % (uint32_t) S); ps->prim_ids[s] /= (uint32_t) S; }
+  ps->curve_capsule.assign((size_t) n * 8, 0.f);
+  for (int s = 0; s < n; s++) {
+    float *cap = &ps->curve_capsule[(size_t) s * 8];
+    const int i0 = c.indices[ps->prim_ids[s]];
+    if (c.velocity) { cap[6] = INFINITY; continue; }
+    double b[12];
+    for (int k = 0; k < 12; k++) b[k] = c.P[3 * i0 + k];
+    for (int d = seg_depth - 1; d >= 0; d--) {            // the same de Casteljau splits as above, one path
+      const bool right = ((piece_of[s] >> d) & 1) != 0;
+      double o[12];
+      for (int a = 0; a < 3; a++) {
+        const double p0 = b[a], p1 = b[3 + a], p2 = b[6 + a], p3 = b[9 + a];
+        const double q0 = .5 * (p0 + p1), q1 = .5 * (p1 + p2), q2 = .5 * (p2 + p3);
+        const double r0 = .5 * (q0 + q1), r1 = .5 * (q1 + q2);
+        const double m = .5 * (r0 + r1);
+        if (!right) { o[a] = p0; o[3 + a] = q0; o[6 + a] = r0; o[9 + a] = m; }
+        else { o[a] = m; o[3 + a] = r1; o[6 + a] = q2; o[9 + a] = p3; }
+      }
+      for (int k = 0; k < 12; k++) b[k] = o[k];
+    }
+    const double *A = b, *B = b + 9;
+    auto dist_to_chord = [&](const double *p) {
+      double u[3], w[3], uu = 0, uw = 0;
+      for (int a = 0; a < 3; a++) { u[a] = B[a] - A[a]; w[a] = p[a] - A[a]; uu += u[a] * u[a]; uw += u[a] * w[a]; }
+      double t = uu > 0 ? uw / uu : 0;
+      t = t < 0 ? 0 : (t > 1 ? 1 : t);
+      double d2 = 0;
+      for (int a = 0; a < 3; a++) { const double q = w[a] - t * u[a]; d2 += q * q; }
+      return std::sqrt(d2);
+    };
+    const double w0 = c.width[i0], w1 = c.width[i0 + 3];
+    const double radius = .5 * (w0 > w1 ? w0 : w1);
+    double reach = std::max(dist_to_chord(b + 3), dist_to_chord(b + 6)) + radius;
+    double slack = 0, scale = 0;
+    for (int a = 0; a < 3; a++) {
+      cap[a] = (float) A[a]; cap[3 + a] = (float) B[a];
+      slack += std::fabs(A[a] - (double) cap[a]) + std::fabs(B[a] - (double) cap[3 + a]);
+      scale = std::max(scale, std::max(std::fabs(A[a]), std::fabs(B[a])));
+    }
+    reach = reach * 1.000001 + slack + 1e-9 * scale + 1e-12;
+    cap[6] = std::nextafter((float) reach, INFINITY);
+    cap[7] = 0.f;
+  }
   ps->curve_cp.resize((size_t) n * 12);
   ps->curve_width.resize((size_t) n * 2);
   ps->curve_Cd.assign((size_t) n * 6, 0.f);

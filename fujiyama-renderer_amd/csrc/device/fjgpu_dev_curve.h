@@ -102,6 +102,28 @@ __device__ __forceinline__ bool bz_misses_ray(const Bz &b)
   return mnx >= radius || mxx <= -radius || mny >= radius || mxy <= -radius || mxz <= 1e-6;
 }
 
+// before any ribbon arithmetic: is the ray (as a line, object space) within `reach` of the chord
+// of the PIECE this BLAS slot stands for?  (fjgpu_curve_build.cc: a conservative capsule; a ray
+// outside it cannot hit the curve within this piece.)  Line-to-segment distance: the segment
+// parameter of the closest pair clamped to [0, 1] -- the distance is a convex function of it --
+// then the distance of that point to the line; 1e-6 of slack covers the arithmetic.
+__device__ __forceinline__ bool capsule_may_hit(const FJ_GLOBAL float *cap, V3 oo, V3 od)
+{
+  const double reach = (double) cap[6];
+  if (!(reach < 1e30)) return true;
+  const V3 A = mk((double) cap[0], (double) cap[1], (double) cap[2]);
+  const V3 u = mk((double) cap[3] - A.x, (double) cap[4] - A.y, (double) cap[5] - A.z);
+  const V3 w0 = A - oo;
+  const double a = dot(u, u), b = dot(u, od), c = dot(od, od), d = dot(u, w0), e = dot(od, w0);
+  const double D = a * c - b * b;
+  double sc = 0;
+  if (D > 1e-12 * a * c) { sc = (b * e - c * d) * filter_rcp(D); sc = sc < 0 ? 0 : (sc > 1 ? 1 : sc); }
+  const V3 S = w0 + sc * u;
+  const double tt = dot(S, od) * filter_rcp(c);
+  const V3 q = S - tt * od;
+  return dot(q, q) <= reach * reach * 1.000001;
+}
+
 // first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
 // (exactly the test curve_ray starts with: a curve rejected here is rejected there)
 __device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, const RaySpace &rsp)

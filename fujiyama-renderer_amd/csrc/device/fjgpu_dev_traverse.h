@@ -100,6 +100,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
                                            // dependent load in front of every node fetch
   uint32_t cur = TRAV_DONE;
   uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
+  uint32_t pend = 0xffffffffu;            // BLAS slot of a curve whose second-stage test is deferred (the lane walks on)
   int sp = 0;
 
   for (;;) {
@@ -140,7 +141,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     }
 
     // ---- lanes between instances: enter the next instance or retire the ray
-    if (have && cur == TRAV_DONE) {
+    if (have && cur == TRAV_DONE && (!kCurves || pend == 0xffffffffu)) {
       bool found = false;
       while (!dead_ray && ti < tend) {
         const DTNode *tn_ = &S.group_nodes[ti];
@@ -187,7 +188,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     for (int step = 0; step < TRAV_STEPS; step++) {
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
       if (__ballot(inner) == 0ull) break;
-      if (inner) {
+        if (inner) {
         const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
         if (kCount) lc->nodes++;
         // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
@@ -233,11 +234,15 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         // once per piece entered (same ray, same instance: same result)
         const size_t sl = first;
         const uint32_t cid = FJ_G(uint32_t, P->prim_ids)[sl];
-        if (cid != last_curve) {
+        if (cid != last_curve && (!P->curve_capsule || capsule_may_hit(FJ_G(float, P->curve_capsule) + sl * 8, oo, od))) {
           last_curve = cid;
           if (kCount) lc->prims++;
           const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
           deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace});
+          // the second stage is deferred: the lane remembers the curve and walks on (its result
+          // only shortens the ray or ends it -- the walk stays correct without it); a lane that
+          // already carries a deferred curve waits here instead
+          if (deep && pend == 0xffffffffu) { pend = (uint32_t) sl; deep = false; }
         }
       } else {
         for (uint32_t k = 0; k < cnt; k++) {
@@ -266,14 +271,16 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     // PMC on C5 showed 8.8 of 64 lanes active per VALU instruction when every lane ran it as
     // soon as it reached a curve): it waits until enough lanes need it, or nobody can walk on
     if (kCurves) {
-      const unsigned long long deepm = __ballot(have && deep);
-      if (deepm) {
-        const unsigned long long busym = __ballot(have && !deep && cur != TRAV_DONE);   // walkers and fresh leaves
-        if ((unsigned) __popcll(deepm) >= tune.leaf_wait || busym == 0ull) {
-          if (have && deep) {
-            deep = false;
+      const bool carrying = have && pend != 0xffffffffu;
+      const unsigned long long pendm = __ballot(carrying);
+      if (pendm) {
+        // lanes that can make progress without a second-stage result: at an inner node or a fresh leaf
+        const unsigned long long busym = __ballot(have && !deep && cur != TRAV_DONE);
+        if ((unsigned) __popcll(pendm) >= tune.leaf_wait || busym == 0ull) {
+                if (carrying) {
             bool stop = false;
-            const size_t sl = (cur & 0x7fffffffu) >> 3;
+            const size_t sl = pend;
+            pend = 0xffffffffu;
             const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
             double t, u = 0;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
@@ -288,8 +295,13 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
                 stop = anyhit;
               }
             }
-            if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
-            else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+            if (stop) { pol.finish(idx, best); have = false; deep = false; cur = TRAV_DONE; }
+            else if (deep) {
+              // the curve this lane was waiting at becomes the deferred one; walk on
+              pend = (cur & 0x7fffffffu) >> 3;
+              deep = false;
+              cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+            }
           }
         }
       }

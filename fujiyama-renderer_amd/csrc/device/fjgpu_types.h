@@ -55,6 +55,8 @@ struct DPrimSet {
   const double *curve_width;   // [n_curves][2]  end widths (BLAS order)
   const float *curve_Cd;       // [n_curves][6]  end colours (BLAS order)
   const int8_t *curve_depth;   // [n_curves]     cached split depth (BLAS order)
+  const float *curve_capsule;  // [n_curves][8]  A xyz, B xyz, reach, pad: the PIECE of the curve a BLAS slot stands for lies
+                               //                within `reach` (ribbon radius included) of the segment AB; or null
   const double *curve_vel;     // [n_curves][12] control-point velocities (BLAS order) or null: Curve::ray_intersect
                                //                moves each control point by time * velocity
   double bounds[6];            // Accelerator::bounds_ = primset bounds + 1e-4 (object space)
