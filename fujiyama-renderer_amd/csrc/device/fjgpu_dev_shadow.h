@@ -438,7 +438,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             gi++;
             const DInstance *I = &S.instances[tn_->inst];
             if (kCount) lc->insts++;
-            if (!box_ray_ref_fast(single ? G->sbounds : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+            // (a single-instance group's box: the light loop queued this ray BECAUSE this very test
+            // -- same box, same ray, same range -- passed there)
+            if (!single && !box_ray_ref_fast(I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
             oo = xpoint(I->Minv, o);
             od = xvector(I->Minv, d);
             if (has_negative_zero(od)) continue;
