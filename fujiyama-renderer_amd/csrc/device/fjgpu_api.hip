@@ -6,11 +6,13 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <chrono>
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fjgpu.h"
@@ -82,6 +84,7 @@ struct fjgpu_scene {
   struct Level { DRay *rays; DPath *paths; size_t cap; };
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   int max_children;                // most child rays one shading event can emit in this scene
+  bool bounce_diffuse, bounce_reflect, bounce_refract;   // bounce types some shader of the scene emits
   bool uses_sample_uid;            // sample times / random streams are keyed by (tile id << 20) + sample index
   DHit *d_hits;
   DLightRec *d_lrecs[2];           // double buffered: the shadow stream consumes one while shading fills the other
@@ -101,7 +104,21 @@ struct fjgpu_scene {
   double tri_record_bytes;         // 36 when every mesh is stored as f32 triangles, else 72
   size_t blas_nodes;
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
+  // frame-level buffers of fjgpu_render_frame_multi (lazily sized, freed with the scene)
+  float *d_frame = nullptr; size_t d_frame_n = 0;      // this device's framebuffer
+  float *d_slab = nullptr; size_t d_slab_n = 0;        // packed tiles: own ones (sender) / incoming (first device)
+  int32_t *d_rects = nullptr; size_t d_rects_n = 0;    // tile rectangles of a slab
 };
+
+static int grow(void **p, size_t *have, size_t want, size_t elem)
+{
+  if (*have >= want && *p) return 0;
+  if (*p) (void) hipFree(*p);
+  *p = nullptr; *have = 0;
+  if (hipMalloc(p, std::max<size_t>(want, 1) * elem) != hipSuccess) return -1;
+  *have = want;
+  return 0;
+}
 
 // Option "overlap_shadow": the light loop + shadow traversal of a level on their own stream,
 // concurrent with the next level's closest-hit work.  Measured on C3: the kernels do overlap,
@@ -117,6 +134,25 @@ static int enable_overlap(fjgpu_scene *sc)
   for (int k = 0; k < 2; k++)
     if (hipEventCreateWithFlags(&sc->ev_shadow_done[k], hipEventDisableTiming) != hipSuccess) return -1;
   return 0;
+}
+
+// A render description the tiler can work on: positive sizes and a region inside the frame.
+// The reference only asserts region min < max (src/fj_tiler.cc:75-76) and would write outside
+// its framebuffer for a region past the frame; this is a public C ABI, so it is refused.
+static const char *bad_tiling(const fj_render_desc *r)
+{
+  if (r->xres <= 0 || r->yres <= 0 || r->tile_w <= 0 || r->tile_h <= 0)
+    return "bad render settings: resolution and tilesize must be positive";
+  if (r->region[0] < 0 || r->region[1] < 0 || r->region[2] > r->xres || r->region[3] > r->yres ||
+      r->region[0] >= r->region[2] || r->region[1] >= r->region[3])
+    return "bad render settings: render_region must be a non-empty rectangle inside the frame";
+  return nullptr;
+}
+static const char *bad_render(const fj_render_desc *r)
+{
+  if (const char *why = bad_tiling(r)) return why;
+  if (r->rate_x <= 0 || r->rate_y <= 0) return "bad render settings: pixelsamples must be positive";
+  return nullptr;
 }
 
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip)
@@ -142,6 +178,7 @@ int fjgpu_device_count(void)
 int fjgpu_tile_count(const fj_render_desc *render)
 {
   if (!render) return 0;
+  if (const char *why = bad_tiling(render)) { (void) fail(FJGPU_EINVAL, why); return 0; }
   std::vector<fjgpu::TileRect> t;
   fjgpu::GenerateTiles(*render, &t);
   return (int) t.size();
@@ -149,7 +186,8 @@ int fjgpu_tile_count(const fj_render_desc *render)
 
 int fjgpu_tile_rect(const fj_render_desc *render, int tile_id, int32_t rect[4])
 {
-  if (!render) return FJGPU_EINVAL;
+  if (!render || !rect) return fail(FJGPU_EINVAL, "null argument");
+  if (const char *why = bad_tiling(render)) return fail(FJGPU_EINVAL, why);
   std::vector<fjgpu::TileRect> t;
   fjgpu::GenerateTiles(*render, &t);
   if (tile_id < 0 || tile_id >= (int) t.size()) return FJGPU_EINVAL;
@@ -157,24 +195,13 @@ int fjgpu_tile_rect(const fj_render_desc *render, int tile_id, int32_t rect[4])
   return 0;
 }
 
-int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
-{
-  if (!out) return fail(FJGPU_EINVAL, "null output handle");
-  *out = nullptr;
-  fjgpu::HostScene hs;
-  std::string err;
-  const auto t_build0 = std::chrono::steady_clock::now();
-  const bool device_build = g_device_build || getenv("FJGPU_DEVICE_BUILD") != nullptr;
-  const int be = fjgpu::BuildHostScene(desc, &hs, &err, device_build);
-  if (getenv("FJGPU_VERBOSE"))
-    fprintf(stderr, "fjgpu: host scene build (BLAS, transforms, lights) %.3f s\n",
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
-  if (be) return fail(be, err);
-  for (int i = 0; i < desc->n_shaders; i++) {
-    const int t = desc->shaders[i].type;
-    (void) t;
-  }
+}  // extern "C"
 
+// Upload a built host scene to one device (fjgpu_scene_create = build + upload; the multi-device
+// entry builds once and uploads to every device).
+static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int device, fjgpu_scene **out)
+{
+  *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(FJGPU_ENODEV, "no HIP device visible: the fjgpu core has no CPU fallback");
@@ -262,6 +289,42 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   std::memset(&S, 0, sizeof(S));
   e |= M.upload(dps.data(), dps.size(), &S.primsets);
   e |= M.upload(hs.instances.data(), hs.instances.size(), &S.instances);
+  {
+    // flat per-instance records of the lean any-hit walk (static mesh instances): node and
+    // triangle arrays as 32-bit offsets from the lowest of their addresses
+    uintptr_t lo = UINTPTR_MAX, hi = 0;
+    for (const DPrimSet &P : dps) {
+      if (P.type != FJ_PRIMSET_MESH || P.n_prims == 0) continue;
+      const uintptr_t pn = (uintptr_t) P.nodes, pt = (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts);
+      lo = std::min(lo, std::min(pn, pt)); hi = std::max(hi, std::max(pn, pt));
+    }
+    // (hipMalloc returns 256-byte aligned blocks: offsets in units of 128 B span 512 GB)
+    bool fits = lo != UINTPTR_MAX && lo % 128 == 0 && (hi - lo) / 128 < 0xffffffffull;
+    for (const DPrimSet &P : dps)
+      if (P.type == FJ_PRIMSET_MESH && P.n_prims > 0 &&
+          (((uintptr_t) P.nodes - lo) % 128 != 0 || ((uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts) - lo) % 128 != 0)) fits = false;
+    S.blas_base = fits ? (const char *) lo : nullptr;
+    if (!fits && lo != UINTPTR_MAX && getenv("FJGPU_VERBOSE"))
+      fprintf(stderr, "fjgpu: BLAS arrays span %zu bytes from %p: no 32-bit offsets, the general shadow walk is used\n", (size_t) (hi - lo), (void *) lo);
+    std::vector<DAnyInst> ai(hs.instances.size());
+    for (size_t i = 0; i < hs.instances.size(); i++) {
+      const DInstance &I = hs.instances[i];
+      const DPrimSet &P = dps[I.primset];
+      DAnyInst &a = ai[i];
+      std::memset(&a, 0, sizeof(a));
+      std::memcpy(a.Minv, I.Minv, sizeof(a.Minv));
+      std::memcpy(a.bounds, P.bounds, sizeof(a.bounds));
+      a.root = P.root;
+      a.n_prims = (P.type == FJ_PRIMSET_MESH && S.blas_base) ? P.n_prims : 0;
+      if (a.n_prims) {
+        const uintptr_t pt = (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts);
+        a.node_base = (uint32_t) (((uintptr_t) P.nodes - lo) / 128);
+        a.tri_base = (uint32_t) ((pt - lo) / 128);
+        a.tris_f32 = P.tri_verts32 ? 1 : 0;
+      }
+    }
+    e |= M.upload(ai.data(), ai.size(), &S.any_insts);
+  }
   e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
   e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
@@ -270,7 +333,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
   for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
-  S.pad_ = 0;
+  S.multi_instance_groups = 0;
+  for (const auto &g : hs.groups) if (g.n_instances > 1) S.multi_instance_groups = 1;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   S.lrec_hair = nullptr;
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
@@ -292,7 +356,8 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
     // (scenes with curve sets run the kernels that keep FJ_STACK_LDS_CURVES entries in LDS)
     bool any_curves = false;
     for (const auto &ps : hs.primsets) if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) any_curves = true;
-    const int lds_entries = (any_curves || S.has_motion) ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS;
+    (void) any_curves;
+    const int lds_entries = FJ_STACK_LDS_MIN;      // the kernel with the fewest LDS entries decides
     if (need > lds_entries) {
       const size_t entries = (size_t) (need - lds_entries) * persistent_threads();
       if (M.alloc(entries, &S.stack_overflow) || M.alloc(entries, &S.stack_overflow_shadow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
@@ -320,19 +385,62 @@ int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
   sc->cam_fov = hs.cam_fov;
   sc->n_light_samples = S.n_light_samples;
   sc->max_children = 0;
+  sc->bounce_diffuse = sc->bounce_reflect = sc->bounce_refract = false;
   sc->uses_sample_uid = S.has_motion || S.cam_xform != nullptr || S.has_area;
   for (int i = 0; i < desc->n_shaders; i++) {
     const fj_shader_desc &sh = desc->shaders[i];
     if (sh.type == FJ_SHADER_PATHTRACING) sc->uses_sample_uid = true;
     auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
     int k = 0;
-    if (sh.type == FJ_SHADER_PLASTIC) k = sh.do_reflect ? 1 : 0;
-    else if (sh.type == FJ_SHADER_GLASS) k = 2;
-    else if (sh.type == FJ_SHADER_PATHTRACING) k = (int) lum(sh.diffuse) + (int) lum(sh.reflect) + (int) lum(sh.refract);
+    if (sh.type == FJ_SHADER_PLASTIC) { k = sh.do_reflect ? 1 : 0; if (k) sc->bounce_reflect = true; }
+    else if (sh.type == FJ_SHADER_GLASS) { k = 2; sc->bounce_reflect = sc->bounce_refract = true; }
+    else if (sh.type == FJ_SHADER_PATHTRACING) {
+      k = (int) lum(sh.diffuse) + (int) lum(sh.reflect) + (int) lum(sh.refract);
+      if (lum(sh.diffuse)) sc->bounce_diffuse = true;
+      if (lum(sh.reflect)) sc->bounce_reflect = true;
+      if (lum(sh.refract)) sc->bounce_refract = true;
+    }
     sc->max_children = std::max(sc->max_children, k);
   }
   HIP_TRY(hipDeviceSynchronize());
   *out = sc.release();
+  return 0;
+}
+
+static int build_host_scene(const fj_scene_desc *desc, fjgpu::HostScene *hs)
+{
+  std::string err;
+  const auto t_build0 = std::chrono::steady_clock::now();
+  const bool device_build = g_device_build || getenv("FJGPU_DEVICE_BUILD") != nullptr;
+  const int be = fjgpu::BuildHostScene(desc, hs, &err, device_build);
+  if (getenv("FJGPU_VERBOSE"))
+    fprintf(stderr, "fjgpu: host scene build (BLAS, transforms, lights) %.3f s\n",
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count());
+  if (be) return fail(be, err);
+  return 0;
+}
+
+extern "C" {
+
+int fjgpu_scene_create(const fj_scene_desc *desc, int device, fjgpu_scene **out)
+{
+  if (!out || !desc) return fail(FJGPU_EINVAL, "null argument");
+  *out = nullptr;
+  fjgpu::HostScene hs;
+  if (const int be = build_host_scene(desc, &hs)) return be;
+  return upload_scene(desc, hs, device, out);
+}
+
+int fjgpu_scene_create_multi(const fj_scene_desc *desc, const int *devices, int n_devices, fjgpu_scene **out)
+{
+  if (!out || !desc || !devices || n_devices < 1) return fail(FJGPU_EINVAL, "bad argument");
+  for (int k = 0; k < n_devices; k++) out[k] = nullptr;
+  fjgpu::HostScene hs;                         // built once (the BLAS build is the expensive part), replicated
+  if (const int be = build_host_scene(desc, &hs)) return be;
+  for (int k = 0; k < n_devices; k++) {
+    const int e = upload_scene(desc, hs, devices[k], &out[k]);
+    if (e) { for (int j = 0; j < k; j++) { fjgpu_scene_destroy(out[j]); out[j] = nullptr; } return e; }
+  }
   return 0;
 }
 
@@ -341,9 +449,13 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   if (!scene) return;
   (void) hipSetDevice(scene->device);
   (void) hipDeviceSynchronize();
+  if (getenv("FJGPU_PHASE_STATS")) debug_phase_stats();
   if (scene->shadow_stream) (void) hipStreamDestroy(scene->shadow_stream);
   for (hipEvent_t e : scene->ev_shadow_done) if (e) (void) hipEventDestroy(e);
   for (hipEvent_t e : scene->ev_pool) (void) hipEventDestroy(e);
+  if (scene->d_frame) (void) hipFree(scene->d_frame);
+  if (scene->d_slab) (void) hipFree(scene->d_slab);
+  if (scene->d_rects) (void) hipFree(scene->d_rects);
   delete scene;
 }
 
@@ -356,7 +468,7 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
   // 1: shadow rays are walked by k_shadow_anyhit (every occluder opaque, no curves, no motion), 0: by k_shadow_trace
-  if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion) ? 1 : 0; return 0; }
+  if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion && scene->S.blas_base) ? 1 : 0; return 0; }
   return fail(FJGPU_EINVAL, "unknown query " + n);
 }
 
@@ -385,6 +497,10 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
 {
   if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap) {
     sc->work.reset(new DeviceBuffers());
+    // the adaptive sampler's buffers lived in the old arena (a new arena may be allocated at the
+    // old one's address, so the owner pointer alone does not tell)
+    sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
+    sc->d_aseen = sc->d_afinal = nullptr; sc->d_apstate = sc->d_acells = nullptr;
     DeviceBuffers &W = *sc->work;
     int e = 0;
     e |= W.alloc(samples * 2, &sc->d_suv);
@@ -451,8 +567,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   if (r->sampler_type != 0 && !adaptive) return fail(FJGPU_EINVAL, "unknown sampler_type");
   if (adaptive && (r->adaptive_max_subdivision < 0 || r->adaptive_max_subdivision > 8 || !(r->adaptive_subdivision_threshold >= 0)))
     return fail(FJGPU_EINVAL, "adaptive_max_subdivision must be in [0, 8] and adaptive_subdivision_threshold >= 0");
-  if (r->xres <= 0 || r->yres <= 0 || r->tile_w <= 0 || r->tile_h <= 0 || r->rate_x <= 0 || r->rate_y <= 0)
-    return fail(FJGPU_EINVAL, "bad render settings");
+  if (const char *why = bad_render(r)) return fail(FJGPU_EINVAL, why);
   HIP_TRY(hipSetDevice(sc->device));
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
 
@@ -477,6 +592,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
       ? (size_t) (a_div * (r->tile_w + 2 * margin[0]) + 1) * (size_t) (a_div * (r->tile_h + 2 * margin[1]) + 1)
       : (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
 
+  if (sc->uses_sample_uid && all.size() > 4096)
+    return fail(FJGPU_EUNSUPPORTED, "frames of more than 4096 tiles are not supported for scenes with motion blur, area lights or "
+        "PathtracingShader: their random streams are keyed by a 12-bit tile id (use a larger tilesize)");
   if (sc->uses_sample_uid && full_tile_samples > ((size_t) 1 << 20))
     return fail(FJGPU_EUNSUPPORTED, "tiles of more than 2^20 samples (tilesize x pixelsamples) are not supported for scenes with "
         "motion blur, area lights or PathtracingShader: their per-sample times and random streams are keyed by a 20-bit sample index");
@@ -489,30 +607,42 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
   const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
+  // recursion levels this scene can reach: one queue per level, level = bounces so far, and a
+  // bounce type only occurs if some shader of the scene emits it
+  const int deepest = (sc->bounce_diffuse ? std::max(0, r->max_diffuse_depth) : 0) +
+      (sc->bounce_reflect ? std::max(0, r->max_reflect_depth) : 0) + (sc->bounce_refract ? std::max(0, r->max_refract_depth) : 0);
+  if (sc->levels.size() < (size_t) deepest + 1) sc->levels.resize((size_t) deepest + 1, fjgpu_scene::Level{nullptr, nullptr, 0});
   long bt = sc->batch_tiles;
   if (bt <= 0) {
-    const size_t per_sample = 32 + 3 * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
+    const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
     const size_t target = std::min<size_t>((size_t) 160 << 20, (size_t) (.4 * (double) free_now) / per_sample);
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
   bt = std::min<long>(bt, (long) ids.size());
   bt = std::min<long>(bt, (long) (((size_t) 1 << 31) / full_tile_samples));   // sample slots are 32-bit
   if (bt < 1) bt = 1;
-  const size_t cap_samples = full_tile_samples * (size_t) bt;
-  // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
-  // max_children), so a queue never needs more than one entry per sample
-  // (small frames get queues of at least 8 M entries: with room for the worst-case fan-out the
-  // scheduler does not have to cut their levels into chunks of a few thousand rays)
-  const size_t cap_rays = std::max<size_t>(cap_samples, std::min<size_t>((size_t) 8 << 20, cap_samples * 16)) + 1024;
   sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
-  // one queue per recursion level: camera + every diffuse / reflect / refract bounce
-  {
-    const size_t nlev = 2 + (size_t) std::max(0, r->max_diffuse_depth) + std::max(0, r->max_reflect_depth) + std::max(0, r->max_refract_depth);
-    if (sc->levels.size() < nlev) sc->levels.resize(nlev, fjgpu_scene::Level{nullptr, nullptr, 0});
+  size_t cap_samples = 0, cap_rays = 0;
+  for (;;) {
+    cap_samples = full_tile_samples * (size_t) bt;
+    // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
+    // max_children), so a queue never needs more than one entry per sample
+    // (small frames get queues of at least 8 M entries: with room for the worst-case fan-out the
+    // scheduler does not have to cut their levels into chunks of a few thousand rays)
+    cap_rays = std::max<size_t>(cap_samples, std::min<size_t>((size_t) 8 << 20, cap_samples * 16)) + 1024;
+    bool ok = ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) == 0;
+    // every reachable level now, so that a failure shrinks the batch instead of ending the frame
+    for (int l = 0; ok && l <= deepest; l++) ok = ensure_level(sc, l, cap_rays) == 0;
+    if (ok) break;
+    (void) hipGetLastError();
+    if (bt == 1) return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
+    // another process holds part of the HBM: half the batch (the old arena is released first)
+    sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0;
+    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
+    sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
+    bt = std::max<long>(1, bt / 2);
   }
-  if (ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) || ensure_level(sc, 0, cap_rays))
-    return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
   // adaptive grid: split / leaf byte per lattice cell of every level (4/3 of the finest level)
   const size_t a_cells0_cap = adaptive ? (size_t) bt * (size_t) (r->tile_w + 2 * margin[0]) * (size_t) (r->tile_h + 2 * margin[1]) : 0;
   const size_t a_cell_bytes = a_cells0_cap * (((((size_t) 1) << (2 * (r->adaptive_max_subdivision + 1))) - 1) / 3);
@@ -542,7 +672,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   ShadowParams swp;
   swp.cos_half_pi = std::cos(3.14159265358979323846 / 2.);
   swp.cos_pi = std::cos(3.14159265358979323846);
-  swp.pad = 0;
+  swp.pre_resolve = (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) ? 1 : 0;   // the lean any-hit walk consumes the queue
   swp.cast_shadow = r->cast_shadow;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
   ResolveParams rp;
@@ -662,8 +792,10 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
       return 0;
     };
     std::function<int(int, uint32_t)> process = [&](int level, uint32_t count) -> int {
-      if (level + 1 >= (int) sc->levels.size()) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
-      if (ensure_level(sc, level + 1, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for a ray queue level");
+      // rays of the deepest reachable level cannot emit children (has_reached_bounce_limit):
+      // there is no next queue
+      const bool can_emit = level < deepest;
+      if (can_emit && ensure_level(sc, level + 1, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for a ray queue level");
       const uint32_t kids = (uint32_t) std::max(1, sc->max_children);
       const uint32_t chunk_max = kids <= 1 ? count : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
       for (uint32_t off = 0; off < count; off += chunk_max) {
@@ -683,7 +815,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         Sl.lrec_hair = sc->d_lhair[lb];
         e = timed(st, &acc.shade_ms, [&]() {
           return launch_shade(st, Sl, shp, rays, paths, sc->d_hits, n, sc->d_accum,
-              sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_lrecs[lb], sc->d_cnt);
+              can_emit ? sc->levels[level + 1].rays : nullptr, can_emit ? sc->levels[level + 1].paths : nullptr, sc->d_lrecs[lb], sc->d_cnt);
         });
         if (e) return e;
         DCounters hc;
@@ -727,6 +859,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
           if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[lb], sst); shadow_pending[lb] = true; }
         }
         if (hc.next_count) {
+          if (!can_emit) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
           e = process(level + 1, hc.next_count);
           if (e) return e;
         }
@@ -820,21 +953,109 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   return 0;
 }
 
+// One frame on G devices of this process: the reference's worker pool (execute_rendering,
+// src/fj_renderer.cc:747-791; MtRunParallelLoop, src/fj_multi_thread.cc:86-132) with GPUs for
+// workers.  Tile k of the list goes to scene k % G (interleaved deal: neighbouring tiles cost
+// alike), every device renders its share on its own host thread, packs the finished tiles into
+// one slab, and the slab crosses xGMI as one peer copy into the first device, which scatters it
+// into the frame; the frame goes to the host once.
+int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_render_desc *r,
+    const int32_t *tile_ids, int n_tiles, float *h_fb, fjgpu_stats *stats)
+{
+  if (!scenes || n_scenes < 1 || !r || !h_fb) return fail(FJGPU_EINVAL, "null argument");
+  for (int k = 0; k < n_scenes; k++) if (!scenes[k]) return fail(FJGPU_EINVAL, "null scene");
+  if (const char *why = bad_render(r)) return fail(FJGPU_EINVAL, why);
+  std::vector<fjgpu::TileRect> all;
+  fjgpu::GenerateTiles(*r, &all);
+  std::vector<int32_t> ids;
+  if (tile_ids) ids.assign(tile_ids, tile_ids + std::max(0, n_tiles));
+  else for (size_t i = 0; i < all.size(); i++) ids.push_back((int32_t) i);
+  for (int32_t id : ids) if (id < 0 || id >= (int32_t) all.size()) return fail(FJGPU_EINVAL, "tile id out of range");
+  const int G = n_scenes;
+  const size_t npx = (size_t) r->xres * r->yres;
+  const int tile_px = r->tile_w * r->tile_h;
+  std::vector<std::vector<int32_t>> mine(G);
+  for (size_t k = 0; k < ids.size(); k++) mine[k % G].push_back(ids[k]);
+  fjgpu_scene *first = scenes[0];
+
+  // the first device's frame and the staging area for the other devices' slabs
+  HIP_TRY(hipSetDevice(first->device));
+  if (grow((void **) &first->d_frame, &first->d_frame_n, npx * 4, sizeof(float))) return fail(FJGPU_ENOMEM, "device allocation failed for the frame");
+  HIP_TRY(hipMemset(first->d_frame, 0, npx * 4 * sizeof(float)));
+  std::vector<size_t> stage_off(G, 0);
+  size_t stage_px = 0, rects_n = 0;
+  for (int d = 1; d < G; d++) { stage_off[d] = stage_px; stage_px += mine[d].size() * (size_t) tile_px; rects_n += mine[d].size(); }
+  if (G > 1) {
+    if (grow((void **) &first->d_slab, &first->d_slab_n, stage_px * 4, sizeof(float)) ||
+        grow((void **) &first->d_rects, &first->d_rects_n, rects_n * 4, sizeof(int32_t)))
+      return fail(FJGPU_ENOMEM, "device allocation failed for the tile slabs");
+  }
+
+  std::vector<int> rcs(G, 0);
+  std::vector<std::string> errs(G);
+  std::vector<fjgpu_stats> sts(G);
+  auto work = [&](int d) {
+    fjgpu_scene *sc = scenes[d];
+    fjgpu_stats &st = sts[d];
+    std::memset(&st, 0, sizeof(st));
+    auto bad = [&](int code, const std::string &m) { rcs[d] = code; errs[d] = m; };
+    if (hipSetDevice(sc->device) != hipSuccess) return bad(FJGPU_ENODEV, "hipSetDevice failed");
+    if (mine[d].empty()) return;
+    float *fb = first->d_frame;
+    if (d > 0) {
+      // (a second scene on the first device -- a test set-up -- still renders into its own frame)
+      if (grow((void **) &sc->d_frame, &sc->d_frame_n, npx * 4, sizeof(float)) ||
+          grow((void **) &sc->d_slab, &sc->d_slab_n, mine[d].size() * (size_t) tile_px * 4, sizeof(float)) ||
+          grow((void **) &sc->d_rects, &sc->d_rects_n, mine[d].size() * 4, sizeof(int32_t)))
+        return bad(FJGPU_ENOMEM, "device allocation failed for a device's frame");
+      fb = sc->d_frame;
+    }
+    const int e = fjgpu_render_tiles(sc, r, mine[d].data(), (int) mine[d].size(), fb, nullptr, &st);
+    if (e) return bad(e, fjgpu_last_error());
+    if (d > 0) {
+      std::vector<int32_t> rects(mine[d].size() * 4);
+      for (size_t k = 0; k < mine[d].size(); k++) {
+        const fjgpu::TileRect &t = all[mine[d][k]];
+        rects[4 * k] = t.xmin; rects[4 * k + 1] = t.ymin; rects[4 * k + 2] = t.xmax; rects[4 * k + 3] = t.ymax;
+      }
+      if (hipMemcpy(sc->d_rects, rects.data(), rects.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return bad(FJGPU_ENODEV, "rect upload failed");
+      if (launch_move_tiles(nullptr, false, fb, r->xres, sc->d_rects, (int) mine[d].size(), tile_px, sc->d_slab)) return bad(FJGPU_ENODEV, "pack launch failed");
+      // one peer copy per device: over xGMI when peer access is available, staged by the runtime otherwise
+      const size_t bytes = mine[d].size() * (size_t) tile_px * 4 * sizeof(float);
+      if (hipMemcpyPeer(first->d_slab + stage_off[d] * 4, first->device, sc->d_slab, sc->device, bytes) != hipSuccess)
+        return bad(FJGPU_ENODEV, std::string("peer copy of a tile slab: ") + hipGetErrorString(hipGetLastError()));
+    }
+  };
+  if (G == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < G; d++) th.emplace_back(work, d);
+    for (auto &t : th) t.join();
+  }
+  for (int d = 0; d < G; d++) if (rcs[d]) return fail(rcs[d], "device " + std::to_string(scenes[d]->device) + ": " + errs[d]);
+
+  HIP_TRY(hipSetDevice(first->device));
+  if (G > 1) {
+    std::vector<int32_t> rects;
+    for (int d = 1; d < G; d++)
+      for (int32_t id : mine[d]) { const fjgpu::TileRect &t = all[id]; rects.insert(rects.end(), {t.xmin, t.ymin, t.xmax, t.ymax}); }
+    if (!rects.empty()) {
+      HIP_TRY(hipMemcpy(first->d_rects, rects.data(), rects.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      if (launch_move_tiles(nullptr, true, first->d_frame, r->xres, first->d_rects, (int) (rects.size() / 4), tile_px, first->d_slab))
+        return fail(FJGPU_ENODEV, "unpack launch failed");
+    }
+  }
+  HIP_TRY(hipMemcpy(h_fb, first->d_frame, npx * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  if (stats) for (int d = 0; d < G; d++) stats[d] = sts[d];
+  return 0;
+}
+
 int fjgpu_render_frame(fjgpu_scene *sc, const fj_render_desc *r, float *h_fb, fjgpu_stats *stats)
 {
-  if (!sc || !r || !h_fb) return fail(FJGPU_EINVAL, "null argument");
-  HIP_TRY(hipSetDevice(sc->device));
-  const size_t n = (size_t) r->xres * r->yres * 4;
-  float *d_fb = nullptr;
-  HIP_TRY(hipMalloc(&d_fb, n * sizeof(float)));
-  (void) hipMemset(d_fb, 0, n * sizeof(float));
-  const int rc = fjgpu_render_tiles(sc, r, nullptr, 0, d_fb, nullptr, stats);
-  hipError_t ce = hipSuccess;
-  if (rc == 0) ce = hipMemcpy(h_fb, d_fb, n * sizeof(float), hipMemcpyDeviceToHost);
-  (void) hipFree(d_fb);
-  if (rc) return rc;
-  if (ce != hipSuccess) return fail(FJGPU_ENODEV, std::string("framebuffer copy: ") + hipGetErrorString(ce));
-  return 0;
+  fjgpu_scene *one[1] = {sc};
+  if (!sc) return fail(FJGPU_EINVAL, "null argument");
+  return fjgpu_render_frame_multi(one, 1, r, nullptr, 0, h_fb, stats);
 }
 
 int fjgpu_trace(fjgpu_scene *sc, int group, int n, const double *rays, double *out_t, int32_t *out_ids,

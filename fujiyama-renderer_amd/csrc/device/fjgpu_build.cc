@@ -333,8 +333,8 @@ struct Builder {
     DNode &w = wide[me];
     for (int i = 0; i < 4; i++) {
       for (int a = 0; a < 3; a++) {
-        w.box[i][a] = i < k ? c[i].mn[a] : FLT_MAX;
-        w.box[i][3 + a] = i < k ? c[i].mx[a] : -FLT_MAX;
+        w.box[i][2 * a] = i < k ? c[i].mn[a] : FLT_MAX;
+        w.box[i][2 * a + 1] = i < k ? c[i].mx[a] : -FLT_MAX;
       }
       w.child[i] = child[i];
       w.pad[i] = 0;
@@ -441,7 +441,14 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err, bool de
   if (bad) { *err = "mesh index out of range"; return FJGPU_EINVAL; }
   tm.lap("primitive boxes", m.n_faces);
   for (int k = 0; k < 3; k++) { ps->grid_cell[k] = 0; ps->grid_n[k] = 0; }
-  BuildBlas(ps, refs, FJ_MAX_LEAF_PRIMS, 1.2f);    // a node step ~ 1.2 triangle tests
+  {
+    // experiment knobs: leaf size / SAH cost of a node step in triangle tests
+    int max_leaf = FJ_MAX_LEAF_PRIMS;
+    float trav_cost = 1.2f;                        // a node step ~ 1.2 triangle tests
+    if (const char *e = getenv("FJGPU_MAX_LEAF")) max_leaf = atoi(e);
+    if (const char *e = getenv("FJGPU_TRAV_COST")) trav_cost = (float) atof(e);
+    BuildBlas(ps, refs, max_leaf, trav_cost);
+  }
   tm.lap("BLAS total", m.n_faces);
   // pre-gathered vertices in leaf order; as f32 when that loses nothing (meshes read from
   // PLY files carry f32 coordinates): half the bytes per triangle test, identical operands

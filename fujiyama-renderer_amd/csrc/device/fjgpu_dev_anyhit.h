@@ -1,0 +1,324 @@
+// fjgpu_dev_anyhit.h -- the lean any-hit walk: shadow rays of scenes in which every possible
+// occluder is opaque (Os = 1) and no curve set / time-sampled transform exists -- the common
+// case and the dominant kernel of C1-C3.
+// Part of the kernels translation unit: included by fjgpu_kernels.hip only (device code,
+// compiled with -ffp-contract=off; see the header of that file).
+#ifndef FJGPU_DEV_ANYHIT_H
+#define FJGPU_DEV_ANYHIT_H
+
+// Same tests, same instances, same result (occluded or not) as traverse_persistent with
+// any-hit rays (SlIlluminance's shadow SlTrace, src/fj_shading.cc:338-355, through
+// Accelerator::Intersect -> TriRayIntersect); what is gone is the closest-hit bookkeeping.
+//
+// Scheduling.  A lane is in one of three states: TURNOVER (no BLAS walk in progress: idle,
+// just finished, or between the instances of a group), INNER (at a 4-wide node) or LEAF
+// (holding 1..4 triangles).  Every iteration the WAVE executes exactly one phase -- the one
+// most lanes wait for (turnover once enough lanes collected there, or when nothing else can
+// run) -- instead of all phases in sequence with whoever happens to be there: lanes pile up
+// where the wave is not, so a phase runs with most of the wave (measured before: turnover ran
+// with 17, inner steps with 42, triangle tests with 16 of 64 lanes).  The leaf phase tests ONE
+// triangle per lane and execution, so lanes with 1 and 4 triangles do not wait for each other.
+//
+// Box tests are the conservative f32 slab test (slab32_test, fjgpu_dev_math.h): 3 packed
+// fma + 8 min/max per box instead of 12 conversions + 24 f64 operations.
+//
+// Entry.  The light loop has already tested the (single) instance box of single-instance
+// shadow groups and writes ~instance into the queue entry: the walk reads one flat record
+// (DAnyInst) and starts.  Groups with several instances walk the threaded instance BVH here.
+// lane id the compiler cannot treat as a loop invariant
+__device__ __forceinline__ uint32_t opaque_lane_id()
+{
+  uint32_t t;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+  return t;
+}
+#ifndef FJ_NO_SCHED_FENCE
+#define FJ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FJ_SCHED_FENCE() do { } while (0)
+#endif
+#ifdef FJ_PHASE_STATS
+// debug build only: wave-level phase executions and the lanes active in them
+__device__ unsigned long long g_phase[16];
+#define PH(i, v) do { ph[i] += (unsigned long long) (v); } while (0)
+#else
+#define PH(i, v) do { } while (0)
+#endif
+#ifdef FJ_EXP_SLAB_VALIDATE
+__device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
+#endif
+
+// kMulti = false: every shadow group of the scene has one instance, so every queue entry carries
+// its instance (the instance-BVH walk and its registers are compiled out).
+template <bool kCount, bool kMulti>
+__device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
+    uint32_t n, uint32_t *head, uint32_t *s_stack, LocalCounters *lc)
+{
+  const unsigned lane = __lane_id();
+  // Per-lane traversal stack: FJ_STACK_LDS_ANYHIT entries in LDS ([depth][thread]), deeper ones
+  // in the global overflow area ([depth][global thread]; the builder reports the worst case).
+  // Addresses are rebuilt from the thread index where they are needed: loop-invariant pointers
+  // held in registers were what the compiler spilled (and reloaded before every push).
+  // (the lane id comes from a volatile asm: a plain threadIdx.x expression is hoisted out of the
+  // loop as an invariant and then spilled all the same)
+  const uint32_t wave_first = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;     // SGPR
+#define AH_TID() (wave_first + opaque_lane_id())
+#define AH_LDS(depth) s_stack[(depth) * BLOCK + AH_TID()]
+#define AH_OVF(depth) S.stack_overflow_shadow[(size_t) ((depth) - FJ_STACK_LDS_ANYHIT) * (gridDim.x * BLOCK) + (size_t) blockIdx.x * BLOCK + AH_TID()]
+  auto push = [&](int &sp_, uint32_t v) { if (sp_ < FJ_STACK_LDS_ANYHIT) AH_LDS(sp_) = v; else AH_OVF(sp_) = v; sp_++; };
+  auto pop = [&](int &sp_) -> uint32_t { --sp_; return sp_ < FJ_STACK_LDS_ANYHIT ? AH_LDS(sp_) : AH_OVF(sp_); };
+  bool head_live = true;                   // wave-uniform: the global head still has entries
+  uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
+  tune.grab = adaptive_grab(tune.grab, n);
+  bool have = false;                       // the lane holds a ray whose fate is open
+  uint32_t idx = 0;
+  V3 oo = mk(0, 0, 0), od = oo;
+  Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#ifdef FJ_EXP_SLAB_VALIDATE
+  V3 inv_keep = oo;
+#endif
+  float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
+  const float tmin32 = 9.9999e-5f;         // <= .0001
+  int gi = 0, gend = 0;                    // cursor in the group's instance BVH; gi < 0: ~instance, settled by the light loop
+  uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base
+  bool tris_f32 = true;
+  uint32_t cur = TRAV_DONE;
+  int sp = 0;
+  const double tmin = .0001;
+#ifdef FJ_PHASE_STATS
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+  for (;;) {
+    PH(0, 1);
+    const bool fin = cur == TRAV_DONE;
+    const bool at_leaf = !fin && (cur & FJ_LEAF_FLAG);
+    const bool at_inner = !fin && !at_leaf;
+    const unsigned long long m_leaf = __ballot(at_leaf), m_inner = __ballot(at_inner);
+    const unsigned n_leaf = (unsigned) __popcll(m_leaf), n_inner = (unsigned) __popcll(m_inner);
+    // lanes for which a turnover does something: a ray to retire / move on, or a new one to fetch
+    const bool can_fetch = head_live || next < range_end;
+    const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
+    const unsigned n_turn = (unsigned) __popcll(m_turn);
+
+    if (n_turn >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
+      if (m_turn == 0ull) break;           // nothing in flight, nothing left to fetch
+      PH(1, 1); PH(2, n_turn);
+      // ---- turnover: retire, fetch, enter
+      if (next >= range_end && head_live) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
+        base = __shfl(base, 0);
+        if (base >= n) head_live = false;
+        else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
+      }
+      bool fetch = false;
+      if (fin) {
+        fetch = true;
+        if (have) {
+          if (kMulti && gi < gend) fetch = false;    // the group has more instances: the same ray goes on
+          else {
+            // reached the light: add c (an opaque occluder would have added c * (1 - Os) = 0)
+            const DShadowRay *q = &squeue[idx];
+            float *acc = s_accum + 4 * (size_t) q->sample;
+            const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
+            if (r0 != 0.f) atomicAdd(acc + 0, r0);
+            if (r1 != 0.f) atomicAdd(acc + 1, r1);
+            if (r2 != 0.f) atomicAdd(acc + 2, r2);
+            have = false;
+          }
+        }
+      }
+      const unsigned long long m_fetch = __ballot(fetch);
+      if (fetch) {
+        const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t) (m_fetch >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_fetch, 0u));   // set bits below this lane
+        if (my < range_end) {
+          const int g = squeue[my].group;
+          if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
+            have = true;
+            idx = my;
+            if (!kMulti || g < 0) { gi = g; gend = 0; }
+            else { gi = S.groups[g].first; gend = gi + S.groups[g].count; }
+          }
+        }
+      }
+      next += (uint32_t) __popcll(m_fetch);
+      if (next > range_end) next = range_end;
+      if (fin && have) {
+        const DShadowRay *q = &squeue[idx];
+        const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
+        const double tmax = q->tmax;
+        V3 winv = o;
+        bool plain = false, single = false, dead = false;
+        if (kMulti && gi >= 0) {
+          // BoxRayIntersect's -0.0 quirk: such a ray fails every box test in the reference
+          dead = has_negative_zero(d);
+          winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
+          plain = plain_dir(d);
+          single = S.groups[q->group].n_instances == 1;
+          if (dead) gi = gend;
+        }
+        for (;;) {
+          int inst = -1;
+          if (gi < 0) { inst = ~gi; gi = gend = 0; if (kCount) lc->insts++; }     // its box test passed in the light loop
+          else if (!kMulti) break;
+          else {
+            while (gi < gend) {
+              const DTNode *tn_ = &S.group_nodes[gi];
+              if (tn_->inst < 0) {         // inner node of the instance BVH
+                double tq;
+                gi = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? gi + 1 : tn_->skip;
+                continue;
+              }
+              gi++;
+              if (kCount) lc->insts++;
+              // (a single-instance group's box: the light loop queued this ray BECAUSE that test passed)
+              if (!single && !box_ray_ref_fast(S.instances[tn_->inst].wbounds, o, d, winv, plain, tmin, tmax)) continue;
+              inst = tn_->inst;
+              break;
+            }
+            if (inst < 0) break;           // no instance left: the ray reaches the light (next turnover)
+          }
+          const DAnyInst *A = &S.any_insts[inst];
+          if (A->n_prims == 0) continue;
+          oo = xpoint(A->Minv, o);
+          od = xvector(A->Minv, d);
+          if (has_negative_zero(od)) continue;
+          const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
+          double tn;
+          if (!slab(A->bounds, A->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
+          s32 = slab32_setup(oo, inv, A->bounds);
+#ifdef FJ_EXP_SLAB_VALIDATE
+          inv_keep = mk(1. / od.x, 1. / od.y, 1. / od.z);
+#endif
+          tmax32 = f32_above(tmax);
+          node_base = A->node_base; tri_base = A->tri_base; tris_f32 = A->tris_f32 != 0;
+          cur = A->root; sp = 0;
+          break;
+        }
+      }
+      continue;
+    }
+
+    if (n_inner >= n_leaf) {
+      // ---- inner nodes: one 128-byte node per lane; further steps without a new vote while at
+      // least tune.min_inner lanes stay at inner nodes
+      for (uint32_t step = 0;; step++) {
+      const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
+      if (step > 0) {
+        const unsigned n_now = (unsigned) __popcll(__ballot(in_now));
+        if (step >= tune.anyhit_steps || n_now < tune.min_inner) break;
+        PH(3, 1); PH(4, n_now);
+      } else { PH(3, 1); PH(4, n_inner); }
+      // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
+      const bool deep = __ballot(in_now && sp + 3 > FJ_STACK_LDS_ANYHIT) != 0ull;
+      if (in_now) {
+        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (S.blas_base + ((size_t) (node_base + cur) << 7));
+        if (kCount) lc->nodes++;
+        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
+        float tq;
+        // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
+        const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &tq);
+        FJ_SCHED_FENCE();
+        const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &tq);
+        FJ_SCHED_FENCE();
+        const bool h2 = slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &tq) && e.z != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h3 = slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &tq) && e.w != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+#ifdef FJ_EXP_SLAB_VALIDATE
+        {   // every box the f64 test accepts must be accepted by the f32 test
+          double td;
+          const bool g0 = slab_f32box(q0.xy, q0.zw, q1.xy, oo, inv_keep, tmin, tmax, &td);
+          const bool g1 = slab_f32box(q1.zw, q2.xy, q2.zw, oo, inv_keep, tmin, tmax, &td);
+          const bool g2 = e.z != FJ_NO_CHILD && slab_f32box(q3.xy, q3.zw, q4.xy, oo, inv_keep, tmin, tmax, &td);
+          const bool g3 = e.w != FJ_NO_CHILD && slab_f32box(q4.zw, q5.xy, q5.zw, oo, inv_keep, tmin, tmax, &td);
+          const int lost = (int) (g0 && !h0) + (int) (g1 && !h1) + (int) (g2 && !h2) + (int) (g3 && !h3);
+          const int extra = (int) (h0 && !g0) + (int) (h1 && !g1) + (int) (h2 && !g2) + (int) (h3 && !g3);
+          if (lost) atomicAdd(&g_slab_lost, (unsigned long long) lost);
+          if (extra) atomicAdd(&g_slab_extra, (unsigned long long) extra);
+          atomicAdd(&g_slab_tests, (unsigned long long) (2 + (e.z != FJ_NO_CHILD) + (e.w != FJ_NO_CHILD)));
+        }
+#endif
+        // any hit ends the ray and 7 of 8 rays reach the light, so the visiting order is free:
+        // no distance sort (children are stored by decreasing surface area)
+        uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
+        if (!h2) { r2 = r3; }
+        if (!h1) { r1 = r2; r2 = r3; }
+        if (!h0) { r0 = r1; r1 = r2; r2 = r3; }
+        const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
+        if (nh == 0) cur = (sp == 0) ? TRAV_DONE : pop(sp);
+        else {
+          cur = r0;
+          if (!deep) {
+            // three unconditional stores (whatever lies above the new top is dead) instead of
+            // three predicated ones
+            uint32_t *top = &AH_LDS(sp);
+            top[0] = r1; top[BLOCK] = r2; top[2 * BLOCK] = r3;
+            sp += nh - 1;
+          } else {
+            if (nh > 1) push(sp, r1);
+            if (nh > 2) push(sp, r2);
+            if (nh > 3) push(sp, r3);
+          }
+        }
+      }
+      }
+    } else {
+      // ---- leaves: ONE triangle per lane; the first hit inside [tmin, tmax] ends the ray
+      PH(5, 1); PH(6, n_leaf);
+      if (at_leaf) {
+        const uint32_t first = (cur & 0x7fffffffu) >> 3;
+        const uint32_t more = cur & 7u;
+        double t, u, v;
+        if (kCount) lc->prims++;
+        const double tmax = squeue[idx].tmax;
+        V3 v0, v1, v2;
+        const char *tris = S.blas_base + ((size_t) tri_base << 7);
+        load_tri(tris_f32 ? nullptr : (const double *) tris, tris_f32 ? (const float *) tris : nullptr, first, &v0, &v1, &v2);
+        if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+          have = false; cur = TRAV_DONE;     // occluded: nothing to add
+          PH(10, 1);
+        }
+        else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
+        else cur = (sp == 0) ? TRAV_DONE : pop(sp);
+      }
+    }
+  }
+#undef AH_LDS
+#undef AH_OVF
+#undef AH_TID
+#ifdef FJ_PHASE_STATS
+  // 0-6 are wave-uniform tallies (lane 0 speaks for the wave); 10 was counted by single lanes
+  for (int i = 0; i < 16; i++) {
+    const unsigned long long v = i == 10 ? wave_sum(ph[i]) : ph[i];
+    if (lane == 0 && v) atomicAdd(&g_phase[i], v);
+  }
+#endif
+}
+
+// blocks per CU (= waves per SIMD): 96 VGPRs without a spill for the single-instance walk; the
+// instance-BVH walk of the general one needs 128 (with spills a frame took twice as long)
+#ifndef FJ_ANYHIT_MINB
+#define FJ_ANYHIT_MINB 5
+#endif
+#ifndef FJ_ANYHIT_MINB_MULTI
+#define FJ_ANYHIT_MINB_MULTI 4
+#endif
+template <bool kCount, bool kMulti>
+__global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
+    DCounters *cnt, TravTune tune)
+{
+  __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
+  const uint32_t n = cnt->shadow_count;
+  LocalCounters lc = {0, 0, 0};
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
+  if (kCount) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->squeued, (unsigned long long) n);
+  }
+}
+
+#endif

@@ -26,6 +26,7 @@ __device__ __forceinline__ V3 normalize(V3 a)
 // stack also waits for the node or triangle fetch in flight.  These arrays are global memory.
 #define FJ_GLOBAL __attribute__((address_space(1)))
 typedef float fj_v4f __attribute__((ext_vector_type(4)));
+typedef float fj_v2f __attribute__((ext_vector_type(2)));
 typedef uint32_t fj_v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
@@ -63,13 +64,78 @@ __device__ __forceinline__ bool slab(const double bmin[3], const double bmax[3],
   return tn <= tf;
 }
 
-__device__ __forceinline__ bool slab_f32box(const float *bmin, const float *bmax, V3 o, V3 inv,
+// the f64 test on a DNode child box ((min, max) pairs); kept for validation builds
+__device__ __forceinline__ bool slab_f32box(fj_v2f px, fj_v2f py, fj_v2f pz, V3 o, V3 inv,
     double tmin, double tmax, double *tnear)
 {
-  const double mn[3] = {(double) bmin[0], (double) bmin[1], (double) bmin[2]};
-  const double mx[3] = {(double) bmax[0], (double) bmax[1], (double) bmax[2]};
+  const double mn[3] = {(double) px.x, (double) py.x, (double) pz.x};
+  const double mx[3] = {(double) px.y, (double) py.y, (double) pz.y};
   return slab(mn, mx, o, inv, tmin, tmax, tnear);
 }
+
+// ---- conservative f32 slab test on the BLAS node boxes (culling only).
+// DNode stores a child's box as three (min, max) pairs, so one packed fma yields both plane
+// distances of an axis.  Per (ray, instance) and axis a the entry code keeps
+//   i = (float)(1/od_a),  o = (float)(oo_a/od_a),  e = 3.6e-7 (Bmax_a |i| + |o|),
+//   l = -(o + e),  h = e - o,     Bmax_a >= |any box coordinate| of the primitive set.
+// For a box plane b (f32) the exact distance is t = (b - oo_a)/od_a.  t~ = fmaf(b, i, -o)
+// differs from t by at most |b/od| 2^-24 (rounding of i) + |oo/od| 2^-24 (rounding of o; the
+// f64 reciprocal and product before it are good to 2^-49) + |t~| 2^-24 (the fma's rounding)
+// <= 2^-23 (Bmax |i| + |o|)(1 + 2^-18) =: E.  e is 3 E; folding it into the addend costs
+// another 2^-24 |o + e|, so fmaf(b, i, l) <= t - E' and fmaf(b, i, h) >= t + E' with E' > E:
+// [min over the two planes of the l-variant, max of the h-variant] contains the exact slab
+// interval, and the f64 interval of slab_f32box (own error ~2^-52).  Whatever the f64 test
+// accepts this one accepts: it can only cull less.  An axis whose e is not a finite number
+// below 1e30 (direction component zero or denormal: 1/od = inf) gets i = 0, l = -1e30,
+// h = 1e30: interval [-1e30, 1e30], it never culls.  With e < 1e30 every product is finite or
+// an infinity of one sign: no NaN can arise (box coordinates are finite).
+// one axis: t_lo = fmaf(b, i, l), t_hi = fmaf(b, i, h).  (Plain values, no pointers into a
+// struct: the compiler kept a by-reference Slab32 in scratch memory.)
+struct Slab32Axis { float i, l, h; };
+struct Slab32 { Slab32Axis x, y, z; };
+
+// inv = 1/od good to 2^-49 (filter_rcp) or exact
+__device__ __forceinline__ Slab32Axis slab32_axis(double inv, double oo, double bmax_abs)
+{
+  const float i = (float) inv, o = (float) (oo * inv);
+  // (node boxes are rounded outward from the f64 bounds by up to 2 ulp: the factor covers 8)
+  const float e = 3.6e-7f * ((float) bmax_abs * 1.000001f * fabsf(i) + fabsf(o));
+  const bool ok = e < 1e30f;
+  Slab32Axis a;
+  a.i = ok ? i : 0.f;
+  a.l = ok ? -(o + e) : -1e30f;
+  a.h = ok ? e - o : 1e30f;
+  return a;
+}
+
+// bounds = {min xyz, max xyz} of the primitive set (every node box lies inside)
+__device__ __forceinline__ Slab32 slab32_setup(V3 oo, V3 inv, const double *bounds)
+{
+  Slab32 s;
+  s.x = slab32_axis(inv.x, oo.x, fmax(fabs(bounds[0]), fabs(bounds[3])));
+  s.y = slab32_axis(inv.y, oo.y, fmax(fabs(bounds[1]), fabs(bounds[4])));
+  s.z = slab32_axis(inv.z, oo.z, fmax(fabs(bounds[2]), fabs(bounds[5])));
+  return s;
+}
+
+// px py pz = the (min, max) pairs of a child box; tmin32 <= tmin and tmax32 >= tmax of the ray.
+// *tnear = conservative entry distance (an ordering key for the closest-hit walk).
+__device__ __forceinline__ bool slab32_test(fj_v2f px, fj_v2f py, fj_v2f pz, const Slab32 s, float tmin32, float tmax32, float *tnear)
+{
+  const fj_v2f lx = __builtin_elementwise_fma(px, (fj_v2f) (s.x.i), (fj_v2f) (s.x.l));
+  const fj_v2f hx = __builtin_elementwise_fma(px, (fj_v2f) (s.x.i), (fj_v2f) (s.x.h));
+  const fj_v2f ly = __builtin_elementwise_fma(py, (fj_v2f) (s.y.i), (fj_v2f) (s.y.l));
+  const fj_v2f hy = __builtin_elementwise_fma(py, (fj_v2f) (s.y.i), (fj_v2f) (s.y.h));
+  const fj_v2f lz = __builtin_elementwise_fma(pz, (fj_v2f) (s.z.i), (fj_v2f) (s.z.l));
+  const fj_v2f hz = __builtin_elementwise_fma(pz, (fj_v2f) (s.z.i), (fj_v2f) (s.z.h));
+  const float tn = fmaxf(fmaxf(fmaxf(fminf(lx.x, lx.y), fminf(ly.x, ly.y)), fminf(lz.x, lz.y)), tmin32);
+  const float tf = fminf(fminf(fminf(fmaxf(hx.x, hx.y), fmaxf(hy.x, hy.y)), fmaxf(hz.x, hz.y)), tmax32);
+  *tnear = tn;
+  return tn <= tf;
+}
+// f32 bounds of an f64 ray range: down / up to the neighbouring float
+__device__ __forceinline__ float f32_below(double x) { const float f = (float) x; return (double) f <= x ? f : nextafterf(f, -INFINITY); }
+__device__ __forceinline__ float f32_above(double x) { const float f = (float) x; return (double) f >= x ? f : nextafterf(f, INFINITY); }
 
 // Reference quirk kept for identical results: BoxRayIntersect (src/fj_box.cc:73-138)
 // branches on `dir >= 0`, which is true for -0.0, and then divides by -0.0: the

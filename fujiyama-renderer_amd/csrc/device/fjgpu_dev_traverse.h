@@ -61,11 +61,11 @@ struct TravStack {
     return sp < lds_n ? lds[sp * BLOCK] : ovf[(size_t) (sp - lds_n) * ovf_stride];
   }
 };
-__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf, double *s_rayspace = nullptr)
+__device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf, double *s_rayspace = nullptr, int lds_entries = 0)
 {
   TravStack st;
   st.lds = s_stack + threadIdx.x;
-  st.lds_n = s_rayspace ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS;
+  st.lds_n = lds_entries ? lds_entries : (s_rayspace ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS);
   st.rayspace = s_rayspace ? s_rayspace + threadIdx.x : nullptr;
   st.ovf_stride = gridDim.x * BLOCK;
   st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
@@ -86,7 +86,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   tune.grab = adaptive_grab(tune.grab, n);
   bool have = false;
   uint32_t idx = 0;
-  V3 o = mk(0, 0, 0), oo = o, od = o, inv = o, d = o, winv = o;
+  V3 o = mk(0, 0, 0), oo = o, od = o, d = o, winv = o;
+  Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};        // conservative f32 slab constants of (ray, instance)
   double tmin = 0, tmax = 0, rtime = 0;
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
@@ -169,11 +170,12 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           od = xvector(I->Minv, d);
         }
         if (has_negative_zero(od)) continue;
-        inv = mk(1. / od.x, 1. / od.y, 1. / od.z);
+        const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
         P = &S.primsets[I->primset];
         nodes = P->nodes;
         if (P->n_prims == 0) continue;
         if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+        s32 = slab32_setup(oo, inv, P->bounds);
         found = true;
         break;
       }
@@ -191,22 +193,19 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (inner) {
         const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
         if (kCount) lc->nodes++;
-        // 128-byte node: eight 16-byte loads (4 child boxes + 4 child refs)
+        // 128-byte node: seven 16-byte loads (4 child boxes as (min, max) pairs + 4 child refs)
         const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
         const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
-        const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-        const float b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-        const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
-        const float b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
         const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
-        double t0, t1, t2, t3;
-        const bool h0 = slab_f32box(b0, b0 + 3, oo, inv, tmin, tf2, &t0);                          // slot 0 always exists
-        const bool h1 = slab_f32box(b1, b1 + 3, oo, inv, tmin, tf2, &t1);                          // slot 1 always exists
-        const bool h2 = e.z != FJ_NO_CHILD && slab_f32box(b2, b2 + 3, oo, inv, tmin, tf2, &t2);
-        const bool h3 = e.w != FJ_NO_CHILD && slab_f32box(b3, b3 + 3, oo, inv, tmin, tf2, &t3);
+        const float tmin32 = f32_below(tmin), tmax32 = f32_above(tf2);
+        float t0, t1, t2, t3;
+        const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);                          // slot 0 always exists
+        const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);                          // slot 1 always exists
+        const bool h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
+        const bool h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
         // near-to-far order is a heuristic only: f32 keys, misses sort last
-        float k0 = h0 ? fminf((float) t0, FLT_MAX) : INFINITY, k1 = h1 ? fminf((float) t1, FLT_MAX) : INFINITY;
-        float k2 = h2 ? fminf((float) t2, FLT_MAX) : INFINITY, k3 = h3 ? fminf((float) t3, FLT_MAX) : INFINITY;
+        float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY;
+        float k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
         uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
 #define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
         FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)

@@ -37,7 +37,7 @@ struct ShadeParams {
 
 struct ShadowParams {
   double cos_half_pi, cos_pi;  // cos(PI/2.), cos(PI) evaluated by the host libm
-  uint32_t pad;
+  uint32_t pre_resolve;        // 1: queue entries of single-instance groups carry ~instance (lean any-hit walk)
   uint32_t queue_capacity;     // entries of the shadow-ray queue
   int32_t cast_shadow;
 };
@@ -58,6 +58,10 @@ void shadow_queue_reset(hipStream_t st, DCounters *cnt);
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events);
+// multi-GPU frame: pack a device's tiles (d_rects [n][4] = xmin ymin xmax ymax) into a slab of
+// tile_px pixels per tile, or scatter such a slab into the framebuffer (unpack)
+int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *slab);
+void debug_phase_stats();     // FJ_PHASE_STATS builds: print and reset the any-hit walk's phase tallies (stderr)
 // threads of the largest persistent grid (sizes per-thread scratch such as the stack overflow area)
 size_t persistent_threads();
 

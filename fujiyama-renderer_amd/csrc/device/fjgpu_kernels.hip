@@ -11,14 +11,15 @@
 //                         instance loop -> 4-wide BLAS, LDS stack -> FP64 Moller-Trumbore)
 //   fjgpu_dev_shade.h     k_gen_camera (sampler + Camera::GetRay), k_shade (trace_surface's
 //                         attribute setup + the shader plugins; light records and child rays)
-//   fjgpu_dev_shadow.h    k_shadow_cull (SlIlluminance light loop), k_shadow_trace,
-//                         k_shadow_anyhit (lean any-hit walk)
+//   fjgpu_dev_shadow.h    k_shadow_cull (SlIlluminance light loop), k_shadow_trace
+//   fjgpu_dev_anyhit.h    k_shadow_anyhit (lean any-hit walk: phase-scheduled, f32 slabs)
 //   here                  k_resolve (reconstruct_image / apply_pixel_filter), host launchers
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 
 #include "fjgpu_types.h"
 #include "fjgpu_kernels.h"
@@ -31,6 +32,7 @@
 #include "fjgpu_dev_traverse.h"
 #include "fjgpu_dev_shade.h"
 #include "fjgpu_dev_shadow.h"
+#include "fjgpu_dev_anyhit.h"
 #include "fjgpu_dev_adaptive.h"
 
 // ------------------------------------------------------------------ k_resolve
@@ -86,10 +88,27 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(ResolveParams rp, const TileD
   }
 }
 
+// ---------------------------------------------------------- k_move_tiles
+// Multi-GPU frame (fjgpu_render_frame_multi): a device's finished tiles are packed into one
+// contiguous slab (tile k at k * tile_px pixels), the slab crosses xGMI as ONE peer copy, and
+// the first device scatters it into its framebuffer.  kUnpack = false: framebuffer -> slab.
+template <bool kUnpack>
+__global__ void __launch_bounds__(BLOCK) k_move_tiles(float4 *fb, int xres, const int4 *rects, int tile_px, float4 *slab)
+{
+  const int4 r = rects[blockIdx.y];
+  const int w = r.z - r.x, h = r.w - r.y;
+  for (int p = blockIdx.x * BLOCK + threadIdx.x; p < w * h; p += gridDim.x * BLOCK) {
+    const size_t at = (size_t) (r.y + p / w) * xres + (r.x + p % w);
+    const size_t to = (size_t) blockIdx.y * tile_px + p;
+    if (kUnpack) fb[at] = slab[to]; else slab[to] = fb[at];
+  }
+}
+
 // ----------------------------------------------------------- host launchers
 // persistent launches: at most PERSIST_BLOCKS_PER_CU resident blocks per CU
 #define PERSIST_BLOCKS_PER_CU 4
-static unsigned persistent_grid(unsigned long long blocks_needed)
+#define PERSIST_BLOCKS_PER_CU_MAX 8      // no kernel launches more (sizes per-thread scratch)
+static unsigned persistent_grid(unsigned long long blocks_needed, int blocks_per_cu = PERSIST_BLOCKS_PER_CU)
 {
   static int cus = 0;
   if (cus == 0) {
@@ -98,25 +117,35 @@ static unsigned persistent_grid(unsigned long long blocks_needed)
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const unsigned long long cap = (unsigned long long) cus * PERSIST_BLOCKS_PER_CU;
+  const unsigned long long cap = (unsigned long long) cus * blocks_per_cu;
   return (unsigned) (blocks_needed < cap ? (blocks_needed ? blocks_needed : 1) : cap);
 }
 
-size_t persistent_threads() { return (size_t) persistent_grid(~0ull) * BLOCK; }
+size_t persistent_threads() { return (size_t) persistent_grid(~0ull, PERSIST_BLOCKS_PER_CU_MAX) * BLOCK; }
+
+// blocks per CU of the lean any-hit walk: what its registers and LDS stack allow
+static int anyhit_blocks_per_cu(bool multi)
+{
+  int b = multi ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB;
+  if (const char *e = getenv("FJGPU_ANYHIT_BLOCKS")) b = atoi(e);
+  if (b < 1) b = 1;
+  if (b > PERSIST_BLOCKS_PER_CU_MAX) b = PERSIST_BLOCKS_PER_CU_MAX;
+  return b;
+}
 
 static TravTune trav_tune()
 {
   static TravTune t = {0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
-    t.refill = env("FJGPU_TRAV_REFILL", 24);
+    t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 256);
     // lean any-hit walk: up to `anyhit_steps` inner steps per iteration, the 2nd and later ones only
     // while at least `min_inner` lanes are at inner nodes (C3 -4.5 ms, C6 -30 ms; the general walk
     // keeps the fixed 3: incoherent rays (C4) and curve leaves (C5) lost 2-7 % with it)
-    t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 6);
-    t.min_inner = env("FJGPU_TRAV_MININNER", 32);
+    t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 4);
+    t.min_inner = env("FJGPU_TRAV_MININNER", 24);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
@@ -177,7 +206,7 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
 // the rays of every recursion level instead of once per level.
 uint32_t shadow_queue_padding()          // every resident wave may leave one partially filled chunk
 {
-  return persistent_grid(1ull << 30) * (BLOCK / 64) * SQ_CHUNK;
+  return persistent_grid(1ull << 30, PERSIST_BLOCKS_PER_CU_MAX) * (BLOCK / 64) * SQ_CHUNK;
 }
 
 void shadow_queue_reset(hipStream_t st, DCounters *cnt)
@@ -202,11 +231,11 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
-  if (S.all_opaque && !S.has_curves && !S.has_motion) {
-    if (count_events)
-      hipLaunchKernelGGL(k_shadow_anyhit<true>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
-    else
-      hipLaunchKernelGGL(k_shadow_anyhit<false>, dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+  if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
+#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
+    if (S.multi_instance_groups) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
+    else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
+#undef FJ_LAUNCH_ANYHIT
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
@@ -216,6 +245,36 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
   }
   LAUNCH_CHECK();
   return 0;
+}
+
+int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *slab)
+{
+  if (n_tiles <= 0) return 0;
+  const dim3 grid((tile_px + BLOCK - 1) / BLOCK, n_tiles);
+  if (unpack) hipLaunchKernelGGL(k_move_tiles<true>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects, tile_px, (float4 *) slab);
+  else hipLaunchKernelGGL(k_move_tiles<false>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects, tile_px, (float4 *) slab);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+void debug_phase_stats()
+{
+#ifdef FJ_EXP_SLAB_VALIDATE
+  unsigned long long lost = 0, extra = 0, tests = 0;
+  (void) hipMemcpyFromSymbol(&lost, HIP_SYMBOL(g_slab_lost), sizeof(lost));
+  (void) hipMemcpyFromSymbol(&extra, HIP_SYMBOL(g_slab_extra), sizeof(extra));
+  (void) hipMemcpyFromSymbol(&tests, HIP_SYMBOL(g_slab_tests), sizeof(tests));
+  fprintf(stderr, "fjgpu phase slab32 validation: %llu box tests, %llu lost (must be 0), %llu extra\n", tests, lost, extra);
+#endif
+#ifdef FJ_PHASE_STATS
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
+  static const char *names[16] = {"iters", "entry_execs", "entry_lanes", "inner_execs", "inner_lanes", "leaf_execs", "leaf_lanes",
+      "tri_execs", "tri_lanes", "", "hits", "refills", "", "", "", ""};
+  for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-12s %llu\n", names[i], h[i]);
+  unsigned long long z[16] = {0};
+  (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+#endif
 }
 
 int launch_resolve(hipStream_t st, const ResolveParams &rp, const TileDesc *d_tiles, int n_tiles, int max_tile_pixels,

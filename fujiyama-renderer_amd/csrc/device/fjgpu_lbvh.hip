@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(LB) k_collapse(Tree T, const Box6 *boxes, cons
       if (half_area(bx[b]) > half_area(bx[a])) { const Box6 tb = bx[a]; bx[a] = bx[b]; bx[b] = tb; const uint32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr; }
   DNode w;
   for (int i = 0; i < 4; i++) {
-    for (int c = 0; c < 3; c++) { w.box[i][c] = i < k ? bx[i].mn[c] : FLT_MAX; w.box[i][3 + c] = i < k ? bx[i].mx[c] : -FLT_MAX; }
+    for (int c = 0; c < 3; c++) { w.box[i][2 * c] = i < k ? bx[i].mn[c] : FLT_MAX; w.box[i][2 * c + 1] = i < k ? bx[i].mx[c] : -FLT_MAX; }
     w.pad[i] = 0;
     if (i >= k) { w.child[i] = FJ_NO_CHILD; continue; }
     if (is_leaf_range(T, ref[i])) { w.child[i] = leaf_ref_of(T, ref[i]); continue; }

@@ -12,7 +12,7 @@
 // child ref: 0xffffffff -> no child; bit 31 set -> leaf, payload = (first_prim << 3) |
 //            (count - 1); else index of the child DNode.
 struct DNode {
-  float box[4][6];             // child k: min xyz, max xyz
+  float box[4][6];             // child k: (min, max) pairs of x, y, z -- one packed fma per axis (slab32_test)
   uint32_t child[4];
   uint32_t pad[4];
 };
@@ -33,6 +33,11 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 #ifndef FJ_STACK_LDS_CURVES
 #define FJ_STACK_LDS_CURVES 24
 #endif
+// the lean any-hit walk runs more blocks per CU: 24 entries x 1 KB per block
+#ifndef FJ_STACK_LDS_ANYHIT
+#define FJ_STACK_LDS_ANYHIT 24
+#endif
+#define FJ_STACK_LDS_MIN 24          // smallest of the three (sizes the global overflow area)
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
@@ -86,6 +91,22 @@ struct DInstance {
                                // the time-0 matrices); -1 = static
   int32_t pad[2];
 };
+
+// Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
+// load after the queue entry instead of instance -> primitive set -> pointers)
+struct DAnyInst {
+  double Minv[12];             // world -> object
+  double bounds[6];            // the primitive set's padded box (object space)
+  // node and triangle arrays as 32-bit offsets from DScene.blas_base (two registers per lane
+  // instead of four), both in units of 128 B
+  uint32_t node_base;
+  uint32_t tri_base;           // pre-gathered triangles: f32 (36 B) or f64 (72 B) records
+  uint32_t root;
+  uint32_t tris_f32;           // 1: f32 records
+  int32_t n_prims;
+  uint32_t pad[3];
+};
+static_assert(sizeof(DAnyInst) == 176, "DAnyInst layout");
 
 // Instance level of a group: a THREADED bounding-volume hierarchy (depth-first node list with
 // skip links, no stack).  Walk: i = first; a leaf (inst >= 0) is a candidate instance, go to
@@ -141,6 +162,9 @@ struct DScene {
   const DLightSample *light_samples;
   DLightHair *lrec_hair;       // work buffer (set per render call) or null
   const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
+  const DAnyInst *any_insts;       // [n_instances] (static mesh instances; the lean any-hit walk)
+  const char *blas_base;           // lowest address of any BLAS node / triangle array (DAnyInst offsets); null: the
+                                   // arrays do not fit 32-bit offsets and the general shadow walk is used
   int32_t n_light_samples;
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
@@ -156,7 +180,7 @@ struct DScene {
   const double *time_tab;      // draw k of the per-tile time stream (sample index in the tile -> [0,1])
   double time_start, time_end; // Renderer sample_time_range
   int32_t has_motion;          // any time-sampled instance transform: traversal / shading evaluate them
-  int32_t pad_;
+  int32_t multi_instance_groups;   // some group has more than one instance (else every shadow-queue entry names its instance)
   // camera (static case): eye, matrix rows, uv_size
   double cam_M[12];
   double cam_uv_size[2];
@@ -208,7 +232,8 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
   double o[3], d[3], tmax;
   float c[3];                  // W * Kd * Cl: added to the sample, scaled by (1 - occluder Os)
   uint32_t sample;
-  int32_t group;
+  int32_t group;               // shadow target group; or ~instance when the light loop already settled that this
+                               // one instance is the only candidate (single-instance group, lean any-hit walk)
   uint32_t tindex;             // sample index in its tile: the ray's time is time_tab[tindex] (motion blur)
 };
 

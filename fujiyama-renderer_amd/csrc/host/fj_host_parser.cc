@@ -294,5 +294,13 @@ int  fj_SiSetProperty3(long i, const char *n, double a, double b, double c) { re
 int  fj_SiSetProperty4(long i, const char *n, double a, double b, double c, double d) { return SiSetProperty4(i, n, a, b, c, d); }
 int  fj_SiSetStringProperty(long i, const char *n, const char *s) { return SiSetStringProperty(i, n, s); }
 int  fj_SiSetSampleProperty3(long i, const char *n, double a, double b, double c, double t) { return SiSetSampleProperty3(i, n, a, b, c, t); }
+int  fj_SiSetFrameReportCallback(long r, void *data, fj_frame_callback start, fj_frame_callback abort_, fj_frame_callback done)
+{
+  return SiSetFrameReportCallback(r, data, (FrameStartCallback) start, (FrameAbortCallback) abort_, (FrameDoneCallback) done);
+}
+int  fj_SiSetTileReportCallback(long r, void *data, fj_tile_callback start, fj_sample_callback sample_done, fj_tile_callback done)
+{
+  return SiSetTileReportCallback(r, data, (TileStartCallback) start, (SampleDoneCallback) sample_done, (TileDoneCallback) done);
+}
 
 }  // extern "C"

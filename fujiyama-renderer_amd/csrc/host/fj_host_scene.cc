@@ -467,60 +467,80 @@ static int render_scene(Scene *sc, Renderer *ren)
   fb->Resize(ren->d.xres, ren->d.yres, 4);          // preprocess_framebuffer, src/fj_renderer.cc:805-816
   if (g_deferred_render) return 0;
 
-  fjgpu_scene *gs = nullptr;
-  int err = fjgpu_scene_create(&sc->desc, 0, &gs);
+  // Workers are GPUs: `thread_count` devices, or every visible one with `use_max_thread`
+  // (Renderer::GetThreadCount, src/fj_renderer.cc:632-641); FJ_GPU_DEVICES caps it.
+  int ndev = fjgpu_device_count();
+  if (ndev < 1) { g_last_error = "no HIP device visible: the fjgpu core has no CPU fallback"; return -1; }
+  int want = ren->use_max_thread ? ndev : std::min(ndev, std::max(1, ren->thread_count));
+  if (const char *e = getenv("FJ_GPU_DEVICES")) want = std::max(1, std::min(want, atoi(e)));
+  std::vector<int> devices(want);
+  for (int k = 0; k < want; k++) devices[k] = k;
+  std::vector<fjgpu_scene *> gs(want, nullptr);
+  int err = fjgpu_scene_create_multi(&sc->desc, devices.data(), want, gs.data());
   if (err) { g_last_error = std::string("fjgpu_scene_create: ") + fjgpu_last_error(); return -1; }
+  auto destroy_all = [&]() { for (fjgpu_scene *g : gs) fjgpu_scene_destroy(g); };
   const double t1 = now_s();
 
   const int ntiles = fjgpu_tile_count(&sc->render);
   fj::FrameInfo finfo;
-  finfo.frame_id = 1; finfo.worker_count = 1; finfo.tile_count = ntiles;
+  finfo.frame_id = 1; finfo.worker_count = want; finfo.tile_count = ntiles;
   finfo.xres = ren->d.xres; finfo.yres = ren->d.yres;
   finfo.frame_region.min.x = ren->d.region[0]; finfo.frame_region.min.y = ren->d.region[1];
   finfo.frame_region.max.x = ren->d.region[2]; finfo.frame_region.max.y = ren->d.region[3];
   finfo.framebuffer = fb;
-  if (ren->frame_start && ren->frame_start(ren->frame_data, &finfo) == fj::CALLBACK_INTERRUPT) { fjgpu_scene_destroy(gs); return -1; }
+  // render_frame_start: an interrupt here ends execute_rendering with an error before any tile
+  // (src/fj_renderer.cc:774-777)
+  if (ren->frame_start && ren->frame_start(ren->frame_data, &finfo) == fj::CALLBACK_INTERRUPT) { destroy_all(); return -1; }
 
-  // tile start hooks (may cancel the frame, src/fj_renderer.cc:1030-1046,1106-1118)
-  std::vector<int32_t> tile_ids;
-  bool cancelled = false;
-  for (int t = 0; t < ntiles && !cancelled; t++) {
+  auto tile_info = [&](int t) {
     fj::TileInfo ti;
     int32_t rect[4];
     fjgpu_tile_rect(&sc->render, t, rect);
-    ti.frame_id = 1; ti.worker_id = 0; ti.region_id = t; ti.total_region_count = ntiles;
+    ti.frame_id = 1; ti.worker_id = t % want; ti.region_id = t; ti.total_region_count = ntiles;
     ti.tile_region.min.x = rect[0]; ti.tile_region.min.y = rect[1]; ti.tile_region.max.x = rect[2]; ti.tile_region.max.y = rect[3];
     ti.framebuffer = fb;
-    if (ren->tile_start && ren->tile_start(ren->tile_data, &ti) == fj::CALLBACK_INTERRUPT) { cancelled = true; break; }
+    return ti;
+  };
+  // Tile start hooks, in queue order.  The reference's worker pool stops handing out tiles once
+  // a tile_start hook returns CALLBACK_INTERRUPT (render_tile -> LoopStatus::Cancel,
+  // src/fj_renderer.cc:1098-1121; src/fj_multi_thread.cc:75-79,127-130): that tile and all
+  // later ones are never rendered, the tiles started before it are finished and reported, and
+  // execute_rendering still reports the frame as done and returns 0 (src/fj_renderer.cc:787-790;
+  // nothing in the reference ever invokes the frame_abort hook).  Same here: the frame that is
+  // submitted holds exactly the tiles whose hook said CONTINUE.
+  std::vector<int32_t> tile_ids;
+  for (int t = 0; t < ntiles; t++) {
+    const fj::TileInfo ti = tile_info(t);
+    if (ren->tile_start && ren->tile_start(ren->tile_data, &ti) == fj::CALLBACK_INTERRUPT) break;
     tile_ids.push_back(t);
   }
 
-  fjgpu_stats st;
-  std::memset(&st, 0, sizeof(st));
+  std::vector<fjgpu_stats> st(want);
+  std::memset(st.data(), 0, sizeof(fjgpu_stats) * want);
   const double t2 = now_s();
-  err = fjgpu_render_frame(gs, &sc->render, fb->GetWritable(0, 0, 0), &st);
+  err = fjgpu_render_frame_multi(gs.data(), want, &sc->render, tile_ids.data(), (int) tile_ids.size(), fb->GetWritable(0, 0, 0), st.data());
   const double t3 = now_s();
-  if (err) g_last_error = std::string("fjgpu_render_frame: ") + fjgpu_last_error();
-  fjgpu_scene_destroy(gs);
+  if (err) g_last_error = std::string("fjgpu_render_frame_multi: ") + fjgpu_last_error();
+  destroy_all();
   if (err) return -1;
 
-  // sample_done is reported once per tile batch, tile_done once per tile
-  if (ren->sample_done) ren->sample_done(ren->tile_data);
+  // sample_done is reported once per frame (a per-sample host call is infeasible; an interrupt
+  // from it has nothing left to stop), tile_done once per rendered tile
+  if (ren->sample_done) (void) ren->sample_done(ren->tile_data);
   for (int32_t t : tile_ids) {
-    fj::TileInfo ti;
-    int32_t rect[4];
-    fjgpu_tile_rect(&sc->render, t, rect);
-    ti.frame_id = 1; ti.worker_id = 0; ti.region_id = t; ti.total_region_count = ntiles;
-    ti.tile_region.min.x = rect[0]; ti.tile_region.min.y = rect[1]; ti.tile_region.max.x = rect[2]; ti.tile_region.max.y = rect[3];
-    ti.framebuffer = fb;
+    const fj::TileInfo ti = tile_info(t);
     if (ren->tile_done) ren->tile_done(ren->tile_data, &ti);
   }
   if (ren->frame_done) ren->frame_done(ren->frame_data, &finfo);
 
   g_last_stats.prepare_seconds = t1 - t0;
   g_last_stats.render_seconds = t3 - t2;
-  g_last_stats.rays = st.rays;
-  return cancelled ? -1 : 0;
+  std::memset(&g_last_stats.rays, 0, sizeof(g_last_stats.rays));
+  for (const fjgpu_stats &x : st) {
+    g_last_stats.rays.camera += x.rays.camera; g_last_stats.rays.shadow += x.rays.shadow; g_last_stats.rays.diffuse += x.rays.diffuse;
+    g_last_stats.rays.reflect += x.rays.reflect; g_last_stats.rays.refract += x.rays.refract;
+  }
+  return 0;
 }
 
 }  // namespace fjhost

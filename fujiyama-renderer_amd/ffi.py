@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(PKG_DIR, "lib")
+# FJGPU_LIBDIR: an experiment build of the same libraries (scripts/build_variant.sh)
+LIB_DIR = os.environ.get("FJGPU_LIBDIR") or os.path.join(PKG_DIR, "lib")
 
 
 class RayCounts(C.Structure):          # fj_ray_counts

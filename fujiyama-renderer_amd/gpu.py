@@ -28,6 +28,9 @@ def lib():
         L.fjgpu_render_frame.argtypes = [C.c_void_p, C.POINTER(ffi.RenderDesc), C.c_void_p, C.POINTER(ffi.GpuStats)]
         L.fjgpu_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(ffi.GpuStats)]
+        L.fjgpu_scene_create_multi.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.fjgpu_render_frame_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ffi.RenderDesc), C.c_void_p, C.c_int,
+                                               C.c_void_p, C.POINTER(ffi.GpuStats)]
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.fjgpu_global_option.argtypes = [C.c_char_p, C.c_long]
         L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
@@ -100,6 +103,43 @@ class Scene(object):
         _check(lib().fjgpu_trace(self._h, group, n, rays.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
                                  ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p), C.byref(st)))
         return t, ids, uv, st
+
+
+class MultiScene(object):
+    """The same scene resident on several devices (fjgpu_scene_create_multi): one host-side
+    build, one upload per entry of `devices` (an index may repeat: two replicas on one device
+    exercise the multi-device path on a single GPU)."""
+
+    def __init__(self, scene_desc_ptr, devices):
+        self.n = len(devices)
+        self._h = (C.c_void_p * self.n)()
+        devs = (C.c_int * self.n)(*devices)
+        _check(lib().fjgpu_scene_create_multi(scene_desc_ptr, devs, self.n, self._h))
+
+    def close(self):
+        for k in range(self.n):
+            if self._h[k]:
+                lib().fjgpu_scene_destroy(self._h[k])
+                self._h[k] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_frame(self, render, tile_ids=None):
+        """Tile k of the list on replica k % n, slabs gathered on the first device ->
+        numpy [H, W, 4] float32 plus one GpuStats per replica."""
+        fb = np.zeros((render.yres, render.xres, 4), dtype=np.float32)
+        st = (ffi.GpuStats * self.n)()
+        if tile_ids is None:
+            ids_p, n = None, 0
+        else:
+            ids = np.ascontiguousarray(tile_ids, dtype=np.int32)
+            ids_p, n = ids.ctypes.data_as(C.c_void_p), len(ids)
+        _check(lib().fjgpu_render_frame_multi(self._h, self.n, C.byref(render), ids_p, n, fb.ctypes.data_as(C.c_void_p), st))
+        return fb, list(st)
 
 
 def global_option(name, value):

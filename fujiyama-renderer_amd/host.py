@@ -12,6 +12,22 @@ TYPE_FRAMEBUFFER = 3
 TYPE_RENDERER = 8
 
 
+class FrameInfo(C.Structure):          # fj::FrameInfo, src/fj_callback.h:15-37
+    _fields_ = [("frame_id", C.c_int32), ("worker_count", C.c_int), ("tile_count", C.c_int), ("xres", C.c_int),
+                ("yres", C.c_int), ("frame_region", C.c_int * 4), ("framebuffer", C.c_void_p)]
+
+
+class TileInfo(C.Structure):           # fj::TileInfo, src/fj_callback.h:39-59
+    _fields_ = [("frame_id", C.c_int32), ("worker_id", C.c_int), ("region_id", C.c_int), ("total_region_count", C.c_int),
+                ("tile_region", C.c_int * 4), ("framebuffer", C.c_void_p)]
+
+
+FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(FrameInfo))
+TILE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TileInfo))
+SAMPLE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+CALLBACK_CONTINUE, CALLBACK_INTERRUPT = 0, -1
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -27,6 +43,12 @@ def lib():
         L.fj_framebuffer_data.restype = C.POINTER(C.c_float)
         L.fj_scene_last_stats.argtypes = [C.POINTER(ffi.RenderStats)]
         L.fj_SiCloseScene.restype = C.c_int
+        L.fj_SiRenderScene.argtypes = [C.c_long]
+        L.fj_SiRenderScene.restype = C.c_int
+        L.fj_SiSetFrameReportCallback.argtypes = [C.c_long, C.c_void_p, FRAME_CB, FRAME_CB, FRAME_CB]
+        L.fj_SiSetFrameReportCallback.restype = C.c_int
+        L.fj_SiSetTileReportCallback.argtypes = [C.c_long, C.c_void_p, TILE_CB, SAMPLE_CB, TILE_CB]
+        L.fj_SiSetTileReportCallback.restype = C.c_int
         _lib = L
     return _lib
 
@@ -47,6 +69,36 @@ def run_scene_text(text, deferred=False, echo=False):
     if rc != 0:
         raise SceneError(L.fj_scene_last_error().decode("utf-8", "replace"))
     return 0
+
+
+def render_with_callbacks(renderer_index=0, frame_start=None, frame_done=None, tile_start=None, tile_done=None,
+                          sample_done=None, frame_abort=None):
+    """SiSetFrameReportCallback / SiSetTileReportCallback + SiRenderScene on renderer
+    #renderer_index of the current scene (built with run_scene_text(..., deferred=True)).
+    Callbacks are Python callables (info) -> CALLBACK_CONTINUE / CALLBACK_INTERRUPT.
+    Returns SiRenderScene's status (0 = SI_SUCCESS, -1 = SI_FAIL)."""
+    L = lib()
+    rid = TYPE_ID_OFFSET * TYPE_RENDERER + renderer_index
+
+    def wrap(kind, fn):
+        if fn is None:
+            return kind()
+        if kind is SAMPLE_CB:
+            return kind(lambda data: int(fn() or 0))
+        return kind(lambda data, info: int(fn(info.contents) or 0))
+
+    keep = [wrap(FRAME_CB, frame_start), wrap(FRAME_CB, frame_abort), wrap(FRAME_CB, frame_done),
+            wrap(TILE_CB, tile_start), wrap(SAMPLE_CB, sample_done), wrap(TILE_CB, tile_done)]
+    if L.fj_SiSetFrameReportCallback(rid, None, keep[0], keep[1], keep[2]) != 0:
+        raise SceneError("SiSetFrameReportCallback failed")
+    if L.fj_SiSetTileReportCallback(rid, None, keep[3], keep[4], keep[5]) != 0:
+        raise SceneError("SiSetTileReportCallback failed")
+    L.fj_scene_set_deferred_render(0)
+    rc = L.fj_SiRenderScene(rid)
+    # unhook before the ctypes thunks go away
+    L.fj_SiSetFrameReportCallback(rid, None, FRAME_CB(), FRAME_CB(), FRAME_CB())
+    L.fj_SiSetTileReportCallback(rid, None, TILE_CB(), SAMPLE_CB(), TILE_CB())
+    return rc
 
 
 def get_desc():

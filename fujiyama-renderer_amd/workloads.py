@@ -16,14 +16,30 @@ from . import synth
 from .fujiyama import SceneInterface
 
 
-def point_lights(si, n=32, seed=7):
-    """n point lights over the scene: x,z uniform in [0,14), y = 12, I = 1/n."""
-    rng = np.random.RandomState(seed)
+# The 32 point lights of the reference's scenes, (x, z) at y = 12, intensity 1/32 each: the same
+# set in scenes/teapot.scn:16-111, happy_buddhas.scn, xyzrgb_dragon.scn:20-115 and
+# furry_bunny.scn (scene DATA the workloads keep verbatim).
+REFERENCE_LIGHTS_XZ = (
+    (0.900771, 4.09137), (2.02315, 5.28021), (10.69, 13.918), (4.28027, 7.58462),
+    (12.9548, 1.19914), (6.55808, 2.31772), (0.169064, 10.9623), (1.25002, 4.51314),
+    (2.46758, 5.73382), (3.55644, 6.84334), (4.76112, 8.00264), (13.3267, 9.10333),
+    (14.4155, 2.68084), (8.10755, 3.79629), (9.21103, 4.9484), (2.83469, 6.09221),
+    (4.00945, 7.18302), (12.6072, 0.832089), (6.21169, 1.98055), (7.39599, 10.5563),
+    (8.52421, 4.15086), (9.5891, 5.39715), (3.18967, 13.9542), (4.41432, 0.082813),
+    (5.48803, 1.21856), (6.57647, 2.31432), (0.265098, 10.9453), (8.84422, 12.1117),
+    (10.0154, 5.67625), (11.0907, 14.4043), (4.71726, 7.98851), (13.3907, 9.08986),
+)
+
+
+def point_lights(si, n=32):
+    """the first n of the reference's 32 point lights (y = 12), intensity 1/n each"""
     for i in range(n):
-        x, z = rng.uniform(0, 14, size=2)
+        x, z = REFERENCE_LIGHTS_XZ[i % 32]
+        if i >= 32:                       # more lights than the reference has: a second, shifted ring
+            x, z = x + .37 * (i // 32), z + .53 * (i // 32)
         name = "light%d" % i
         si.NewLight(name, "PointLight")
-        si.SetProperty3(name, "translate", float(np.float32(x)), 12, float(np.float32(z)))
+        si.SetProperty3(name, "translate", x, 12, z)
         si.SetProperty1(name, "intensity", 1.0 / n)
 
 

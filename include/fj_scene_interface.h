@@ -204,6 +204,15 @@ int  fj_SiSetProperty3(long id, const char *name, double v0, double v1, double v
 int  fj_SiSetProperty4(long id, const char *name, double v0, double v1, double v2, double v3);
 int  fj_SiSetStringProperty(long id, const char *name, const char *string);
 int  fj_SiSetSampleProperty3(long id, const char *name, double v0, double v1, double v2, double time);
+/* callbacks: (void *data, const FrameInfo * / const TileInfo *) -> CALLBACK_CONTINUE (0) or
+ * CALLBACK_INTERRUPT (-1); layouts of src/fj_callback.h:15-98; NULL = no hook */
+typedef int (*fj_frame_callback)(void *data, const void *frame_info);
+typedef int (*fj_tile_callback)(void *data, const void *tile_info);
+typedef int (*fj_sample_callback)(void *data);
+int  fj_SiSetFrameReportCallback(long renderer, void *data, fj_frame_callback frame_start, fj_frame_callback frame_abort,
+    fj_frame_callback frame_done);
+int  fj_SiSetTileReportCallback(long renderer, void *data, fj_tile_callback tile_start, fj_sample_callback sample_done,
+    fj_tile_callback tile_done);
 
 /* ---- helpers on top of the Si API ---- */
 

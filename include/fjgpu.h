@@ -47,9 +47,9 @@ typedef struct fjgpu_scene fjgpu_scene;
 /* Per-launch device counters, summed over the call (all optional to read) */
 typedef struct fjgpu_stats {
   fj_ray_counts rays;          /* same events the reference would count */
-  uint64_t nodes_visited;      /* BLAS nodes fetched (64 B each) */
-  uint64_t prims_tested;       /* triangle / curve tests (72 B each) */
-  uint64_t insts_tested;       /* instance records fetched (192 B each) */
+  uint64_t nodes_visited;      /* BLAS nodes fetched (128 B each: a 4-wide node) */
+  uint64_t prims_tested;       /* triangle tests (36 B each: f32 vertices, or 72 B as f64) / curve tests */
+  uint64_t insts_tested;       /* instance boxes tested (48 B each) */
   uint64_t rays_traced;        /* rays entering a trace kernel (closest + shadow) */
   uint64_t shadow_traversed;   /* shadow rays that survived the instance-box cull and walked a BLAS */
   double   trace_ms;           /* HIP-event time of the trace kernels (closest + shadow) */
@@ -96,6 +96,21 @@ int fjgpu_render_tiles(fjgpu_scene *scene, const fj_render_desc *render,
 /* Convenience: all tiles, result copied to a HOST buffer (xres*yres*4 floats). */
 int fjgpu_render_frame(fjgpu_scene *scene, const fj_render_desc *render,
     float *h_framebuffer, fjgpu_stats *stats);
+
+/* The same scene resident on several devices of this process: the host-side build (BLAS,
+ * matrices, light samples) runs once, the result is uploaded to every device in `devices`.
+ * out[n_devices]; on failure nothing is left allocated. */
+int fjgpu_scene_create_multi(const fj_scene_desc *desc, const int *devices, int n_devices, fjgpu_scene **out);
+
+/* One frame on the devices of `scenes` (replicas of one scene, fjgpu_scene_create_multi) -- the
+ * reference's worker pool with GPUs for workers (execute_rendering, src/fj_renderer.cc:747-791;
+ * MtRunParallelLoop, src/fj_multi_thread.cc:86-132).  Tile k of `tile_ids` (NULL = all tiles of
+ * the render region) is rendered by scenes[k % n_scenes] on that device's own host thread; each
+ * device packs its finished tiles into one slab, which crosses xGMI as one peer copy into
+ * scenes[0]'s device; the assembled frame is copied to the HOST buffer once.  Pixels of tiles not
+ * listed are 0.  stats: NULL or [n_scenes], one entry per device. */
+int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_render_desc *render,
+    const int32_t *tile_ids, int n_tiles, float *h_framebuffer, fjgpu_stats *stats);
 
 /* Closest hit of n rays against group `group` (HOST arrays; copied in/out).
  * rays [n][8] = orig xyz, dir xyz, tmin, tmax.  out_t [n] (DBL_MAX on miss),

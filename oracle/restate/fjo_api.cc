@@ -31,6 +31,13 @@ int fjo_scene_render(void *h, const fj_render_desc *r, const int32_t *tile_ids, 
   return RenderTiles(static_cast<Scene *>(h), *r, tile_ids, n_tiles, fb, nthreads, counts);
 }
 
+// the same with the reference's serial random streams (RenderTiles: serial_rng)
+int fjo_scene_render_serial(void *h, const fj_render_desc *r, const int32_t *tile_ids, int n_tiles,
+    float *fb, fj_ray_counts *counts)
+{
+  return RenderTiles(static_cast<Scene *>(h), *r, tile_ids, n_tiles, fb, 1, counts, 1);
+}
+
 // closest hit of n rays against one group. rays: [n][8] = orig, dir, tmin, tmax.
 // out_t[n] (REAL_MAX on miss), out_ids[n][2] = instance, prim (-1 on miss),
 // out_attr[n][8] = N.xyz, u, v, P.xyz

@@ -295,7 +295,15 @@ struct SurfIn {
 struct RenderState {
   const Scene *sc;
   fj_ray_counts counts;
-  XorShift pt_rng;        // per-worker stream for PathtracingShader (a29)
+  // Serial-stream mode (pins the restatement to a ONE-thread reference render bit for bit):
+  // the reference's own generators in its own draw order -- PathtracingShader's rng[thread 0],
+  // one per shader instance (shaders/pathtracing_shader/pathtracing_shader.cc:50,186-188), and
+  // one XorShift per area light (src/fj_rectangle_light.h:23, src/fj_sphere_light.cc:9,33),
+  // all default seeded, never re-seeded, drawn from in shading-call order over the whole frame
+  // (tiles in queue order, samples in raster order, recursion depth first).  Off: the
+  // counter-based contract shared with the device (see pt_draw2 / area_stream).
+  bool serial_rng = false;
+  std::vector<XorShift> shader_rng, light_rng;
   double cos_half_pi, cos_pi;
 };
 
@@ -451,17 +459,18 @@ static XorShift area_stream(uint32_t uid, uint32_t key, int light)
 
 // SlNewLightSamples for one shading event: the static table, with the samples of area
 // lights generated in place (same order: lights in scene order, samples in draw order)
-static const std::vector<LightSample> &event_light_samples(const RenderState *rs, const Cxt &cxt, std::vector<LightSample> *tmp)
+static const std::vector<LightSample> &event_light_samples(RenderState *rs, const Cxt &cxt, std::vector<LightSample> *tmp)
 {
   const Scene &sc = *rs->sc;
   if (!sc.has_area_lights) return sc.light_samples;
   *tmp = sc.light_samples;
   int cur = -1;
-  XorShift rng;
+  XorShift event_rng;
   for (LightSample &s : *tmp) {
     const fj_light_desc &L = sc.d->lights[s.light];
     if (L.type != FJ_GRID_LIGHT && L.type != FJ_SPHERE_LIGHT) continue;
-    if (s.light != cur) { cur = s.light; rng = area_stream(cxt.sample_uid, cxt.path_key, cur); }
+    if (s.light != cur && !rs->serial_rng) { cur = s.light; event_rng = area_stream(cxt.sample_uid, cxt.path_key, cur); }
+    XorShift &rng = rs->serial_rng ? rs->light_rng[s.light] : event_rng;
     const Xfm &x = sc.light_xfm[s.light];
     if (L.type == FJ_GRID_LIGHT) {
       const double px = rng.NextFloat01() - .5;
@@ -701,8 +710,13 @@ static uint32_t pt_mix(uint32_t uid, uint32_t key)
   return h;
 }
 
-static void pt_draw2(uint32_t uid, uint32_t key, double *x1, double *x2)
+static void pt_draw2(RenderState *rs, int shader, uint32_t uid, uint32_t key, double *x1, double *x2)
 {
+  if (rs->serial_rng) {          // rng[MtGetThreadID() = 0] of this shader instance, :186-188
+    *x1 = rs->shader_rng[shader].NextFloat01();
+    *x2 = rs->shader_rng[shader].NextFloat01();
+    return;
+  }
   uint32_t st[4];
   uint32_t seed = pt_mix(uid, key);
   for (uint32_t i = 0; i < 4; i++) st[i] = seed = 1812433253U * (seed ^ (seed >> 30)) + i;   // XorShift(unsigned)
@@ -734,7 +748,7 @@ static void PathtracingEvaluate(RenderState *rs, const fj_shader_desc &sh, const
     u = Normalize(Cross(u, w));
     const V3 v = Cross(w, u);
     double x1, x2;
-    pt_draw2(cxt.sample_uid, cxt.path_key, &x1, &x2);
+    pt_draw2(rs, (int) (&sh - d->shaders), cxt.sample_uid, cxt.path_key, &x1, &x2);
     const double r1 = 2. * PI * x1;
     const double r2 = x2;
     const double r2sqrt = std::sqrt(r2);
@@ -906,8 +920,9 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
 }
 
 int RenderTiles(Scene *sc, const fj_render_desc &r, const int32_t *tile_ids, int n_tiles,
-    float *fb, int nthreads, fj_ray_counts *counts_out)
+    float *fb, int nthreads, fj_ray_counts *counts_out, int serial_rng)
 {
+  if (serial_rng) nthreads = 1;                    // one worker, tiles in queue order: the reference with thread_count 1
   if (r.sampler_type != 0 && r.sampler_type != 1) return -2;
   if (r.sampler_type == 1 && (r.adaptive_max_subdivision < 0 || r.adaptive_max_subdivision > 8)) return -2;
   if (build_light_samples(sc)) return -3;
@@ -930,6 +945,11 @@ int RenderTiles(Scene *sc, const fj_render_desc &r, const int32_t *tile_ids, int
     std::memset(&rs.counts, 0, sizeof(rs.counts));
     rs.cos_half_pi = std::cos(PI / 2.);
     rs.cos_pi = std::cos(PI);
+    rs.serial_rng = serial_rng != 0;
+    if (rs.serial_rng) {
+      rs.shader_rng.assign((size_t) sc->d->n_shaders, XorShift());
+      rs.light_rng.assign((size_t) sc->d->n_lights, XorShift());
+    }
     std::vector<Sample> samples;
     AdaptiveGrid grid;
     for (;;) {

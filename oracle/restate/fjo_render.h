@@ -26,8 +26,11 @@ void CameraGetRay(const CameraState &cam, const double uv[2], double time, Ray *
 double GaussianFilter(double xwidth, double ywidth, double x, double y);
 Col4 TextureLookup(const fj_texture_desc &tex, float u, float v);
 
+// serial_rng != 0: one worker and the reference's own random streams in its draw order (the
+// restatement then reproduces a `thread_count 1` reference render of PathtracingShader / area
+// light scenes bit for bit); 0: the counter-based streams shared with the device
 int RenderTiles(Scene *sc, const fj_render_desc &r, const int32_t *tile_ids, int n_tiles,
-    float *fb, int nthreads, fj_ray_counts *counts);
+    float *fb, int nthreads, fj_ray_counts *counts, int serial_rng = 0);
 
 }  // namespace fjo
 #endif

@@ -1,19 +1,10 @@
 #!/bin/bash
-# usage: scripts/build_variant.sh NAME [-DFOO ...]   -> fujiyama-renderer_amd/lib/var/NAME/libfjgpu.so
-# (perf experiments: the device library rebuilt with extra macros)
+# usage: scripts/build_variant.sh NAME "-DFLAG ..."   -> fujiyama-renderer_amd/lib_var/NAME/{libfjgpu.so,libfjscene.so}
+# An experiment build of the product libraries next to the default one; select it at run time
+# with FJGPU_LIBDIR=fujiyama-renderer_amd/lib_var/NAME (ffi.py).  Built artefacts travel with gpurun.
 set -e
-name=$1; shift
+name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/fujiyama-renderer_amd/csrc
-out=$root/fujiyama-renderer_amd/lib/var/$name
-o=/tmp/var_$name
-rm -rf $o $out; mkdir -p $out $o
-for f in fjgpu_kernels fjgpu_api fjgpu_lbvh; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$root/include -I$src/device "$@" -c -o $o/$f.o $src/device/$f.hip &
-done
-for f in fjgpu_build fjgpu_xform fjgpu_curve_build; do
-  g++ -O3 -std=c++17 -ffp-contract=off -fPIC -I$root/include -I$src/device "$@" -c -o $o/$f.o $src/device/$f.cc &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libfjgpu.so $o/*.o -pthread
-echo built $out/libfjgpu.so
+pkg=$root/fujiyama-renderer_amd
+make -s -C $pkg/csrc -j8 EXTRA="$flags" OBJ=$pkg/csrc/build/var_$name LIBDIR=$pkg/lib_var/$name BINDIR=$pkg/csrc/build/var_$name/bin all
+echo "built $pkg/lib_var/$name"

@@ -16,7 +16,7 @@ def custom_scene(asset_dir, res=(64, 48), spp=(2, 2), lights=3, floor_props=(), 
     si.SetProperty3("cam1", "translate", 0.5, 2.0, 6)
     si.SetProperty3("cam1", "rotate", -12, 4, 0)
     si.SetProperty1("cam1", "fov", 40)
-    workloads.point_lights(si, lights, seed=3)
+    workloads.point_lights(si, lights)
     tex_ids = {}
     for name, path_key in textures:
         si.NewTexture(name, a[path_key])

@@ -30,15 +30,19 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 from frame_cases import FRAMES  # noqa: E402  (name -> (builder, kwargs): the golden frame set)
 
 
-# rendered by the reference too, but compared STATISTICALLY: PathtracingShader draws from a
-# per-thread serial XorShift in the reference (image depends on the worker schedule), the
-# restatement and the device use the counter-based stream of DESIGN.md 4
-STAT_FRAMES = {
-    "stat_c4_cornell_64x48_8spp": ("cornell", dict(res=(64, 48), spp=(8, 8), mesh="tiny")),
-    # area lights draw from one unsynchronised XorShift per light in the reference
-    "stat_area_grid_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="grid")),
-    "stat_area_sphere_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="sphere")),
-    "stat_area_both_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="both")),
+# PathtracingShader draws its bounce directions from rng[thread id] of the shader instance and
+# the area lights from one XorShift per light shared by all workers: with several worker threads
+# the reference's image depends on the schedule.  With ONE worker it is deterministic, so these
+# frames are rendered with `use_max_thread 0, thread_count 1`; the restatement's serial-stream
+# mode reproduces them bit for bit (tests/test_oracle_golden.py).
+ONE_THREAD = (("use_max_thread", (0,)), ("thread_count", (1,)))
+SERIAL_FRAMES = {
+    "serial_c4_cornell_64x48_8spp": ("cornell", dict(res=(64, 48), spp=(8, 8), mesh="tiny", extra=ONE_THREAD)),
+    "serial_c4_cornell_depth1_48x32_3spp": ("cornell", dict(res=(48, 32), spp=(3, 3), mesh="tiny",
+                                                          extra=ONE_THREAD + (("max_diffuse_depth", (1,)),))),
+    "serial_area_grid_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="grid", extra=ONE_THREAD)),
+    "serial_area_sphere_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="sphere", extra=ONE_THREAD)),
+    "serial_area_both_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="both", extra=ONE_THREAD)),
 }
 
 
@@ -87,7 +91,7 @@ def main():
     print("wrote", out, os.path.getsize(out))
 
     frames = {}
-    texts = {name: workloads.BUILDERS[builder](asset_dir, **kw) for name, (builder, kw) in list(FRAMES.items()) + list(STAT_FRAMES.items())}
+    texts = {name: workloads.BUILDERS[builder](asset_dir, **kw) for name, (builder, kw) in list(FRAMES.items()) + list(SERIAL_FRAMES.items())}
     for name, kw in edge_scenes.EDGE_CASES.items():
         texts["edge_" + name] = edge_scenes.custom_scene(asset_dir, **kw)
     for name, text in texts.items():

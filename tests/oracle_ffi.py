@@ -32,6 +32,8 @@ def lib():
         L.fjo_scene_destroy.restype = None
         L.fjo_scene_render.argtypes = [C.c_void_p, C.POINTER(ffi.RenderDesc), C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_int, C.POINTER(ffi.RayCounts)]
+        L.fjo_scene_render_serial.argtypes = [C.c_void_p, C.POINTER(ffi.RenderDesc), C.c_void_p, C.c_int, C.c_void_p,
+                                              C.POINTER(ffi.RayCounts)]
         L.fjo_scene_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -56,6 +58,22 @@ class OracleScene(object):
             ids_p, n = ids.ctypes.data_as(C.c_void_p), len(ids)
         threads = threads or min(os.cpu_count() or 1, 64)
         e = lib().fjo_scene_render(self._h, C.byref(render), ids_p, n, fb.ctypes.data_as(C.c_void_p), threads, C.byref(rc))
+        if e:
+            raise RuntimeError("oracle render failed: %d" % e)
+        return fb, rc
+
+    def render_serial(self, render, tile_ids=None):
+        """one worker, the reference's own random streams in its draw order (fjo_render.h:
+        serial_rng): reproduces a `thread_count 1` reference render of PathtracingShader /
+        area-light scenes bit for bit"""
+        fb = np.zeros((render.yres, render.xres, 4), dtype=np.float32)
+        rc = ffi.RayCounts()
+        if tile_ids is None:
+            ids_p, n = None, 0
+        else:
+            ids = np.ascontiguousarray(tile_ids, dtype=np.int32)
+            ids_p, n = ids.ctypes.data_as(C.c_void_p), len(ids)
+        e = lib().fjo_scene_render_serial(self._h, C.byref(render), ids_p, n, fb.ctypes.data_as(C.c_void_p), C.byref(rc))
         if e:
             raise RuntimeError("oracle render failed: %d" % e)
         return fb, rc

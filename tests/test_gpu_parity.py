@@ -46,8 +46,10 @@ def close_enough(a, st_a, b, st_b, adaptive, tol):
     exact = (st_a is None or st_a == st_b) and float(rel_err(a, b).max()) <= tol
     if exact or not adaptive:
         return exact
-    cam_a, cam_b = st_a["camera"], st_b["camera"]
     bad = int((rel_err(a, b) > tol).any(axis=2).sum())
+    if st_a is None:          # two device renders of one frame: pixels only
+        return bad <= max(16, a.shape[0] * a.shape[1] // 500)
+    cam_a, cam_b = st_a["camera"], st_b["camera"]
     return abs(cam_a - cam_b) <= max(64, cam_b // 1000) and bad <= max(16, a.shape[0] * a.shape[1] // 500)
 
 
@@ -421,3 +423,87 @@ def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, tiles, a
         x0, y0, x1, y1 = gpu.tile_rect(rd, t)
         assert out[y0:y1, x0:x1].any()
         assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL
+
+
+def test_multi_device_frame_equals_single_device_frame(asset_dir):
+    """fjgpu_render_frame_multi (the worker pool with GPUs for workers, src/fj_renderer.cc:747-791):
+    two replicas -- on one device here -- deal the tiles k % 2, pack, peer-copy and scatter their
+    slabs; the frame, the tile subsets and the summed ray counts are those of one device."""
+    text = workloads.teapot(asset_dir, res=(100, 76), spp=(2, 2), mesh="tiny", extra=(("tilesize", (16, 16)),))
+    sp, rd = prepare(text)
+    gs = gpu.Scene(sp)
+    one, st1 = gs.render_frame(rd)
+    gs.close()
+    n = gpu.tile_count(rd)
+    assert n == 7 * 5
+    for replicas in (2, 3):
+        ms = gpu.MultiScene(sp, [0] * replicas)
+        fb, sts = ms.render_frame(rd)
+        assert float(rel_err(fb, one).max()) <= 1e-6       # (f32 atomics: the order of the adds differs run to run)
+        total = {k: sum(getattr(s.rays, k) for s in sts) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
+        assert total == st1.rays.as_dict()
+        assert all(s.rays.camera > 0 for s in sts)         # every replica rendered its share
+        # a tile subset (the cancel path of SiRenderScene): listed tiles as in the full frame, the rest 0
+        ids = [0, 3, 4, 9, 17, 33, 34]
+        sub, _ = ms.render_frame(rd, ids)
+        mask = np.zeros(one.shape[:2], dtype=bool)
+        for t in ids:
+            x0, y0, x1, y1 = gpu.tile_rect(rd, t)
+            mask[y0:y1, x0:x1] = True
+        assert float(rel_err(sub[mask], one[mask]).max()) <= 1e-6 and not sub[~mask].any()
+        ms.close()
+
+
+def test_si_callbacks_and_interrupts(asset_dir):
+    """SiSetFrameReportCallback / SiSetTileReportCallback (src/fj_callback.h:15-98) on the GPU path:
+    one tile_start / tile_done per tile, TileInfo.framebuffer readable in tile_done, and the
+    reference's interrupt semantics -- a tile_start hook returning CALLBACK_INTERRUPT stops the
+    queue (that tile and later ones are not rendered, earlier ones are), frame_done still fires and
+    RenderScene succeeds (src/fj_renderer.cc:787-790,1098-1121); a frame_start interrupt fails the
+    render before any tile (src/fj_renderer.cc:774-777)."""
+    text = workloads.teapot(asset_dir, res=(96, 64), spp=(2, 2), mesh="tiny", extra=(("tilesize", (32, 32)),))
+    host.run_scene_text(text, deferred=False)
+    full = host.framebuffer(0)
+    assert full[..., 3].max() > 0
+    host.run_scene_text(text, deferred=True)
+    ev = {"frame_start": 0, "frame_done": 0, "abort": 0, "start": [], "done": [], "sample": 0, "lit": []}
+
+    def tile_done(info):
+        ev["done"].append(info.region_id)
+        x0, y0, x1, y1 = tuple(info.tile_region)
+        assert info.total_region_count == 6 and info.framebuffer
+        ev["lit"].append(float(np.abs(host.framebuffer(0)[y0:y1, x0:x1]).max()))
+        return host.CALLBACK_CONTINUE
+
+    def count(key):
+        def fn(*a):
+            ev[key] += 1
+            return host.CALLBACK_CONTINUE
+        return fn
+
+    rc = host.render_with_callbacks(frame_start=count("frame_start"), frame_done=count("frame_done"), frame_abort=count("abort"),
+                                    tile_start=lambda i: ev["start"].append(i.region_id) or 0, tile_done=tile_done,
+                                    sample_done=count("sample"))
+    assert rc == 0 and ev["frame_start"] == 1 and ev["frame_done"] == 1 and ev["abort"] == 0
+    assert ev["start"] == list(range(6)) and sorted(ev["done"]) == list(range(6)) and ev["sample"] >= 1
+    assert min(ev["lit"]) > 0                                # every finished tile was readable in its hook
+    assert float(rel_err(host.framebuffer(0), full).max()) <= 1e-6
+
+    # interrupt at the start of tile 2: tiles 0 and 1 are rendered, nothing else is touched
+    host.run_scene_text(text, deferred=True)
+    ev2 = {"done": [], "frame_done": 0}
+    rc = host.render_with_callbacks(tile_start=lambda i: host.CALLBACK_INTERRUPT if i.region_id == 2 else host.CALLBACK_CONTINUE,
+                                    tile_done=lambda i: ev2["done"].append(i.region_id) or 0,
+                                    frame_done=lambda i: ev2.__setitem__("frame_done", ev2["frame_done"] + 1) or 0)
+    part = host.framebuffer(0)
+    assert rc == 0 and sorted(ev2["done"]) == [0, 1] and ev2["frame_done"] == 1
+    assert float(rel_err(part[:32, :64], full[:32, :64]).max()) <= 1e-6
+    assert not part[:32, 64:].any() and not part[32:].any()
+
+    # interrupt at frame start: SI_FAIL, no tile hooks, framebuffer untouched (all zero after the resize)
+    host.run_scene_text(text, deferred=True)
+    ev3 = {"tiles": 0}
+    rc = host.render_with_callbacks(frame_start=lambda i: host.CALLBACK_INTERRUPT,
+                                    tile_start=lambda i: ev3.__setitem__("tiles", ev3["tiles"] + 1) or 0)
+    assert rc == -1 and ev3["tiles"] == 0 and not host.framebuffer(0).any()
+    host.close_scene()

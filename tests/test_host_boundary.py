@@ -35,7 +35,7 @@ def test_libfjgpu_exports_every_declared_symbol():
 
 def test_libfjscene_exports_c_and_cxx_api():
     names = _declared("fj_scene_interface.h", "fj_")
-    assert len([n for n in names if n.startswith("fj_Si")]) == 38
+    assert len([n for n in names if n.startswith("fj_Si")]) == 40
     exp = _exported("libfjscene.so")
     assert [n for n in names if n not in exp] == []
     # the C++ spelling (namespace fj, Itanium mangling) of the 41-function interface

@@ -278,46 +278,44 @@ def test_oracle_frames_match_reference_renders(name, golden_dir, asset_dir):
     assert rc.camera > 0 and rc.shadow > rc.camera
 
 
-def test_oracle_pathtracing_agrees_statistically_with_reference(golden_dir, asset_dir):
-    """C4 (PathtracingShader).  The reference draws its bounce directions from a per-thread
-    serial XorShift, so its image is schedule dependent; the restatement (and the device)
-    use the counter-based stream of DESIGN.md 4 -- same estimator, different random numbers.
-    So: identical alpha/coverage (camera hits do not depend on the RNG), and radiance that
-    agrees within Monte-Carlo noise: global mean < 2 %, 8x8-block means correlated > 0.97."""
-    ref = np.load(os.path.join(golden_dir, "frames.npz"))["stat_c4_cornell_64x48_8spp"]
-    host.run_scene_text(workloads.cornell(asset_dir, res=(64, 48), spp=(8, 8), mesh="tiny"), deferred=True)
-    sp, rd = host.get_desc()
-    osc = oracle_ffi.OracleScene(sp)
-    fb, rc = osc.render(rd, threads=4)
-    osc.close()
-    assert np.array_equal(fb[..., 3], ref[..., 3])
-    assert rc.diffuse > rc.camera and rc.reflect > 0 and rc.refract > 0 and rc.shadow == 0
-    for ch in range(3):
-        a, b = float(fb[..., ch].mean()), float(ref[..., ch].mean())
-        assert abs(a - b) <= .02 * b, (ch, a, b)
-    blk = lambda x: x[..., :3].reshape(6, 8, 8, 8, 3).mean(axis=(1, 3)).ravel()
-    assert np.corrcoef(blk(fb), blk(ref))[0, 1] > .97
+ONE_THREAD = (("use_max_thread", (0,)), ("thread_count", (1,)))
+SERIAL_CASES = {
+    "serial_c4_cornell_64x48_8spp": ("cornell", dict(res=(64, 48), spp=(8, 8), mesh="tiny", extra=ONE_THREAD)),
+    "serial_c4_cornell_depth1_48x32_3spp": ("cornell", dict(res=(48, 32), spp=(3, 3), mesh="tiny",
+                                                          extra=ONE_THREAD + (("max_diffuse_depth", (1,)),))),
+    "serial_area_grid_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="grid", extra=ONE_THREAD)),
+    "serial_area_sphere_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="sphere", extra=ONE_THREAD)),
+    "serial_area_both_64x48_6spp": ("arealights", dict(res=(64, 48), spp=(6, 6), mesh="tiny", kind="both", extra=ONE_THREAD)),
+}
 
 
-@pytest.mark.parametrize("kind", ["grid", "sphere", "both"])
-def test_oracle_area_lights_agree_statistically_with_reference(kind, golden_dir, asset_dir):
-    """RectangleLight / SphereLight draw their sample positions from one XorShift per light
-    shared, unsynchronised, by every worker thread of the reference: its image depends on
-    the schedule.  Restatement and device use the counter-based stream of DESIGN.md 4 (same
-    sampler, different random numbers): identical alpha, radiance within Monte-Carlo noise
-    (global mean < 1 %, 8x8-block means correlated > 0.995)."""
-    ref = np.load(os.path.join(golden_dir, "frames.npz"))["stat_area_%s_64x48_6spp" % kind]
-    host.run_scene_text(workloads.arealights(asset_dir, res=(64, 48), spp=(6, 6), mesh="tiny", kind=kind), deferred=True)
+@pytest.mark.parametrize("name", sorted(SERIAL_CASES))
+def test_oracle_serial_streams_match_one_thread_reference_bit_exactly(name, golden_dir, asset_dir):
+    """C4 (PathtracingShader) and the area lights, pinned EXACTLY.  The reference draws bounce
+    directions from rng[thread id] of the shader instance and area-light positions from one
+    XorShift per light: with one worker thread (`use_max_thread 0`, `thread_count 1`) its render
+    is deterministic, and the restatement's serial-stream mode -- the same generators, default
+    seeded, drawn from in the reference's shading order over the whole frame -- reproduces the
+    reference frame bit for bit: estimator, weights, depth limits and draw order are all pinned."""
+    builder, kw = SERIAL_CASES[name]
+    ref = np.load(os.path.join(golden_dir, "frames.npz"))[name]
+    host.run_scene_text(workloads.BUILDERS[builder](asset_dir, **kw), deferred=True)
     sp, rd = host.get_desc()
     osc = oracle_ffi.OracleScene(sp)
-    fb, rc = osc.render(rd, threads=4)
+    fb, rc = osc.render_serial(rd)
+    # the counter-based streams (the contract shared with the device): same scene, same
+    # estimator, other random numbers -- same SlTrace events that do not depend on them
+    cb, rc2 = osc.render(rd, threads=4)
     osc.close()
-    assert np.array_equal(fb[..., 3], ref[..., 3])
-    assert rc.shadow > rc.camera
-    a, b = float(fb[..., :3].mean()), float(ref[..., :3].mean())
-    assert abs(a - b) <= .01 * b, (a, b)
-    blk = lambda x: x[..., :3].reshape(6, 8, 8, 8, 3).mean(axis=(1, 3)).ravel()
-    assert np.corrcoef(blk(fb), blk(ref))[0, 1] > .995
+    assert fb.shape == ref.shape
+    assert np.array_equal(fb, ref), float(np.abs(fb - ref).max())
+    assert np.array_equal(cb[..., 3], ref[..., 3]) and rc.camera == rc2.camera
+    blk = lambda x: x[..., :3].reshape(x.shape[0] // 8, 8, x.shape[1] // 8, 8, 3).mean(axis=(1, 3)).ravel()
+    assert np.corrcoef(blk(cb), blk(ref))[0, 1] > .97
+    if builder == "cornell":
+        assert rc.diffuse > 0 and rc.shadow == 0
+    else:
+        assert rc.shadow > rc.camera and abs(rc.shadow - rc2.shadow) < .01 * rc.shadow    # (the cone / intensity tests see other positions)
 
 
 def test_oracle_edge_case_frames_match_reference_renders(golden_dir, asset_dir):
