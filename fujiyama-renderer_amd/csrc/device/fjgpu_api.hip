@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -290,19 +291,36 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   e |= M.upload(dps.data(), dps.size(), &S.primsets);
   e |= M.upload(hs.instances.data(), hs.instances.size(), &S.instances);
   {
-    // flat per-instance records of the lean any-hit walk (static mesh instances): node and
-    // triangle arrays as 32-bit offsets from the lowest of their addresses
+    // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
+    // grid = 65536^3 cells over the primitive set's padded bounds
+    std::vector<std::array<double, 6>> qgrid(dps.size());
+    for (size_t i = 0; i < dps.size(); i++) {
+      DPrimSet &P = dps[i];
+      P.qnodes = nullptr;
+      if (P.type != FJ_PRIMSET_MESH || P.n_prims == 0 || e) continue;
+      const size_t n_nodes = std::max<size_t>(1, hs.primsets[i].nodes.size());
+      for (int a = 0; a < 3; a++) {
+        qgrid[i][a] = P.bounds[a];
+        qgrid[i][3 + a] = std::max(1e-300, (P.bounds[3 + a] - P.bounds[a]) / 65535. * (1 + 1e-9));
+      }
+      DNodeQ *q = nullptr;
+      if (M.alloc(n_nodes, &q)) { e = 1; continue; }
+      if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
+      P.qnodes = q;
+    }
+    // flat per-instance records of that walk (static mesh instances): node and triangle arrays
+    // as 32-bit offsets from the lowest of their addresses
     uintptr_t lo = UINTPTR_MAX, hi = 0;
+    auto tris_of = [](const DPrimSet &P) { return (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts); };
     for (const DPrimSet &P : dps) {
-      if (P.type != FJ_PRIMSET_MESH || P.n_prims == 0) continue;
-      const uintptr_t pn = (uintptr_t) P.nodes, pt = (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts);
+      if (!P.qnodes) continue;
+      const uintptr_t pn = (uintptr_t) P.qnodes, pt = tris_of(P);
       lo = std::min(lo, std::min(pn, pt)); hi = std::max(hi, std::max(pn, pt));
     }
     // (hipMalloc returns 256-byte aligned blocks: offsets in units of 128 B span 512 GB)
     bool fits = lo != UINTPTR_MAX && lo % 128 == 0 && (hi - lo) / 128 < 0xffffffffull;
     for (const DPrimSet &P : dps)
-      if (P.type == FJ_PRIMSET_MESH && P.n_prims > 0 &&
-          (((uintptr_t) P.nodes - lo) % 128 != 0 || ((uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts) - lo) % 128 != 0)) fits = false;
+      if (P.qnodes && (((uintptr_t) P.qnodes - lo) % 128 != 0 || (tris_of(P) - lo) % 128 != 0)) fits = false;
     S.blas_base = fits ? (const char *) lo : nullptr;
     if (!fits && lo != UINTPTR_MAX && getenv("FJGPU_VERBOSE"))
       fprintf(stderr, "fjgpu: BLAS arrays span %zu bytes from %p: no 32-bit offsets, the general shadow walk is used\n", (size_t) (hi - lo), (void *) lo);
@@ -315,11 +333,11 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       std::memcpy(a.Minv, I.Minv, sizeof(a.Minv));
       std::memcpy(a.bounds, P.bounds, sizeof(a.bounds));
       a.root = P.root;
-      a.n_prims = (P.type == FJ_PRIMSET_MESH && S.blas_base) ? P.n_prims : 0;
+      a.n_prims = (P.qnodes && S.blas_base) ? P.n_prims : 0;
       if (a.n_prims) {
-        const uintptr_t pt = (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts);
-        a.node_base = (uint32_t) (((uintptr_t) P.nodes - lo) / 128);
-        a.tri_base = (uint32_t) ((pt - lo) / 128);
+        for (int k = 0; k < 3; k++) { a.qorigin[k] = qgrid[I.primset][k]; a.qcell[k] = qgrid[I.primset][3 + k]; }
+        a.node_base = (uint32_t) (((uintptr_t) P.qnodes - lo) / 128);
+        a.tri_base = (uint32_t) ((tris_of(P) - lo) / 128);
         a.tris_f32 = P.tri_verts32 ? 1 : 0;
       }
     }
@@ -333,8 +351,10 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
   for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
+  // (only SHADOW target groups matter: the lean any-hit walk is the one consumer of this flag)
   S.multi_instance_groups = 0;
-  for (const auto &g : hs.groups) if (g.n_instances > 1) S.multi_instance_groups = 1;
+  for (const DInstance &I : hs.instances)
+    if (I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1) S.multi_instance_groups = 1;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   S.lrec_hair = nullptr;
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);

@@ -76,6 +76,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #ifdef FJ_EXP_SLAB_VALIDATE
   V3 inv_keep = oo;
+  int vinst = 0;
 #endif
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
   const float tmin32 = 9.9999e-5f;         // <= .0001
@@ -187,9 +188,10 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
           double tn;
           if (!slab(A->bounds, A->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
-          s32 = slab32_setup(oo, inv, A->bounds);
+          s32 = slab32q_setup(oo, inv, A->qorigin, A->qcell);
 #ifdef FJ_EXP_SLAB_VALIDATE
           inv_keep = mk(1. / od.x, 1. / od.y, 1. / od.z);
+          vinst = inst;
 #endif
           tmax32 = f32_above(tmax);
           node_base = A->node_base; tri_base = A->tri_base; tris_f32 = A->tris_f32 != 0;
@@ -213,32 +215,36 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
       const bool deep = __ballot(in_now && sp + 3 > FJ_STACK_LDS_ANYHIT) != 0ull;
       if (in_now) {
-        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (S.blas_base + ((size_t) (node_base + cur) << 7));
+        // 64-byte quantised node: four 16-byte loads (12 words of (min, max) pairs + 4 child refs)
+        const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
         if (kCount) lc->nodes++;
-        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
-        const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
+        const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], e = nd[3];
         float tq;
         // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
-        const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &tq);
+        const bool h0 = slab32_test(unpack_q(w0.x), unpack_q(w0.y), unpack_q(w0.z), s32, tmin32, tmax32, &tq);
         FJ_SCHED_FENCE();
-        const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &tq);
+        const bool h1 = slab32_test(unpack_q(w0.w), unpack_q(w1.x), unpack_q(w1.y), s32, tmin32, tmax32, &tq);
         FJ_SCHED_FENCE();
-        const bool h2 = slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &tq) && e.z != FJ_NO_CHILD;
+        const bool h2 = slab32_test(unpack_q(w1.z), unpack_q(w1.w), unpack_q(w2.x), s32, tmin32, tmax32, &tq) && e.z != FJ_NO_CHILD;
         FJ_SCHED_FENCE();
-        const bool h3 = slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &tq) && e.w != FJ_NO_CHILD;
+        const bool h3 = slab32_test(unpack_q(w2.y), unpack_q(w2.z), unpack_q(w2.w), s32, tmin32, tmax32, &tq) && e.w != FJ_NO_CHILD;
         FJ_SCHED_FENCE();
 #ifdef FJ_EXP_SLAB_VALIDATE
-        {   // every box the f64 test accepts must be accepted by the f32 test
-          double td;
-          const bool g0 = slab_f32box(q0.xy, q0.zw, q1.xy, oo, inv_keep, tmin, tmax, &td);
-          const bool g1 = slab_f32box(q1.zw, q2.xy, q2.zw, oo, inv_keep, tmin, tmax, &td);
-          const bool g2 = e.z != FJ_NO_CHILD && slab_f32box(q3.xy, q3.zw, q4.xy, oo, inv_keep, tmin, tmax, &td);
-          const bool g3 = e.w != FJ_NO_CHILD && slab_f32box(q4.zw, q5.xy, q5.zw, oo, inv_keep, tmin, tmax, &td);
-          const int lost = (int) (g0 && !h0) + (int) (g1 && !h1) + (int) (g2 && !h2) + (int) (g3 && !h3);
-          const int extra = (int) (h0 && !g0) + (int) (h1 && !g1) + (int) (h2 && !g2) + (int) (h3 && !g3);
-          if (lost) atomicAdd(&g_slab_lost, (unsigned long long) lost);
-          if (extra) atomicAdd(&g_slab_extra, (unsigned long long) extra);
-          atomicAdd(&g_slab_tests, (unsigned long long) (2 + (e.z != FJ_NO_CHILD) + (e.w != FJ_NO_CHILD)));
+        {   // every box the f64 test accepts on the DECODED box must be accepted by the f32 test
+          const DAnyInst *Av = &S.any_insts[vinst];
+          auto dec = [&](uint32_t w, int a) { fj_v2f p; p.x = (float) 0; p.y = (float) 0; double lo_ = Av->qorigin[a] + (double) (w & 0xffffu) * Av->qcell[a], hi_ = Av->qorigin[a] + (double) (w >> 16) * Av->qcell[a]; (void) p; return std::pair<double, double>(lo_, hi_); };
+          const uint32_t ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+          const bool hh[4] = {h0, h1, h2, h3};
+          const uint32_t ee[4] = {e.x, e.y, e.z, e.w};
+          for (int k = 0; k < 4; k++) {
+            if (ee[k] == FJ_NO_CHILD) continue;
+            double mn[3], mx[3], td;
+            for (int a = 0; a < 3; a++) { const auto pr = dec(ww[3 * k + a], a); mn[a] = pr.first; mx[a] = pr.second; }
+            const bool g = slab(mn, mx, oo, inv_keep, tmin, squeue[idx].tmax, &td);
+            if (g && !hh[k]) atomicAdd(&g_slab_lost, 1ull);
+            if (hh[k] && !g) atomicAdd(&g_slab_extra, 1ull);
+            atomicAdd(&g_slab_tests, 1ull);
+          }
         }
 #endif
         // any hit ends the ray and 7 of 8 rays reach the light, so the visiting order is free:
@@ -298,10 +304,11 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #endif
 }
 
-// blocks per CU (= waves per SIMD): 96 VGPRs without a spill for the single-instance walk; the
-// instance-BVH walk of the general one needs 128 (with spills a frame took twice as long)
+// blocks per CU (= waves per SIMD).  Measured on C3: 5 waves at 96 VGPRs (no spills, f32 nodes) ran
+// exactly as fast as 4 -- the walk is bound by the L1 request rate and VALU issue, not by latency --
+// and any spill in the loop doubled the frame time: 4 waves, 128 VGPRs, no spills.
 #ifndef FJ_ANYHIT_MINB
-#define FJ_ANYHIT_MINB 5
+#define FJ_ANYHIT_MINB 4
 #endif
 #ifndef FJ_ANYHIT_MINB_MULTI
 #define FJ_ANYHIT_MINB_MULTI 4

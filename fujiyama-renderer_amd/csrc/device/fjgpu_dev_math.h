@@ -118,6 +118,33 @@ __device__ __forceinline__ Slab32 slab32_setup(V3 oo, V3 inv, const double *boun
   return s;
 }
 
+// The same constants for QUANTISED boxes (DNodeQ): a plane is g0 + q cell with q an integer in
+// [0, 65535], so t = (g0 + q cell - oo)/od = q (cell/od) + (g0 - oo)/od, and
+//   t~ = fmaf((float) q, A, B),  A = (float)(cell/od),  B = (float)((g0 - oo)/od)
+// is off by at most 2^-23 (65535 |A| + |B|)(1 + 2^-18) (roundings of A, of B, of the fma; (float) q
+// is exact).  i = A, l = B - e, h = B + e with e three times that bound, as above.
+__device__ __forceinline__ Slab32Axis slab32q_axis(double inv, double oo, double g0, double cell)
+{
+  const float A = (float) (cell * inv), B = (float) ((g0 - oo) * inv);
+  const float e = 3.6e-7f * (65535.f * 1.000001f * fabsf(A) + fabsf(B));
+  const bool ok = e < 1e30f;
+  Slab32Axis a;
+  a.i = ok ? A : 0.f;
+  a.l = ok ? B - e : -1e30f;
+  a.h = ok ? B + e : 1e30f;
+  return a;
+}
+__device__ __forceinline__ Slab32 slab32q_setup(V3 oo, V3 inv, const double *g0, const double *cell)
+{
+  Slab32 s;
+  s.x = slab32q_axis(inv.x, oo.x, g0[0], cell[0]);
+  s.y = slab32q_axis(inv.y, oo.y, g0[1], cell[1]);
+  s.z = slab32q_axis(inv.z, oo.z, g0[2], cell[2]);
+  return s;
+}
+// (min, max) pair of grid coordinates packed in one 32-bit word -> two floats
+__device__ __forceinline__ fj_v2f unpack_q(uint32_t w) { fj_v2f p; p.x = (float) (w & 0xffffu); p.y = (float) (w >> 16); return p; }
+
 // px py pz = the (min, max) pairs of a child box; tmin32 <= tmin and tmax32 >= tmax of the ray.
 // *tnear = conservative entry distance (an ordering key for the closest-hit walk).
 __device__ __forceinline__ bool slab32_test(fj_v2f px, fj_v2f py, fj_v2f pz, const Slab32 s, float tmin32, float tmax32, float *tnear)

@@ -58,6 +58,8 @@ void shadow_queue_reset(hipStream_t st, DCounters *cnt);
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events);
+// the quantised node array of the lean any-hit walk from the f32 one (same indices)
+int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ *out);
 // multi-GPU frame: pack a device's tiles (d_rects [n][4] = xmin ymin xmax ymax) into a slab of
 // tile_px pixels per tile, or scatter such a slab into the framebuffer (unpack)
 int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *slab);

@@ -104,6 +104,36 @@ __global__ void __launch_bounds__(BLOCK) k_move_tiles(float4 *fb, int xres, cons
   }
 }
 
+// ------------------------------------------------------- k_quantize_nodes
+// DNode -> DNodeQ (fjgpu_types.h): child boxes outward onto the 65536^3 grid origin + q * cell.
+// floor / ceil in f64, then checked against the decoded plane and stepped outward if a rounding
+// went the wrong way: the decoded box always contains the f32 box.
+__global__ void __launch_bounds__(BLOCK) k_quantize_nodes(const DNode *nodes, uint32_t n, double ox, double oy, double oz,
+    double cx, double cy, double cz, DNodeQ *out)
+{
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const DNode nd = nodes[i];
+  DNodeQ q;
+  const double o[3] = {ox, oy, oz}, c[3] = {cx, cy, cz};
+  for (int k = 0; k < 4; k++) {
+    q.child[k] = nd.child[k];
+    for (int a = 0; a < 3; a++) {
+      const double lo = (double) nd.box[k][2 * a], hi = (double) nd.box[k][2 * a + 1];
+      double ql = floor((lo - o[a]) / c[a]), qh = ceil((hi - o[a]) / c[a]);
+      if (!(ql >= 0)) ql = 0;                    // (also the empty slots' +-FLT_MAX / NaN)
+      if (!(qh <= 65535)) qh = 65535;
+      if (!(qh >= 0)) qh = 0;
+      if (!(ql <= 65535)) ql = 65535;
+      if (o[a] + ql * c[a] > lo && ql > 0) ql -= 1;
+      if (o[a] + qh * c[a] < hi && qh < 65535) qh += 1;
+      q.q[k][2 * a] = (uint16_t) ql;
+      q.q[k][2 * a + 1] = (uint16_t) qh;
+    }
+  }
+  out[i] = q;
+}
+
 // ----------------------------------------------------------- host launchers
 // persistent launches: at most PERSIST_BLOCKS_PER_CU resident blocks per CU
 #define PERSIST_BLOCKS_PER_CU 4
@@ -243,6 +273,15 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
     else { if (count_events) FJ_LAUNCH_SHADOW(false, true, false); else FJ_LAUNCH_SHADOW(false, false, false); }
 #undef FJ_LAUNCH_SHADOW
   }
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ *out)
+{
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_quantize_nodes, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, n, origin[0], origin[1], origin[2],
+      cell[0], cell[1], cell[2], out);
   LAUNCH_CHECK();
   return 0;
 }

@@ -18,6 +18,17 @@ struct DNode {
 };
 static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 
+// ---- the same node for the lean any-hit walk: 64 B = four 16-byte loads instead of seven (the
+// walk is bound by the L1's request rate: one request per lane and load instruction, because every
+// lane reads another node).  Child boxes are quantised to a 65536^3 grid over the primitive set's
+// padded bounds (DAnyInst.qorigin / qcell), outward: min = floor, max = ceil, so the decoded box
+// contains the f32 box of the DNode with the same index.  Same child refs, same node indices.
+struct DNodeQ {
+  uint16_t q[4][6];            // child k: (min, max) pairs of x, y, z in grid units
+  uint32_t child[4];
+};
+static_assert(sizeof(DNodeQ) == 64, "DNodeQ must be 64 bytes");
+
 #define FJ_NO_CHILD 0xffffffffu
 #define FJ_LEAF_FLAG 0x80000000u
 #ifndef FJ_MAX_LEAF_PRIMS
@@ -42,6 +53,7 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
   const DNode *nodes;
+  const DNodeQ *qnodes;        // the same tree with quantised boxes (meshes; the lean any-hit walk) or null
   const double *tri_verts;     // [n_prims][9]  pre-gathered v0 v1 v2 in BLAS leaf order (72 B / tri), or null:
   const float *tri_verts32;    // [n_prims][9]  the same values as f32 (36 B / tri) when EVERY coordinate of the
                                //               mesh is exactly representable in f32 (PLY data is); widened to
@@ -97,16 +109,17 @@ struct DInstance {
 struct DAnyInst {
   double Minv[12];             // world -> object
   double bounds[6];            // the primitive set's padded box (object space)
+  double qorigin[3], qcell[3]; // grid of the quantised nodes: plane = qorigin + q * qcell
   // node and triangle arrays as 32-bit offsets from DScene.blas_base (two registers per lane
   // instead of four), both in units of 128 B
-  uint32_t node_base;
+  uint32_t node_base;          // DNodeQ array
   uint32_t tri_base;           // pre-gathered triangles: f32 (36 B) or f64 (72 B) records
   uint32_t root;
   uint32_t tris_f32;           // 1: f32 records
   int32_t n_prims;
   uint32_t pad[3];
 };
-static_assert(sizeof(DAnyInst) == 176, "DAnyInst layout");
+static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 
 // Instance level of a group: a THREADED bounding-volume hierarchy (depth-first node list with
 // skip links, no stack).  Walk: i = first; a leaf (inst >= 0) is a candidate instance, go to
@@ -180,7 +193,7 @@ struct DScene {
   const double *time_tab;      // draw k of the per-tile time stream (sample index in the tile -> [0,1])
   double time_start, time_end; // Renderer sample_time_range
   int32_t has_motion;          // any time-sampled instance transform: traversal / shading evaluate them
-  int32_t multi_instance_groups;   // some group has more than one instance (else every shadow-queue entry names its instance)
+  int32_t multi_instance_groups;   // some SHADOW target group has more than one instance (else every shadow-queue entry names its instance)
   // camera (static case): eye, matrix rows, uv_size
   double cam_M[12];
   double cam_uv_size[2];

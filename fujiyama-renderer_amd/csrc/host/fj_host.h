@@ -6,6 +6,7 @@
 #define FJ_HOST_H
 
 #include "fj_scene_interface.h"
+#include "fj_plugin_abi.h"
 #include "fjgpu.h"
 
 #include <map>
@@ -60,16 +61,30 @@ struct Texture {
   int LoadFile(const std::string &path);
 };
 
+// a plugin DSO opened through the reference's protocol (fj_host_plugin.cc)
+struct LoadedPlugin {
+  void *dso;
+  fj::PluginInfo info;
+  std::vector<void *> instances;       // created through info.create_instance, deleted on close
+  LoadedPlugin() : dso(nullptr) {}
+};
+int OpenPluginDso(const char *filename, LoadedPlugin *out);   // 0 or a fj::PlgErrorNo
+void ClosePluginDso(LoadedPlugin *p);
+
 enum PluginKind { PLUGIN_SHADER, PLUGIN_PROCEDURE };
 struct Plugin {
   std::string name;       // PluginInfo.plugin_name, e.g. "PlasticShader"
   PluginKind kind;
-  int shader_type;        // FJ_SHADER_* for shader plugins
+  int shader_type;        // FJ_SHADER_* for shader plugins: the device implementation
+  std::unique_ptr<LoadedPlugin> loaded;   // the DSO when one was found; null: built in, known by name
+  ~Plugin() { if (loaded) ClosePluginDso(loaded.get()); }
 };
 
 struct Shader {
-  const Plugin *plugin;
+  Plugin *plugin;
+  void *instance;         // the DSO's own instance (its setters are called like the reference calls them) or null
   fj_shader_desc d;
+  Shader() : plugin(nullptr), instance(nullptr) {}
 };
 
 struct Procedure {

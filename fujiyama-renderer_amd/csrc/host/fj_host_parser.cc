@@ -174,8 +174,13 @@ struct Parser {
     else if (c == "SetStringProperty") st = SiSetStringProperty(ids[0], str[1], str[2]);
     else if (c == "SetSampleProperty3") st = SiSetSampleProperty3(ids[0], str[1], num[2], num[3], num[4], num[5]);
     else if (c == "ShowPropertyList") {
-      const PropertyInfo *p = SiGetPropertyList(str[0]);
-      for (; p && p->name; p++) std::printf("#   %-24s %d\n", p->name, p->nvalues);
+      // "(Type) : (Name) : (Default)" like print_property_list, tools/scene_parser/command.cc:584-650
+      const Property *p = SiGetPropertyList(str[0]);
+      if (!p) std::printf("#   No property is available for %s\n", str[0]);
+      for (; p && p->IsValid(); p++) {
+        const Vector4 &d = p->GetDefaultValue();
+        std::printf("#   %-15.15s : %-20.20s : (%g, %g, %g, %g)\n", p->GetTypeString(), p->GetName(), d.x, d.y, d.z, d.w);
+      }
     }
 
     if (makes_entry) {
@@ -246,6 +251,22 @@ const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int 
   if (height) *height = fb->GetHeight();
   if (nchannels) *nchannels = fb->GetChannelCount();
   return fb->GetReadOnly(0, 0, 0);
+}
+
+int fj_scene_property_table(const char *type_name, char *out, int out_size)
+{
+  const Property *p = SiGetPropertyList(type_name);
+  if (!p || !out || out_size <= 0) return -1;
+  std::string text;
+  char line[256];
+  for (; p->IsValid(); p++) {
+    const Vector4 &d = p->GetDefaultValue();
+    std::snprintf(line, sizeof(line), "%s %s %.17g %.17g %.17g %.17g\n", p->GetTypeString(), p->GetName(), d.x, d.y, d.z, d.w);
+    text += line;
+  }
+  if ((int) text.size() + 1 > out_size) return -1;
+  std::memcpy(out, text.c_str(), text.size() + 1);
+  return (int) text.size();
 }
 
 int fj_scene_last_stats(fj_render_stats *out)

@@ -329,7 +329,20 @@ static int set_property(long id, const std::string &name, int n, const double *v
   }
   case Type_Shader: {
     Shader *s = get(sc->shaders, e.index);
-    return s ? set_shader_property(s, name, n, v) : -1;
+    if (!s) return -1;
+    if (s->plugin && s->plugin->loaded) {
+      // PropFind(type, name) in the DSO's table, then its setter (src/fj_scene_interface.cc:1237-1275)
+      static const int types[5] = {fj::PROP_NONE, fj::PROP_SCALAR, fj::PROP_VECTOR2, fj::PROP_VECTOR3, fj::PROP_VECTOR4};
+      const fj::Property *q = fj::PropFind(s->plugin->loaded->info.property_list, types[n], name.c_str());
+      if (!q) return -1;
+      fj::PropertyValue pv;
+      pv.type = types[n];
+      pv.vector = fj::Vector4(v[0], n > 1 ? v[1] : 0, n > 2 ? v[2] : 0, n > 3 ? v[3] : 0);
+      if (s->instance && q->SetValue(s->instance, pv)) return -1;
+      (void) set_shader_property(s, name, n, v);
+      return 0;
+    }
+    return set_shader_property(s, name, n, v);
   }
   case Type_Procedure: {
     Procedure *p = get(sc->procedures, e.index);
@@ -556,27 +569,58 @@ static Status status_of(int err) { return err ? SI_FAIL : SI_SUCCESS; }
 
 int SiGetErrorNo(void) { return si_errno; }
 
-// A plugin is identified by its PluginInfo.plugin_name (reference
-// src/fj_plugin.cc:28-69 dlopens the DSO and asks it).  The device shaders and the
-// geometry procedures of the hot path are built in, keyed by the DSO's file
-// name (e.g. ".../PlasticShader.so"); anything else is refused loudly.
+// SiOpenPlugin (reference src/fj_scene_interface.cc:193-222 -> Plugin::Open, src/fj_plugin.cc:28-69).
+// The DSO is opened through the reference's own protocol when the loader finds it (fj_host_plugin.cc):
+// dlopen(name [+ ".so"]), Initialize(PluginInfo *), validation; PluginInfo.plugin_name then selects
+// the DEVICE implementation of a shader, and the DSO's Property table gives names, types and
+// defaults.  A shader DSO whose plugin_name has no device twin is refused loudly -- there is no
+// host shading path.  When no DSO of that name can be loaded, the plugins this build carries
+// itself (the five device shaders and the three geometry procedures of the hot path) are found by
+// the file's base name, e.g. ".../PlasticShader.so" or "PlasticShader".
+static const struct KnownPlugin { const char *name; PluginKind kind; int shader; } kKnownPlugins[] = {
+  {"PlasticShader", PLUGIN_SHADER, FJ_SHADER_PLASTIC}, {"ConstantShader", PLUGIN_SHADER, FJ_SHADER_CONSTANT},
+  {"GlassShader", PLUGIN_SHADER, FJ_SHADER_GLASS}, {"HairShader", PLUGIN_SHADER, FJ_SHADER_HAIR},
+  {"PathtracingShader", PLUGIN_SHADER, FJ_SHADER_PATHTRACING},
+  {"StanfordPlyProcedure", PLUGIN_PROCEDURE, 0}, {"CurveGeneratorProcedure", PLUGIN_PROCEDURE, 0},
+  {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0},
+};
+
 ID SiOpenPlugin(const char *filename)
 {
   Scene *sc = get_scene();
   if (!sc || !filename) return SI_BADID;
+  std::unique_ptr<LoadedPlugin> lp(new LoadedPlugin());
+  const int perr = OpenPluginDso(filename, lp.get());
+  if (perr == 0) {
+    const std::string name(lp->info.plugin_name), type(lp->info.plugin_type);
+    for (const auto &k : kKnownPlugins)
+      if (name == k.name && type == (k.kind == PLUGIN_SHADER ? "Shader" : "Procedure")) {
+        Plugin *p = new Plugin();
+        p->name = k.name; p->kind = k.kind; p->shader_type = k.shader;
+        p->loaded = std::move(lp);
+        sc->plugins.emplace_back(p);
+        set_errno(SI_ERR_NONE);
+        return encode_id(Type_Plugin, (int) sc->plugins.size() - 1);
+      }
+    ClosePluginDso(lp.get());
+    g_last_error = "plugin '" + name + "' (" + type + ", " + filename + ") has no device implementation";
+    set_errno(SI_ERR_FAILLOAD);
+    return SI_BADID;
+  }
+  if (perr != fj::PLG_ERR_PLUGIN_NOT_FOUND) {
+    // a DSO was found but is not a valid plugin: the reference's error numbers
+    static const int map[] = {SI_ERR_NONE, SI_ERR_PLUGIN_NOT_FOUND, SI_ERR_INIT_PLUGIN_FUNC_NOT_EXIST, SI_ERR_INIT_PLUGIN_FUNC_FAIL,
+        SI_ERR_BAD_PLUGIN_INFO, SI_ERR_CLOSE_PLUGIN_FAIL, SI_ERR_NO_MEMORY};
+    g_last_error = std::string("plugin '") + filename + "' is not a valid plugin";
+    set_errno(map[perr]);
+    return SI_BADID;
+  }
   std::string base(filename);
   const size_t slash = base.find_last_of("/\\");
   if (slash != std::string::npos) base = base.substr(slash + 1);
   const size_t dot = base.find_last_of('.');
   if (dot != std::string::npos) base = base.substr(0, dot);
-  static const struct { const char *name; PluginKind kind; int shader; } known[] = {
-    {"PlasticShader", PLUGIN_SHADER, FJ_SHADER_PLASTIC}, {"ConstantShader", PLUGIN_SHADER, FJ_SHADER_CONSTANT},
-    {"GlassShader", PLUGIN_SHADER, FJ_SHADER_GLASS}, {"HairShader", PLUGIN_SHADER, FJ_SHADER_HAIR},
-    {"PathtracingShader", PLUGIN_SHADER, FJ_SHADER_PATHTRACING},
-    {"StanfordPlyProcedure", PLUGIN_PROCEDURE, 0}, {"CurveGeneratorProcedure", PLUGIN_PROCEDURE, 0},
-    {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0},
-  };
-  for (const auto &k : known)
+  for (const auto &k : kKnownPlugins)
     if (base == k.name) {
       Plugin *p = new Plugin();
       p->name = k.name; p->kind = k.kind; p->shader_type = k.shader;
@@ -584,7 +628,7 @@ ID SiOpenPlugin(const char *filename)
       set_errno(SI_ERR_NONE);
       return encode_id(Type_Plugin, (int) sc->plugins.size() - 1);
     }
-  g_last_error = "plugin '" + base + "' has no device implementation";
+  g_last_error = "plugin '" + base + "' not found, and the build has no device implementation of that name";
   set_errno(SI_ERR_PLUGIN_NOT_FOUND);
   return SI_BADID;
 }
@@ -723,7 +767,7 @@ ID SiNewTexture(const char *filename)
 {
   Scene *sc = get_scene();
   if (!sc) return SI_BADID;
-  Texture *t = new Texture();
+  fjhost::Texture *t = new fjhost::Texture();
   sc->textures.emplace_back(t);
   if (t->LoadFile(filename ? filename : "")) {
     g_last_error = std::string("cannot load texture ") + (filename ? filename : "");
@@ -752,9 +796,22 @@ ID SiNewShader(ID plugin)
   if (!sc || e.type != Type_Plugin) return SI_BADID;
   Plugin *p = get(sc->plugins, e.index);
   if (!p || p->kind != PLUGIN_SHADER) return SI_BADID;
-  Shader *s = new Shader();
+  fjhost::Shader *s = new fjhost::Shader();
   s->plugin = p;
   shader_defaults(&s->d, p->shader_type);
+  if (p->loaded) {
+    // the DSO's instance (its create function applies the property defaults through its own
+    // setters, PropSetAllDefaultValues) and the DSO's defaults mirrored into the device parameters
+    s->instance = p->loaded->info.create_instance();
+    if (s->instance) p->loaded->instances.push_back(s->instance);
+    for (const Property *q = p->loaded->info.property_list; q && q->IsValid(); q++) {
+      const Vector4 &dv = q->GetDefaultValue();
+      const double v[4] = {dv.x, dv.y, dv.z, dv.w};
+      const int n = q->GetType() == PROP_SCALAR ? 1 : q->GetType() == PROP_VECTOR2 ? 2 : q->GetType() == PROP_VECTOR3 ? 3 :
+          q->GetType() == PROP_VECTOR4 ? 4 : 0;
+      if (n) (void) set_shader_property(s, q->GetName(), n, v);     // a property the device twin does not read is ignored
+    }
+  }
   sc->shaders.emplace_back(s);
   set_errno(SI_ERR_NONE);
   return encode_id(Type_Shader, (int) sc->shaders.size() - 1);
@@ -764,7 +821,7 @@ ID SiNewCurve(void)
 {
   Scene *sc = get_scene();
   if (!sc) return SI_BADID;
-  sc->curves.emplace_back(new Curve());
+  sc->curves.emplace_back(new fjhost::Curve());
   set_errno(SI_ERR_NONE);
   return encode_id(Type_Curve, (int) sc->curves.size() - 1);
 }
@@ -773,7 +830,7 @@ ID SiNewLight(int light_type)
 {
   Scene *sc = get_scene();
   if (!sc || light_type < SI_POINT_LIGHT || light_type > SI_DOME_LIGHT) return SI_BADID;
-  Light *l = new Light();
+  fjhost::Light *l = new fjhost::Light();
   std::memset(&l->d, 0, sizeof(l->d));
   l->d.type = light_type;
   l->d.color[0] = l->d.color[1] = l->d.color[2] = 1;
@@ -790,7 +847,7 @@ ID SiNewMesh(void)
 {
   Scene *sc = get_scene();
   if (!sc) return SI_BADID;
-  sc->meshes.emplace_back(new Mesh());
+  sc->meshes.emplace_back(new fjhost::Mesh());
   set_errno(SI_ERR_NONE);
   return encode_id(Type_Mesh, (int) sc->meshes.size() - 1);
 }
@@ -843,11 +900,20 @@ Status SiAssignTexture(ID id, const char *name, ID texture)
   const Entry e = decode_id(id), t = decode_id(texture);
   if (!sc || !name || t.type != Type_Texture || !get(sc->textures, t.index)) return SI_FAIL;
   if (e.type == Type_Shader) {
-    Shader *s = get(sc->shaders, e.index);
-    return s ? status_of(set_shader_texture(s, name, t.index)) : SI_FAIL;
+    fjhost::Shader *s = get(sc->shaders, e.index);
+    if (!s) return SI_FAIL;
+    if (s->plugin && s->plugin->loaded) {
+      const Property *q = PropFind(s->plugin->loaded->info.property_list, PROP_TEXTURE, name);
+      if (!q) return SI_FAIL;
+      // (the DSO only stores the pointer; it is never dereferenced: evaluate() does not run)
+      if (s->instance && q->SetValue(s->instance, PropTexture(reinterpret_cast<fj::Texture *>(get(sc->textures, t.index))))) return SI_FAIL;
+      (void) set_shader_texture(s, name, t.index);
+      return SI_SUCCESS;
+    }
+    return status_of(set_shader_texture(s, name, t.index));
   }
   if (e.type == Type_Light) {
-    Light *l = get(sc->lights, e.index);
+    fjhost::Light *l = get(sc->lights, e.index);
     if (!l || std::string(name) != "environment_map") return SI_FAIL;
     l->d.environment_map = t.index;
     return SI_SUCCESS;
@@ -864,7 +930,7 @@ Status SiAssignShader(ID object, const char *shading_group, ID shader)
   if (!op || !get(sc->shaders, s.index)) return SI_FAIL;
   int gid = 0;
   if (op->primset_type == FJ_PRIMSET_MESH) {   // Mesh::LookupFaceGroup, unknown -> 0
-    const Mesh *m = get(sc->meshes, op->primset);
+    const fjhost::Mesh *m = get(sc->meshes, op->primset);
     auto it = m->face_group_name.find(shading_group ? shading_group : "");
     gid = (it != m->face_group_name.end()) ? it->second : 0;
   }
@@ -917,30 +983,81 @@ Status SiSetStringProperty(ID id, const char *name, const char *string)
   return SI_SUCCESS;
 }
 
-const PropertyInfo *SiGetPropertyList(const char *type_name)
+// Property tables as the reference exposes them (SiGetPropertyList, src/fj_scene_interface.cc:1047-1051
+// -> get_property_list: a built-in type's table, else the table of the opened plugin of that name).
+// The built-in tables carry names, types and defaults (src/internal/fj_property_list_include.cc);
+// the setters live behind SiSetProperty* here, so the entries' own setter is null.
+namespace {
+struct PropRow { const char *name; int n; double v[4]; };
+const Property *make_table(const PropRow *rows, std::vector<Property> *keep)
 {
-  static const PropertyInfo renderer_props[] = {
+  for (const PropRow *r = rows; r->name; r++) {
+    PropertyValue pv = r->n == 1 ? PropScalar(r->v[0]) : r->n == 2 ? PropVector2(r->v[0], r->v[1]) :
+        r->n == 3 ? PropVector3(r->v[0], r->v[1], r->v[2]) : r->n == 4 ? PropVector4(r->v[0], r->v[1], r->v[2], r->v[3]) :
+        PropTexture(nullptr);
+    keep->push_back(Property(r->name, pv, nullptr));
+  }
+  keep->push_back(Property());
+  return keep->data();
+}
+}  // namespace
+
+const Property *SiGetPropertyList(const char *type_name)
+{
+  static const PropRow renderer_props[] = {
     {"sample_jitter", 1, {1}}, {"cast_shadow", 1, {1}}, {"max_diffuse_depth", 1, {3}}, {"max_reflect_depth", 1, {3}},
     {"max_refract_depth", 1, {3}}, {"sample_time_range", 2, {0, 1}}, {"resolution", 2, {320, 240}}, {"tilesize", 2, {32, 32}},
     {"filterwidth", 2, {2, 2}}, {"sampler_type", 1, {0}}, {"adaptive_max_subdivision", 1, {1}},
     {"adaptive_subdivision_threshold", 1, {.05}}, {"pixelsamples", 2, {3, 3}}, {"render_region", 4, {0, 0, 320, 240}},
     {"use_max_thread", 1, {1}}, {"thread_count", 1, {8}}, {nullptr, 0, {0}}};
-  static const PropertyInfo object_props[] = {
+  static const PropRow object_props[] = {
     {"transform_order", 1, {0}}, {"rotate_order", 1, {10}}, {"translate", 3, {0, 0, 0}}, {"rotate", 3, {0, 0, 0}},
     {"scale", 3, {1, 1, 1}}, {nullptr, 0, {0}}};
-  static const PropertyInfo camera_props[] = {
+  static const PropRow camera_props[] = {
     {"transform_order", 1, {0}}, {"rotate_order", 1, {10}}, {"translate", 3, {0, 0, 0}}, {"rotate", 3, {0, 0, 0}},
     {"fov", 1, {30}}, {"znear", 1, {.01}}, {"zfar", 1, {1000}}, {nullptr, 0, {0}}};
-  static const PropertyInfo light_props[] = {
+  static const PropRow light_props[] = {
     {"transform_order", 1, {0}}, {"rotate_order", 1, {10}}, {"translate", 3, {0, 0, 0}}, {"rotate", 3, {0, 0, 0}},
     {"scale", 3, {1, 1, 1}}, {"intensity", 1, {1}}, {"color", 3, {1, 1, 1}}, {"sample_count", 1, {16}},
     {"double_sided", 1, {0}}, {nullptr, 0, {0}}};
+  // the built-in shaders' tables = the Property tables of the reference's plugins (n = 0: a texture)
+  static const PropRow plastic_props[] = {      // shaders/plastic_shader/plastic_shader.cc:50-62
+    {"diffuse", 3, {.8, .8, .8}}, {"specular", 3, {1, 1, 1}}, {"ambient", 3, {1, 1, 1}}, {"roughness", 1, {.1}},
+    {"reflect", 3, {1, 1, 1}}, {"ior", 1, {1.4}}, {"opacity", 1, {1}}, {"diffuse_map", 0, {0}}, {"bump_map", 0, {0}},
+    {"bump_amplitude", 1, {1}}, {nullptr, 0, {0}}};
+  static const PropRow constant_props[] = {     // shaders/constant_shader/constant_shader.cc:28-32
+    {"diffuse", 3, {1, 1, 1}}, {"texture", 0, {0}}, {nullptr, 0, {0}}};
+  static const PropRow glass_props[] = {        // shaders/glass_shader/glass_shader.cc:38-46
+    {"diffuse", 3, {0, 0, 0}}, {"specular", 3, {1, 1, 1}}, {"ambient", 3, {1, 1, 1}}, {"filter_color", 3, {1, 1, 1}},
+    {"roughness", 1, {.1}}, {"ior", 1, {1.4}}, {nullptr, 0, {0}}};
+  static const PropRow hair_props[] = {         // shaders/hair_shader/hair_shader.cc:39-46
+    {"diffuse", 3, {1, 1, 1}}, {"specular", 3, {1, 1, 1}}, {"ambient", 3, {1, 1, 1}}, {"roughness", 1, {.1}},
+    {"reflect", 3, {1, 1, 1}}, {nullptr, 0, {0}}};
+  static const PropRow pathtracing_props[] = {  // shaders/pathtracing_shader/pathtracing_shader.cc:69-84
+    {"emission", 3, {0, 0, 0}}, {"diffuse", 3, {.8, .8, .8}}, {"specular", 3, {0, 0, 0}}, {"ambient", 3, {1, 1, 1}},
+    {"transmit", 3, {1, 1, 1}}, {"roughness", 1, {.1}}, {"reflect", 3, {0, 0, 0}}, {"refract", 3, {0, 0, 0}}, {"ior", 1, {1.4}},
+    {"opacity", 1, {1}}, {"diffuse_map", 0, {0}}, {"bump_map", 0, {0}}, {"bump_amplitude", 1, {1}}, {nullptr, 0, {0}}};
+  static const struct { const char *type; const PropRow *rows; } builtin[] = {
+    {"Renderer", renderer_props}, {"ObjectInstance", object_props}, {"Camera", camera_props}, {"Light", light_props},
+    {"PlasticShader", plastic_props}, {"ConstantShader", constant_props}, {"GlassShader", glass_props},
+    {"HairShader", hair_props}, {"PathtracingShader", pathtracing_props}};
+  static std::vector<Property> tables[sizeof(builtin) / sizeof(builtin[0])];
   if (!type_name) return nullptr;
   const std::string n(type_name);
-  if (n == "Renderer") return renderer_props;
-  if (n == "ObjectInstance") return object_props;
-  if (n == "Camera") return camera_props;
-  if (n == "Light") return light_props;
+  // an opened plugin DSO speaks for itself
+  if (Scene *sc = get_scene())
+    for (const auto &p : sc->plugins)
+      if (p->loaded && n == p->loaded->info.plugin_name) return p->loaded->info.property_list;
+  for (size_t i = 0; i < sizeof(builtin) / sizeof(builtin[0]); i++)
+    if (n == builtin[i].type) {
+      if (i >= 4) {      // a plugin's table exists once the plugin is opened (reference: get_property_list)
+        bool opened = false;
+        if (Scene *sc = get_scene()) for (const auto &p : sc->plugins) if (p->name == n) opened = true;
+        if (!opened) return nullptr;
+      }
+      if (tables[i].empty()) { tables[i].reserve(32); make_table(builtin[i].rows, &tables[i]); }
+      return tables[i].data();
+    }
   return nullptr;
 }
 

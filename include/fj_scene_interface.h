@@ -26,6 +26,7 @@
 
 #ifdef __cplusplus
 #include <vector>
+#include "fj_plugin_abi.h"       /* Property (SiGetPropertyList), the Shader plugin ABI */
 
 namespace fj {
 
@@ -149,9 +150,10 @@ Status SiSetProperty4(ID id, const char *name, double v0, double v1, double v2, 
 Status SiSetStringProperty(ID id, const char *name, const char *string);
 Status SiSetSampleProperty3(ID id, const char *name, double v0, double v1, double v2, double time);
 
-/* property introspection: NULL-name terminated array */
-struct PropertyInfo { const char *name; int nvalues; double defaults[4]; };
-const PropertyInfo *SiGetPropertyList(const char *type_name);
+/* property table of a built-in type ("Renderer", "ObjectInstance", "Camera", "Light") or of an
+ * opened plugin by its plugin name ("PlasticShader" ...), terminated by an invalid Property
+ * (reference src/fj_scene_interface.cc:1047-1051); NULL for an unknown name */
+const Property *SiGetPropertyList(const char *type_name);
 
 Status SiSetFrameReportCallback(ID id, void *data,
     FrameStartCallback frame_start, FrameAbortCallback frame_abort, FrameDoneCallback frame_done);
@@ -233,6 +235,10 @@ void fj_scene_set_deferred_render(int on);
 /* Flat description of the current scene as of the last RenderScene; pointers
  * stay valid until the next RenderScene / SiCloseScene. Returns 0 on success. */
 int fj_scene_get_desc(const fj_scene_desc **scene, const fj_render_desc **render);
+
+/* SiGetPropertyList(type_name) as text, one "type name v0 v1 v2 v3" line per property (the C
+ * spelling of the C++ Property table): bytes written, or -1 when no such table exists */
+int fj_scene_property_table(const char *type_name, char *out, int out_size);
 
 /* Float framebuffer of a FrameBuffer ID: returns pointer (W*H*C floats) or NULL */
 const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int *nchannels);

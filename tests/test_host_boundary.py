@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -184,3 +185,100 @@ def test_save_framebuffer_text_format(tmp_path):
     lines = out.read_text().splitlines()
     assert lines[0] == "#PTO Plain Text Object" and lines[2] == "resolution 4 2" and lines[3] == "channel_count 4"
     assert lines[4] == "begin pixels" and lines[-1] == "end pixels" and len(lines) == 4 * 2 + 6
+
+
+REF_SHADERS = "/root/reference/shaders"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SHADERS), reason="needs /root/reference (build container only)")
+def test_reference_shader_sources_load_as_plugins_through_the_dso_abi(tmp_path):
+    """The Shader plugin ABI (include/fj_plugin_abi.h).  The reference's five shader sources are
+    compiled UNCHANGED against include/ (they only #include "fj_shader.h"), the DSOs are opened by
+    SiOpenPlugin through the reference's protocol -- dlopen, Initialize(PluginInfo *), validation
+    (src/fj_plugin.cc:28-69) -- and identified by PluginInfo.plugin_name, not by file name.  The
+    DSO's own Property table is what SiGetPropertyList returns, its defaults equal the built-in
+    table of the device twin, and its setters are driven by SiSetProperty*."""
+    L = host.lib()
+    L.fj_SiOpenPlugin.restype = C.c_long
+    L.fj_SiOpenPlugin.argtypes = [C.c_char_p]
+    L.fj_SiNewShader.restype = C.c_long
+    L.fj_SiNewShader.argtypes = [C.c_long]
+    L.fj_SiSetProperty3.argtypes = [C.c_long, C.c_char_p, C.c_double, C.c_double, C.c_double]
+    L.fj_SiSetProperty1.argtypes = [C.c_long, C.c_char_p, C.c_double]
+    L.fj_scene_property_table.restype = C.c_int
+    L.fj_scene_property_table.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+
+    def table(name):
+        buf = C.create_string_buffer(8192)
+        n = L.fj_scene_property_table(name.encode(), buf, len(buf))
+        return None if n < 0 else buf.value.decode().splitlines()
+
+    builtins = {}
+    L.fj_SiOpenScene()
+    assert table("PlasticShader") is None                     # a plugin's table exists once it is opened
+    for name in ("PlasticShader", "GlassShader", "ConstantShader", "HairShader", "PathtracingShader"):
+        assert L.fj_SiOpenPlugin(name.encode()) >= 0           # no DSO of that name around: the built-in twin, by name
+        builtins[name] = table(name)
+        assert builtins[name]
+    L.fj_SiCloseScene()
+
+    # the same five, now as DSOs built from the reference's sources against OUR headers, under
+    # file names that say nothing about what is inside
+    L.fj_SiOpenScene()
+    for k, (src, name) in enumerate((("plastic", "PlasticShader"), ("glass", "GlassShader"), ("constant", "ConstantShader"),
+                                     ("hair", "HairShader"), ("pathtracing", "PathtracingShader"))):
+        so = str(tmp_path / ("plugin_%d.so" % k))
+        subprocess.run(["g++", "-std=c++11", "-O1", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include"),
+                        "-o", so, "%s/%s_shader/%s_shader.cc" % (REF_SHADERS, src, src)], check=True)
+        und = subprocess.run(["nm", "-D", "--undefined-only", so], stdout=subprocess.PIPE, text=True, check=True).stdout
+        need = [l.split()[-1] for l in und.splitlines() if "_ZN" in l and "2fj" in l or "_ZTIN2fj" in l]
+        exp = _exported("libfjscene.so")
+        assert [s for s in need if s not in exp] == []        # every fj:: symbol the DSO imports is exported
+        pid = L.fj_SiOpenPlugin(so[:-3].encode())             # ".so" is appended like OsDlopen does
+        assert pid >= 0, host.lib().fj_scene_last_error()
+        assert table(name) == builtins[name], (name, table(name), builtins[name])
+        sid = L.fj_SiNewShader(pid)
+        assert sid >= 0
+        if name != "ConstantShader":
+            assert L.fj_SiSetProperty1(sid, b"roughness", .25) == 0
+        assert L.fj_SiSetProperty3(sid, b"diffuse", .1, .2, .3) == 0
+        assert L.fj_SiSetProperty3(sid, b"no_such_property", 1, 2, 3) == -1
+        assert L.fj_SiSetProperty1(sid, b"diffuse", 1) == -1               # PropFind is by type AND name
+    L.fj_SiCloseScene()
+
+    # a whole scene through the DSOs: the flat description the HIP core receives (shader
+    # parameters after the setters' clamps included) is the one the built-in twins produce --
+    # checked through the CPU oracle, which reads nothing but that description
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+    text = workloads.teapot(str(tmp_path / "assets"), res=(32, 32), spp=(1, 1), mesh="tiny", nlights=3)
+    frames = []
+    for use_dso in (False, True):
+        t = text
+        if use_dso:
+            t = t.replace("OpenPlugin plastic_shader PlasticShader", "OpenPlugin plastic_shader %s" % (tmp_path / "plugin_0"))
+            t = t.replace("OpenPlugin glass_shader GlassShader", "OpenPlugin glass_shader %s" % (tmp_path / "plugin_1"))
+            t = t.replace("OpenPlugin constant_shader ConstantShader", "OpenPlugin constant_shader %s" % (tmp_path / "plugin_2"))
+            assert t.count("plugin_") == 3
+        host.run_scene_text(t, deferred=True)
+        sp, rd = host.get_desc()
+        osc = oracle_ffi.OracleScene(sp)
+        frames.append(osc.render(rd, threads=2)[0])
+        osc.close()
+    assert frames[0][..., 3].max() > 0 and np.array_equal(frames[0], frames[1])
+    host.close_scene()
+
+    # a DSO that is no plugin, and one whose plugin has no device twin
+    L.fj_SiOpenScene()
+    bad = str(tmp_path / "not_a_plugin.so")
+    (tmp_path / "x.cc").write_text("int forty_two() { return 42; }\n")
+    subprocess.run(["g++", "-fPIC", "-shared", "-o", bad, str(tmp_path / "x.cc")], check=True)
+    assert L.fj_SiOpenPlugin(bad.encode()) == -1 and L.fj_SiGetErrorNo() == 6      # SI_ERR_INIT_PLUGIN_FUNC_NOT_EXIST
+    other = str(tmp_path / "other.so")
+    src = open("%s/constant_shader/constant_shader.cc" % REF_SHADERS).read().replace('"ConstantShader"', '"MyOwnShader"')
+    (tmp_path / "other.cc").write_text(src)
+    subprocess.run(["g++", "-std=c++11", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include"), "-o", other,
+                    str(tmp_path / "other.cc")], check=True)
+    assert L.fj_SiOpenPlugin(other.encode()) == -1
+    assert "no device implementation" in host.lib().fj_scene_last_error().decode()
+    L.fj_SiCloseScene()
