@@ -63,12 +63,20 @@ def parse_args():
                     help="diagnostic: on ONE GPU render only the tiles rank 0 of an N-GPU job would own (per-rank cost)")
     ap.add_argument("--device-build", action="store_true",
                     help="build the BLAS on the GPU (LBVH: faster prepare, slower trace) instead of the host SAH build")
+    ap.add_argument("--rank-costs", type=int, default=0,
+                    help="diagnostic: on ONE GPU time the tile share of EVERY rank of an N-GPU job (max over ranks = the N-GPU frame "
+                         "time before the gather)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 counter passes (HBM traffic, VALU issue) that feed the roofline object")
     return ap.parse_args()
 
 
-def algorithmic_bytes(st, s_node, s_prim):
+def algorithmic_bytes(st, s_node, s_prim, s_node_walk=None):
     closest = st.rays_traced - st.rays.shadow
-    return (st.nodes_visited * s_node + st.prims_tested * s_prim + st.insts_tested * S_INST +
+    nodes = st.nodes_visited * s_node
+    if s_node_walk is not None:        # the shadow walk's nodes at its own record size
+        nodes = (st.nodes_visited - st.shadow_nodes) * s_node + st.shadow_nodes * s_node_walk
+    return (nodes + st.prims_tested * s_prim + st.insts_tested * S_INST +
             closest * (S_RAY_IN + S_HIT_OUT) + st.shadow_traversed * S_SHADOW)
 
 
@@ -102,7 +110,7 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
                 head = f.read(24)
             seconds = struct.unpack("<d", head[16:24])[0]
             return {"value": sample_rays / seconds / 1e6, "unit": "Mray/s",
-                    "cores": min(os.cpu_count() or 1, len(sample_ids)), "host_cores": os.cpu_count() or 1,
+                    "cores": min(os.cpu_count() or 1, len(sample_ids)), "host_cores": os.cpu_count() or 1, "cpu_model": cpu_model(),
                     "kind": "reference", "sample": desc, "seconds": seconds, "rays": int(sample_rays)}
         except Exception as e:  # fall through to the port
             sys.stderr.write("cpu_baseline: reference run failed (%s); using the CPU restatement\n" % e)
@@ -113,8 +121,73 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
     _, rc = osc.render(render, tile_ids=sample_ids, threads=cores)
     seconds = time.perf_counter() - t0
     osc.close()
-    return {"value": rc.total() / seconds / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": desc, "seconds": seconds, "rays": int(rc.total())}
+    return {"value": rc.total() / seconds / 1e6, "unit": "Mray/s", "cores": cores, "host_cores": os.cpu_count() or 1,
+            "cpu_model": cpu_model(), "kind": "port", "sample": desc, "seconds": seconds, "rays": int(rc.total())}
+
+
+PMC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+            ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
+             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
+
+
+def pmc_passes(args, kname):
+    """Hardware counters of the dominant kernel for THIS build, measured now: one rocprofv3
+    --kernel-trace --pmc pass per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass,
+    /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"; never combined with other
+    trace domains), each running this script as a child for one timed frame.  Returns
+    {counter: value per launch of the production instantiation}, or None when rocprofv3 is
+    not usable here."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out, tmp = {}, tempfile.mkdtemp(prefix="fjpmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-tiles", "0", "--no-pmc",
+             "--workload", args.workload]
+    if args.mesh:
+        child += ["--mesh", args.mesh]
+    if args.res:
+        child += ["--res"] + [str(v) for v in args.res]
+    if args.spp:
+        child += ["--spp"] + [str(v) for v in args.spp]
+    if args.device_build:
+        child += ["--device-build"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for k, cs in enumerate(PMC_SETS):
+            d = os.path.join(tmp, "p%d" % k)
+            cmd = [exe, "--kernel-trace", "--pmc"] + list(cs) + ["--output-format", "csv", "-d", d, "--"] + child
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            tot, launches = {}, {}
+            for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    # the production instantiation: first template argument (event counting) false
+                    if kname + "<false" not in name:
+                        continue
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    launches.setdefault(r["Counter_Name"], set()).add(r["Dispatch_Id"])
+            for c, v in tot.items():
+                out[c] = v / max(1, len(launches[c]))
+        return out or None
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("bench: rocprofv3 counter passes failed (%s): roofline.traffic is null\n" % e)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -156,6 +229,8 @@ def main():
         gpu.global_option("device_build", 1)
     gs = gpu.Scene(scene_ptr, device=local_rank)
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
+    # the lean any-hit walk reads the quantised 64-byte twin of a node
+    s_node_walk = gs.query("anyhit_node_record_bytes") if gs.query("lean_anyhit") else s_node
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
     if os.environ.get("FJGPU_OVERLAP"):            # experiment switch: light loop + shadow walk on a second stream
@@ -204,7 +279,7 @@ def main():
     # ---------------- aggregate over ranks
     rays_local = float(sum(s.rays.total() for s in stats))
     trace_ms_local = float(sum(s.trace_ms for s in stats))
-    alg_bytes_local = float(algorithmic_bytes(counted, s_node, s_prim)) * len(stats)
+    alg_bytes_local = float(algorithmic_bytes(counted, s_node, s_prim, s_node_walk)) * len(stats)
     launches_local = float(sum(s.trace_launches for s in stats))
     agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
     mx = agg.clone()
@@ -222,51 +297,73 @@ def main():
         # bytes of its launches (its own event counts from the counting frame x record sizes) over
         # the summed HIP-event durations of exactly those launches in the timed frames.
         nf = len(stats)
-        walk_alg = float(counted.shadow_nodes * s_node + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
+        walk_alg = float(counted.shadow_nodes * s_node_walk + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
                          counted.shadow_traversed * S_SHADOW) * nf
         walk_ms = float(sum(s.shadow_walk_ms for s in stats))
         walk_nl = float(sum(s.shadow_walk_launches for s in stats))
         achieved = walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
         kname = "k_shadow_anyhit" if gs.query("lean_anyhit") else "k_shadow_trace"
         # ... and of the whole traversal side (closest-hit walk + light loop + shadow walk), as before
-        alg = float(algorithmic_bytes(counted, s_node, s_prim)) * nf
+        alg = float(algorithmic_bytes(counted, s_node, s_prim, s_node_walk)) * nf
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
-        # HBM traffic of the same kernels from the PMC passes committed under profiles/
-        # (rocprofv3 cannot run inside this process): per frame, spread over this run's launches
-        traffic, traffic_all, traffic_src = None, None, None
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tp) and args.workload == "dragon" and not (args.mesh or args.res or args.spp) and world == 1:
-            with open(tp) as f:
-                tj = json.load(f)
-            tk = tj["kernels"].get(kname)
-            if tk and walk_nl:
-                traffic = (2 * tk["fetch_kb_per_frame"] + tk["write_kb_per_frame"]) * 1024.0 * nf / walk_nl
-            traffic_all = tj["hbm_bytes_per_frame"] * nf / nl if nl else None
-            traffic_src = "profiles/r01_traffic.json"
+        # Hardware counters of the SAME build, measured now by rocprofv3 child passes of this
+        # script (pmc_passes): HBM traffic = 2 x FETCH_SIZE (gfx950 tallies a 128-byte request at
+        # 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KB; VALU issue = ACTIVE_INST_VALU
+        # quad-cycles / (SIMDs x elapsed quad-cycles); lane efficiency = THREAD_CYCLES_VALU /
+        # (64 x ACTIVE_INST_VALU).
+        traffic, traffic_src, pmc, issue = None, None, None, None
+        if world == 1 and not args.no_pmc and args.as_rank_of <= 1:
+            pmc = pmc_passes(args, kname)
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE doubled: gfx950)"
+        if pmc and pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES") and pmc.get("SQ_ACTIVE_INST_VALU"):
+            props = torch.cuda.get_device_properties(device)
+            simds = props.multi_processor_count * 4
+            elapsed_q = pmc["SQ_WAVE_CYCLES"] / pmc["SQ_WAVES"]          # persistent waves live for the whole launch
+            busy = pmc["SQ_ACTIVE_INST_VALU"] / (simds * elapsed_q)
+            lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+            issue = {"valu_busy": busy, "lane_efficiency": lane, "useful_valu_issue": busy * lane,
+                     "waves_waiting_on_memory": pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
+                     "waves_stalled_at_issue": pmc.get("SQ_WAIT_INST_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
+                     "valu_wave_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "simds": simds,
+                     "note": "FP64 / packed-FP32 VALU issue is the bound that binds this walk: 4 cycles per wave instruction, "
+                             "one VALU per SIMD; the HBM side is hbm_counters"}
+        avg_ms = walk_ms / walk_nl if walk_nl else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src,
+                "note": "achieved = algorithmic bytes of SURVEY 8(d) (what the walk must READ, mostly served by L1 / L2) over "
+                        "the kernel's HIP-event time; hbm_counters = what came from HBM; valu_issue = the bound that binds",
+                "hbm_counters": ({"GBps": traffic / (avg_ms * 1e-3) / 1e9, "frac_of_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "traffic_over_algorithmic": traffic / (walk_alg / walk_nl)} if traffic and avg_ms else None),
+                "valu_issue": issue,
                 "kernel": kname, "launches": int(walk_nl),
-                "avg_launch_ms": walk_ms / walk_nl if walk_nl else None,
+                "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
                 "share_of_frame": walk_ms / max(1e-9, float(sum(s.total_ms for s in stats))),
                 "bytes_per_ray": walk_alg / max(1.0, float(counted.shadow_traversed) * nf),
-                "record_bytes": {"node": s_node, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW},
+                "record_bytes": {"node": s_node, "node_shadow_walk": s_node_walk, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN,
+                                 "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW},
                 "kernel_ms_per_frame_rank0": {"k_trace_closest": float(sum(s.closest_ms for s in stats)) / nf,
                                               "k_shadow_cull": float(sum(s.light_loop_ms for s in stats)) / nf,
                                               kname: walk_ms / nf},
                 "all_traversal_kernels": {"kernel": "k_trace_closest+k_shadow_cull+" + kname, "launches": int(nl),
                                           "achieved": alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
                                           "frac": (alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0) / HBM_PEAK_GBPS,
-                                          "algorithmic_bytes_per_frame": alg / nf, "traffic_per_frame": traffic_all * nl / nf if traffic_all else None,
+                                          "algorithmic_bytes_per_frame": alg / nf,
                                           "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * nf)}}
+        # rays that actually walk a BLAS (camera / reflect / ... closest-hit rays + the shadow rays
+        # that survive the instance-box cull), next to the SlTrace-event count of the metric
+        walked = float(sum((s.rays.total() - s.rays.shadow) for s in stats)) + float(counted.shadow_traversed) * nf
         out = {
             "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
             "value": total_rays / elapsed_max / 1e6,
             "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "traversed_Mray_s": walked / elapsed_max / 1e6 if world == 1 else None,
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s-class scene, %dx%d, %dx%d spp, tile %dx%d, %d tiles, 32 point lights"
@@ -284,6 +381,20 @@ def main():
                                                "resolve": s0.resolve_ms, "total": s0.total_ms}},
             "roofline": roof,
         }
+        if world == 1 and args.rank_costs > 1:
+            # per-rank cost of an N-GPU job, every rank's tile share timed on this one GPU
+            # (tile t -> rank t % N): the slowest share bounds the N-GPU frame before the gather
+            costs = []
+            for rk in range(args.rank_costs):
+                tiles_r = fjdist.tiles_of_rank(n_tiles, rk, args.rank_costs)
+                gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)      # warm
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)
+                torch.cuda.synchronize(device)
+                costs.append((time.perf_counter() - t1) / 3 * 1e3)
+            out["config"]["rank_costs_ms"] = {"ranks": args.rank_costs, "per_rank": costs, "max": max(costs),
+                                              "speedup_before_gather": out["ms_per_step"] / max(costs)}
         if world == 1 and args.cpu_tiles != 0:
             # bounded CPU sample: a block of tiles in the middle of the frame, two tiles per
             # host core (the reference hands whole tiles to its worker threads)

@@ -351,10 +351,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
   for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
-  // (only SHADOW target groups matter: the lean any-hit walk is the one consumer of this flag)
-  S.multi_instance_groups = 0;
-  for (const DInstance &I : hs.instances)
-    if (I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1) S.multi_instance_groups = 1;
+  S.pad_ = 0;
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   S.lrec_hair = nullptr;
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
@@ -484,6 +481,7 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (!scene || !name || !value) return fail(FJGPU_EINVAL, "bad query call");
   const std::string n(name);
   if (n == "node_record_bytes") { *value = (double) sizeof(DNode); return 0; }
+  if (n == "anyhit_node_record_bytes") { *value = (double) sizeof(DNodeQ); return 0; }
   if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }

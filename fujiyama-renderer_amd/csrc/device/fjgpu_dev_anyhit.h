@@ -48,9 +48,7 @@ __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 #endif
 
-// kMulti = false: every shadow group of the scene has one instance, so every queue entry carries
-// its instance (the instance-BVH walk and its registers are compiled out).
-template <bool kCount, bool kMulti>
+template <bool kCount>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
     uint32_t n, uint32_t *head, uint32_t *s_stack, LocalCounters *lc)
 {
@@ -117,7 +115,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (fin) {
         fetch = true;
         if (have) {
-          if (kMulti && gi < gend) fetch = false;    // the group has more instances: the same ray goes on
+          if (gi < gend) fetch = false;    // the group has more instances: the same ray goes on
           else {
             // reached the light: add c (an opaque occluder would have added c * (1 - Os) = 0)
             const DShadowRay *q = &squeue[idx];
@@ -138,7 +136,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
             have = true;
             idx = my;
-            if (!kMulti || g < 0) { gi = g; gend = 0; }
+            if (g < 0) { gi = g; gend = 0; }
             else { gi = S.groups[g].first; gend = gi + S.groups[g].count; }
           }
         }
@@ -151,7 +149,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const double tmax = q->tmax;
         V3 winv = o;
         bool plain = false, single = false, dead = false;
-        if (kMulti && gi >= 0) {
+        if (gi >= 0) {
           // BoxRayIntersect's -0.0 quirk: such a ray fails every box test in the reference
           dead = has_negative_zero(d);
           winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
@@ -162,7 +160,6 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         for (;;) {
           int inst = -1;
           if (gi < 0) { inst = ~gi; gi = gend = 0; if (kCount) lc->insts++; }     // its box test passed in the light loop
-          else if (!kMulti) break;
           else {
             while (gi < gend) {
               const DTNode *tn_ = &S.group_nodes[gi];
@@ -304,23 +301,21 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #endif
 }
 
-// blocks per CU (= waves per SIMD).  Measured on C3: 5 waves at 96 VGPRs (no spills, f32 nodes) ran
-// exactly as fast as 4 -- the walk is bound by the L1 request rate and VALU issue, not by latency --
-// and any spill in the loop doubled the frame time: 4 waves, 128 VGPRs, no spills.
+// blocks per CU (= waves per SIMD).  Measured on C3: an instantiation without the instance-BVH walk
+// ran 5 waves at 96 VGPRs without spills exactly as fast as this one runs 4 (76.4 ms both: the walk
+// is bound by VALU issue and the L1 request rate, not by latency), and any spill in the loop doubled
+// the frame time: 4 waves, 128 VGPRs, no spills, one instantiation.
 #ifndef FJ_ANYHIT_MINB
 #define FJ_ANYHIT_MINB 4
 #endif
-#ifndef FJ_ANYHIT_MINB_MULTI
-#define FJ_ANYHIT_MINB_MULTI 4
-#endif
-template <bool kCount, bool kMulti>
-__global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
+template <bool kCount>
+__global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
+  traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

@@ -154,9 +154,9 @@ static unsigned persistent_grid(unsigned long long blocks_needed, int blocks_per
 size_t persistent_threads() { return (size_t) persistent_grid(~0ull, PERSIST_BLOCKS_PER_CU_MAX) * BLOCK; }
 
 // blocks per CU of the lean any-hit walk: what its registers and LDS stack allow
-static int anyhit_blocks_per_cu(bool multi)
+static int anyhit_blocks_per_cu()
 {
-  int b = multi ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB;
+  int b = FJ_ANYHIT_MINB;
   if (const char *e = getenv("FJGPU_ANYHIT_BLOCKS")) b = atoi(e);
   if (b < 1) b = 1;
   if (b > PERSIST_BLOCKS_PER_CU_MAX) b = PERSIST_BLOCKS_PER_CU_MAX;
@@ -165,10 +165,11 @@ static int anyhit_blocks_per_cu(bool multi)
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
+    t.refill_curves = env("FJGPU_TRAV_REFILL_CURVES", 24);   // the ribbon-test instantiations: C5 4.09 s with 24, 4.60 s with 40
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 256);
     // lean any-hit walk: up to `anyhit_steps` inner steps per iteration, the 2nd and later ones only
@@ -262,10 +263,9 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
-#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
-    if (S.multi_instance_groups) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
-    else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
-#undef FJ_LAUNCH_ANYHIT
+    const dim3 grid(persistent_grid(1ull << 30, anyhit_blocks_per_cu()));
+    if (count_events) hipLaunchKernelGGL(k_shadow_anyhit<true>, grid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+    else hipLaunchKernelGGL(k_shadow_anyhit<false>, grid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }

@@ -193,7 +193,7 @@ struct DScene {
   const double *time_tab;      // draw k of the per-tile time stream (sample index in the tile -> [0,1])
   double time_start, time_end; // Renderer sample_time_range
   int32_t has_motion;          // any time-sampled instance transform: traversal / shading evaluate them
-  int32_t multi_instance_groups;   // some SHADOW target group has more than one instance (else every shadow-queue entry names its instance)
+  int32_t pad_;
   // camera (static case): eye, matrix rows, uv_size
   double cam_M[12];
   double cam_uv_size[2];

@@ -253,6 +253,15 @@ const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int 
   return fb->GetReadOnly(0, 0, 0);
 }
 
+int fj_write_fb_file(const char *filename, int width, int height, int nchannels, const float *pixels)
+{
+  if (!filename || !pixels || width <= 0 || height <= 0 || nchannels <= 0) return -1;
+  FrameBuffer fb;
+  fb.Resize(width, height, nchannels);
+  std::memcpy(fb.GetWritable(0, 0, 0), pixels, sizeof(float) * (size_t) width * height * nchannels);
+  return WriteFrameBuffer(filename, fb);
+}
+
 int fj_scene_property_table(const char *type_name, char *out, int out_size)
 {
   const Property *p = SiGetPropertyList(type_name);

@@ -240,6 +240,10 @@ int fj_scene_get_desc(const fj_scene_desc **scene, const fj_render_desc **render
  * spelling of the C++ Property table): bytes written, or -1 when no such table exists */
 int fj_scene_property_table(const char *type_name, char *out, int out_size);
 
+/* The .fb writer of SiSaveFrameBuffer (plain-text PTO, reference src/fj_framebuffer_io.cc:46-68) on a
+ * caller's pixel array [height][width][nchannels] float32: 0 or -1 */
+int fj_write_fb_file(const char *filename, int width, int height, int nchannels, const float *pixels);
+
 /* Float framebuffer of a FrameBuffer ID: returns pointer (W*H*C floats) or NULL */
 const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int *nchannels);
 

@@ -131,7 +131,8 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 int fjgpu_global_option(const char *name, long value);
 
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).
- * "node_record_bytes" (128), "tri_record_bytes" (36 when every mesh is stored as exact f32
+ * "node_record_bytes" (128; "anyhit_node_record_bytes" 64: the lean any-hit walk reads the quantised
+ * twin of a node), "tri_record_bytes" (36 when every mesh is stored as exact f32
  * triangles, else 72), "blas_nodes", "stack_need", "lean_anyhit" (1: shadow rays are walked by
  * k_shadow_anyhit, 0: by the general k_shadow_trace).  Returns 0 or FJGPU_EINVAL. */
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);

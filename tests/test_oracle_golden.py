@@ -341,3 +341,61 @@ def test_oracle_thread_count_invariance(asset_dir):
     b, rb = osc.render(rd, threads=7)
     osc.close()
     assert np.array_equal(a, b) and ra.as_dict() == rb.as_dict()
+
+
+REF_SCENES = "/root/reference/scenes"
+REF_RENDER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_render")
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_SCENES) and os.path.exists(REF_RENDER)), reason="needs /root/reference and oracle/_ref")
+@pytest.mark.parametrize("scene,mesh", [("teapot", "tiny"), ("happy_buddhas", "tiny"), ("xyzrgb_dragon", "small"), ("furry_bunny", "furball")])
+def test_reference_scene_text_through_the_parser_matches_the_reference_render(scene, mesh, asset_dir, tmp_path):
+    """The caller's side of the boundary on the reference's OWN scene text: scenes/<name>.scn --
+    the hand-maintained twin of scenes/<name>.py: its cameras, 32 lights, transforms, shader and
+    group assignments verbatim -- with only the asset / output PATHS replaced (the scans and HDR
+    maps are not in the image: synthetic meshes and sky) and one line added, a render_region that
+    bounds the CPU time (a region only selects tiles).  The unmodified reference renders it
+    (oracle/_ref/ref_render) and writes its .fb; the product's command parser reads the same text
+    (deferred: no GPU here), and the CPU restatement renders the flat description it produced:
+    same pixels, bit for bit.  The product's .fb writer, fed the reference's pixels, writes the
+    reference's .fb file byte for byte (src/fj_framebuffer_io.cc:46-68)."""
+    import re
+    import struct
+    import subprocess
+    from fujiyama_renderer_amd import synth
+    a = synth.ensure_assets(asset_dir, (mesh,))
+    text = open(os.path.join(REF_SCENES, scene + ".scn")).read()
+    text, n_mip = re.subn(r"\S*\.mip\b", a["sky"], text)
+    text, n_floor = re.subn(r"\S*/floor\.ply\b", a["floor"], text)
+    text, n_dome = re.subn(r"\S*/dome\.ply\b", a["dome"], text)
+    text, n_mesh = re.subn(r"\.\./\.\./ply/\w+\.ply\b", a[mesh], text)
+    fb_path = str(tmp_path / (scene + ".fb"))
+    text, n_fb = re.subn(r"(SaveFrameBuffer\s+\S+\s+)\S+", lambda m: m.group(1) + fb_path, text)
+    assert (n_mip, n_floor, n_dome, n_mesh, n_fb) == (1, 1, 1, 1, 1)
+    text, n_res = re.subn(r"(SetProperty2\s+ren1\s+resolution\s+640\s+480[^\n]*\n)", r"\1SetProperty4 ren1 render_region 256 192 384 256\n", text)
+    assert n_res == 1
+    scn = str(tmp_path / (scene + ".scn"))
+    with open(scn, "w") as f:
+        f.write(text)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(REF_RENDER))
+    subprocess.run([REF_RENDER, scn, scn + ".fjfb"], check=True, env=env, stdout=subprocess.DEVNULL, timeout=900)
+    with open(scn + ".fjfb", "rb") as f:
+        b = f.read()
+    w, h, c = struct.unpack("<iii", b[4:16])
+    ref = np.frombuffer(b[24:], dtype=np.float32).reshape(h, w, c).copy()
+    assert (w, h, c) == (640, 480, 4) and ref[192:256, 256:384, 3].max() > 0 and not ref[:192].any()
+
+    # the product's parser, same text (its own SaveFrameBuffer goes to another file: in deferred
+    # mode nothing is rendered, the frame is black)
+    host.run_scene_text(text.replace(fb_path, str(tmp_path / "deferred.fb")), deferred=True)
+    sp, rd = host.get_desc()
+    assert (rd.xres, rd.yres, tuple(rd.region)) == (640, 480, (256, 192, 384, 256)) and rd.rate_x == 3
+    osc = oracle_ffi.OracleScene(sp)
+    fb, _ = osc.render(rd, threads=8)
+    osc.close()
+    assert np.array_equal(fb, ref), float(np.abs(fb - ref).max())
+
+    ours = str(tmp_path / "ours.fb")
+    assert host.lib().fj_write_fb_file(ours.encode(), w, h, c, ref.ctypes.data_as(C.c_void_p)) == 0
+    assert open(ours, "rb").read() == open(fb_path, "rb").read()
+    host.close_scene()
