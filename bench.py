@@ -134,9 +134,10 @@ def pmc_passes(args, kname):
     """Hardware counters of the dominant kernel for THIS build, measured now: one rocprofv3
     --kernel-trace --pmc pass per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass,
     /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"; never combined with other
-    trace domains), each running this script as a child for one timed frame.  Returns
-    {counter: value per launch of the production instantiation}, or None when rocprofv3 is
-    not usable here."""
+    trace domains), each running this script as a child for ONE timed frame.  Returns
+    {counter: sum over the launches of the production instantiation in that frame} (the child may
+    cut the frame into another number of launches than the parent: per-frame sums are comparable,
+    per-launch ones are not), or None when rocprofv3 is not usable here."""
     import csv
     import glob
     import shutil
@@ -161,17 +162,12 @@ def pmc_passes(args, kname):
             d = os.path.join(tmp, "p%d" % k)
             cmd = [exe, "--kernel-trace", "--pmc"] + list(cs) + ["--output-format", "csv", "-d", d, "--"] + child
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
-            tot, launches = {}, {}
             for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
                 for r in csv.DictReader(open(f)):
-                    name = r["Kernel_Name"]
                     # the production instantiation: first template argument (event counting) false
-                    if kname + "<false" not in name:
+                    if kname + "<false" not in r["Kernel_Name"]:
                         continue
-                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-                    launches.setdefault(r["Counter_Name"], set()).add(r["Dispatch_Id"])
-            for c, v in tot.items():
-                out[c] = v / max(1, len(launches[c]))
+                    out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         return out or None
     except Exception as e:  # noqa: BLE001
         sys.stderr.write("bench: rocprofv3 counter passes failed (%s): roofline.traffic is null\n" % e)
@@ -315,8 +311,10 @@ def main():
         traffic, traffic_src, pmc, issue = None, None, None, None
         if world == 1 and not args.no_pmc and args.as_rank_of <= 1:
             pmc = pmc_passes(args, kname)
-        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        launches_per_frame = walk_nl / nf if nf else 1.0
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and launches_per_frame:
+            # (per frame in the child -> per launch of this run)
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / launches_per_frame
             traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE doubled: gfx950)"
         if pmc and pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES") and pmc.get("SQ_ACTIVE_INST_VALU"):
             props = torch.cuda.get_device_properties(device)
@@ -327,7 +325,7 @@ def main():
             issue = {"valu_busy": busy, "lane_efficiency": lane, "useful_valu_issue": busy * lane,
                      "waves_waiting_on_memory": pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
                      "waves_stalled_at_issue": pmc.get("SQ_WAIT_INST_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
-                     "valu_wave_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "simds": simds,
+                     "valu_wave_instructions_per_frame": pmc.get("SQ_INSTS_VALU"), "simds": simds,
                      "note": "FP64 / packed-FP32 VALU issue is the bound that binds this walk: 4 cycles per wave instruction, "
                              "one VALU per SIMD; the HBM side is hbm_counters"}
         avg_ms = walk_ms / walk_nl if walk_nl else None

@@ -73,8 +73,19 @@ class SceneInterface(object):
         self.commands.append("RenderScene %s" % renderer)
 
     def NewTexture(self, name, filename):
-        # .hdr/.jpg pre-conversion (hdr2mip / jpg2mip) is a file-format tool
-        # outside the hot path; textures are given as .mip directly.
+        # .mip as is; .hdr is converted to a .mip in a temp directory first, like the reference's
+        # emitter does with its hdr2mip tool (reference fujiyama.py:222-236,335-347)
+        root, ext = os.path.splitext(filename)
+        if ext == ".hdr":
+            import tempfile
+            import uuid
+            from . import host
+            if not getattr(self, "tempdir", ""):
+                self.tempdir = tempfile.mkdtemp()
+            mip = os.path.join(self.tempdir, "%s_%s.mip" % (uuid.uuid4(), os.path.basename(root)))
+            if host.lib().fj_hdr2mip(filename.encode(), mip.encode()) != 0:
+                raise RuntimeError("hdr2mip failed for %s" % filename)
+            filename = mip
         self.commands.append("NewTexture %s %s" % (name, filename))
 
     def SaveFrameBuffer(self, framebuffer, filename):

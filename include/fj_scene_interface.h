@@ -244,6 +244,10 @@ int fj_scene_property_table(const char *type_name, char *out, int out_size);
  * caller's pixel array [height][width][nchannels] float32: 0 or -1 */
 int fj_write_fb_file(const char *filename, int width, int height, int nchannels, const float *pixels);
 
+/* Radiance .hdr (RGBE, flat or run-length encoded) -> the tiled .mip a Texture reads: the reference's
+ * tools/hdr2mip (resampled to powers of two, tiles of 64; src/fj_mipmap.cc:246-300).  0 or -1. */
+int fj_hdr2mip(const char *hdr_path, const char *mip_path);
+
 /* Float framebuffer of a FrameBuffer ID: returns pointer (W*H*C floats) or NULL */
 const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int *nchannels);
 

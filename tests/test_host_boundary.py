@@ -282,3 +282,71 @@ def test_reference_shader_sources_load_as_plugins_through_the_dso_abi(tmp_path):
     assert L.fj_SiOpenPlugin(other.encode()) == -1
     assert "no device implementation" in host.lib().fj_scene_last_error().decode()
     L.fj_SiCloseScene()
+
+
+def _write_hdr(path, img, rle):
+    """Radiance RGBE writer for the test (flat or new-style RLE scanlines): img [h, w, 3] float"""
+    h, w, _ = img.shape
+    m = img.max(axis=2)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int64)
+    scale = np.where(m > 1e-32, 256.0 / np.exp2(e.astype(np.float64)), 0.0)
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    rgbe[..., :3] = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            if not rle:
+                f.write(rgbe[y].tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                row, x = rgbe[y, :, c], 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 4:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        n = 1
+                        while x + n < w and n < 128 and not (x + n + 3 < w and row[x + n] == row[x + n + 1] == row[x + n + 2] == row[x + n + 3]):
+                            n += 1
+                        f.write(bytes([n]) + row[x:x + n].tobytes())
+                        x += n
+
+
+REF_HDR2MIP = os.path.join(ROOT, "oracle", "_ref", "hdr2mip")
+
+
+@pytest.mark.parametrize("shape,rle", [((128, 256), True), ((150, 300), True), ((64, 64), False), ((40, 100), False), ((9, 7), False)])
+def test_hdr2mip_matches_the_reference_converter(shape, rle, tmp_path):
+    """bin/hdr2mip (tools/hdr2mip of the reference; src/fj_mipmap.cc:246-300): RGBE decode of flat
+    and run-length encoded scanlines, resampling to powers of two, tiling -- the .mip is the
+    reference converter's byte for byte, and the host's texture loader reads it back."""
+    rng = np.random.RandomState(shape[0] * 1000 + shape[1])
+    h, w = shape
+    img = rng.uniform(0, 1, size=(h, w, 3)) ** 3 * rng.choice([.01, 1, 40], size=(h, w, 1))
+    img[: h // 3, : w // 2] = (.25, .5, 8.0)               # long runs for the RLE coder
+    img[h // 2, :] = 0
+    hdr = str(tmp_path / "t.hdr")
+    _write_hdr(hdr, img, rle)
+    ours = str(tmp_path / "ours.mip")
+    tool = os.path.join(ROOT, "fujiyama-renderer_amd", "bin", "hdr2mip")
+    subprocess.run([tool, hdr, ours], check=True)
+    b = open(ours, "rb").read()
+    assert b[:4] == b"MIPM"
+    ver, mw, mh, nc, ts = np.frombuffer(b[4:24], dtype="<i4")
+    p2 = lambda v: 1 << int(np.ceil(np.log2(v)))
+    assert (ver, mw, mh, nc, ts) == (1, p2(w), p2(h), 3, min(64, p2(w), p2(h))) and len(b) == 24 + mw * mh * 3 * 4
+    if os.path.exists(REF_HDR2MIP):
+        ref = str(tmp_path / "ref.mip")
+        subprocess.run([REF_HDR2MIP, hdr, ref], check=True, stdout=subprocess.DEVNULL,
+                       env=dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(REF_HDR2MIP)))
+        assert open(ref, "rb").read() == b
+    # ... and the emitter converts a .hdr texture on the way (reference fujiyama.py:222-236)
+    si = fujiyama.SceneInterface(parse_args=False)
+    si.NewTexture("tex1", hdr)
+    line = si.text().strip()
+    assert line.startswith("NewTexture tex1 ") and line.endswith(".mip") and open(line.split()[-1], "rb").read() == b
