@@ -321,6 +321,9 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     bool fits = lo != UINTPTR_MAX && lo % 128 == 0 && (hi - lo) / 128 < 0xffffffffull;
     for (const DPrimSet &P : dps)
       if (P.qnodes && (((uintptr_t) P.qnodes - lo) % 128 != 0 || (tris_of(P) - lo) % 128 != 0)) fits = false;
+    // the lean walk reads f32 triangle records only (every PLY mesh): a mesh that needs f64
+    // vertices sends the scene's shadow rays through the general walk
+    for (const DPrimSet &P : dps) if (P.qnodes && !P.tri_verts32) fits = false;
     S.blas_base = fits ? (const char *) lo : nullptr;
     if (!fits && lo != UINTPTR_MAX && getenv("FJGPU_VERBOSE"))
       fprintf(stderr, "fjgpu: BLAS arrays span %zu bytes from %p: no 32-bit offsets, the general shadow walk is used\n", (size_t) (hi - lo), (void *) lo);
@@ -351,7 +354,16 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (!hs.cam_static) e |= M.upload(&hs.cam_xform, 1, &S.cam_xform);
   S.has_motion = hs.xforms.empty() ? 0 : 1;
   for (const auto &ps : hs.primsets) if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) S.has_motion = 1;   // vertex velocities need the ray's time too
-  S.pad_ = 0;
+  // shadow rays start at objects whose shader gathers light (SlIlluminance: plastic, hair) and go to
+  // that object's shadow target group
+  S.multi_shadow_groups = 0;
+  for (const DInstance &I : hs.instances) {
+    bool gathers = false;
+    for (int k = 0; k < I.n_shaders; k++)
+      if (I.shaders[k] >= 0 && (hs.shaders[I.shaders[k]].type == FJ_SHADER_PLASTIC || hs.shaders[I.shaders[k]].type == FJ_SHADER_HAIR)) gathers = true;
+    if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1)
+      S.multi_shadow_groups = 1;
+  }
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
   S.lrec_hair = nullptr;
   e |= M.upload(dtex.data(), dtex.size(), &S.textures);
@@ -419,6 +431,9 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     }
     sc->max_children = std::max(sc->max_children, k);
   }
+  S.incoherent_rays = (sc->max_children >= 2 || sc->bounce_diffuse) ? 1 : 0;
+  if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
+  S.pad_inc_ = 0;
   HIP_TRY(hipDeviceSynchronize());
   *out = sc.release();
   return 0;

@@ -37,6 +37,33 @@ __device__ __forceinline__ uint32_t opaque_lane_id()
 #else
 #define FJ_SCHED_FENCE() do { } while (0)
 #endif
+// tri_ray (fjgpu_dev_math.h) statement for statement, with scheduling fences between its steps:
+// left to itself the scheduler overlaps them and the leaf phase needs a dozen registers more than
+// the 96 the walk runs 5 waves with
+__device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
+{
+  const V3 edge1 = v1 - v0;
+  const V3 edge2 = v2 - v0;
+  FJ_SCHED_FENCE();
+  const V3 pvec = cross(dir, edge2);
+  const double det = dot(edge1, pvec);
+  FJ_SCHED_FENCE();
+  if (det > -1e-6 && det < 1e-6) return false;
+  const double inv_det = 1.0 / det;
+  FJ_SCHED_FENCE();
+  const V3 tvec = orig - v0;
+  const double uu = dot(tvec, pvec) * inv_det;
+  if (uu < 0.0 || uu > 1.0) return false;
+  FJ_SCHED_FENCE();
+  const V3 qvec = cross(tvec, edge1);
+  const double vv = dot(dir, qvec) * inv_det;
+  if (vv < 0.0 || uu + vv > 1.0) return false;
+  *t = dot(edge2, qvec) * inv_det;
+  *u = uu;
+  *v = vv;
+  return true;
+}
+
 #ifdef FJ_PHASE_STATS
 // debug build only: wave-level phase executions and the lanes active in them
 __device__ unsigned long long g_phase[16];
@@ -48,7 +75,9 @@ __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 #endif
 
-template <bool kCount>
+// kMulti = false: every shadow group that can receive shadow rays has one instance, so every queue
+// entry names its instance (the instance-BVH walk and its registers are compiled out).
+template <bool kCount, bool kMulti>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
     uint32_t n, uint32_t *head, uint32_t *s_stack, LocalCounters *lc)
 {
@@ -70,7 +99,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   tune.grab = adaptive_grab(tune.grab, n);
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
-  V3 oo = mk(0, 0, 0), od = oo;
+  V3 oo = mk(0, 0, 0), od = oo;            // object-space ray (f64: the triangle test's operands)
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #ifdef FJ_EXP_SLAB_VALIDATE
   V3 inv_keep = oo;
@@ -79,8 +108,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
   const float tmin32 = 9.9999e-5f;         // <= .0001
   int gi = 0, gend = 0;                    // cursor in the group's instance BVH; gi < 0: ~instance, settled by the light loop
-  uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base
-  bool tris_f32 = true;
+  uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base (triangles: f32 records, see fjgpu_api.hip)
   uint32_t cur = TRAV_DONE;
   int sp = 0;
   const double tmin = .0001;
@@ -115,7 +143,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (fin) {
         fetch = true;
         if (have) {
-          if (gi < gend) fetch = false;    // the group has more instances: the same ray goes on
+          if (kMulti && gi < gend) fetch = false;    // the group has more instances: the same ray goes on
           else {
             // reached the light: add c (an opaque occluder would have added c * (1 - Os) = 0)
             const DShadowRay *q = &squeue[idx];
@@ -136,7 +164,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
             have = true;
             idx = my;
-            if (g < 0) { gi = g; gend = 0; }
+            if (!kMulti || g < 0) { gi = g; gend = 0; }
             else { gi = S.groups[g].first; gend = gi + S.groups[g].count; }
           }
         }
@@ -149,7 +177,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const double tmax = q->tmax;
         V3 winv = o;
         bool plain = false, single = false, dead = false;
-        if (gi >= 0) {
+        if (kMulti && gi >= 0) {
           // BoxRayIntersect's -0.0 quirk: such a ray fails every box test in the reference
           dead = has_negative_zero(d);
           winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
@@ -160,6 +188,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         for (;;) {
           int inst = -1;
           if (gi < 0) { inst = ~gi; gi = gend = 0; if (kCount) lc->insts++; }     // its box test passed in the light loop
+          else if (!kMulti) break;
           else {
             while (gi < gend) {
               const DTNode *tn_ = &S.group_nodes[gi];
@@ -179,19 +208,24 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           }
           const DAnyInst *A = &S.any_insts[inst];
           if (A->n_prims == 0) continue;
-          oo = xpoint(A->Minv, o);
-          od = xvector(A->Minv, d);
-          if (has_negative_zero(od)) continue;
-          const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
-          double tn;
-          if (!slab(A->bounds, A->bounds + 3, oo, inv, tmin, tmax, &tn)) continue;
-          s32 = slab32q_setup(oo, inv, A->qorigin, A->qcell);
+          const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
+          if (has_negative_zero(od_)) continue;
+          oo = oo_; od = od_;
+          const V3 inv = mk(filter_rcp(od_.x), filter_rcp(od_.y), filter_rcp(od_.z));
+          // the primitive set's own box: only where several instances are tried (a ray that misses
+          // it finds no child box at the root either; in the single-instance walk the 12 registers
+          // of the box cost more than that one node)
+          if (kMulti) {
+            double tn;
+            if (!slab(A->bounds, A->bounds + 3, oo_, inv, tmin, tmax, &tn)) continue;
+          }
+          s32 = slab32q_setup(oo_, inv, A->qorigin, A->qcell);
 #ifdef FJ_EXP_SLAB_VALIDATE
-          inv_keep = mk(1. / od.x, 1. / od.y, 1. / od.z);
+          inv_keep = mk(1. / od_.x, 1. / od_.y, 1. / od_.z);
           vinst = inst;
 #endif
           tmax32 = f32_above(tmax);
-          node_base = A->node_base; tri_base = A->tri_base; tris_f32 = A->tris_f32 != 0;
+          node_base = A->node_base; tri_base = A->tri_base;
           cur = A->root; sp = 0;
           break;
         }
@@ -278,9 +312,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         if (kCount) lc->prims++;
         const double tmax = squeue[idx].tmax;
         V3 v0, v1, v2;
-        const char *tris = S.blas_base + ((size_t) tri_base << 7);
-        load_tri(tris_f32 ? nullptr : (const double *) tris, tris_f32 ? (const float *) tris : nullptr, first, &v0, &v1, &v2);
-        if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+        load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
+        FJ_SCHED_FENCE();
+        if (tri_ray_fenced(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
           PH(10, 1);
         }
@@ -301,21 +335,23 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #endif
 }
 
-// blocks per CU (= waves per SIMD).  Measured on C3: an instantiation without the instance-BVH walk
-// ran 5 waves at 96 VGPRs without spills exactly as fast as this one runs 4 (76.4 ms both: the walk
-// is bound by VALU issue and the L1 request rate, not by latency), and any spill in the loop doubled
-// the frame time: 4 waves, 128 VGPRs, no spills, one instantiation.
+// blocks per CU (= waves per SIMD): what the registers allow WITHOUT a spill (any spill in the loop
+// doubled the frame time): the instantiation without the instance-BVH walk fits 96 VGPRs = 5 waves,
+// the general one needs 128 = 4 waves.
 #ifndef FJ_ANYHIT_MINB
-#define FJ_ANYHIT_MINB 4
+#define FJ_ANYHIT_MINB 5
 #endif
-template <bool kCount>
-__global__ void __launch_bounds__(BLOCK, FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
+#ifndef FJ_ANYHIT_MINB_MULTI
+#define FJ_ANYHIT_MINB_MULTI 4
+#endif
+template <bool kCount, bool kMulti>
+__global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

@@ -4,6 +4,12 @@
 #ifndef FJGPU_DEV_CURVE_H
 #define FJGPU_DEV_CURVE_H
 
+#ifdef FJ_PHASE_STATS
+__device__ unsigned long long g_curve_stat[8];
+#define FJ_CURVE_STAT(i, v) atomicAdd(&g_curve_stat[i], (unsigned long long) (v))
+#else
+#define FJ_CURVE_STAT(i, v) do { } while (0)
+#endif
 // --------------------------------------------------------- curve test (a23)
 // Curve::ray_intersect + converge_bezier3, reference src/fj_curve.cc:187-232,300-390
 // (Nakamaru-Ono subdivision in ray space).  The reference recurses with a
@@ -150,6 +156,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
   while (j < nleaf) {
+    FJ_CURVE_STAT(0, 1);                    // leaf walks (outer iterations)
     Bz b = root;
     double v0 = 0, vn = 1;
     int L0 = 0;
@@ -166,6 +173,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
     }
     bool pruned = false;
     for (int L = L0;; L++) {
+      FJ_CURVE_STAT(1, 1);                  // nodes visited (inner iterations)
       // (a node taken from the cache passed this test when it was stored)
       if (!(L0 == CL && L == CL && use_cache) && bz_misses_ray(b)) {
         const uint32_t span = 1u << (depth - L);

@@ -89,6 +89,11 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
       // (per pair it cost two dependent loads -- node, then box -- before any arithmetic)
       if (g_single) { for (int q = 0; q < 6; q++) sb[q] = g_sbounds[q]; g_inst = S.group_nodes[g_first].inst; }
     }
+    // A surface point well inside that box (every point of the occluder itself, but for its outermost
+    // 2e-4) needs no box test per light: the unit-length ray leaves the box at t >= 2e-4 > tmin and
+    // entered it at t <= 0 < distance, which is all BoxRayIntersect asks for (src/fj_box.cc:73-138).
+    const bool deep_inside = active && g_single &&
+        Ps.x > sb[0] + 2e-4 && Ps.x < sb[3] - 2e-4 && Ps.y > sb[1] + 2e-4 && Ps.y < sb[4] - 2e-4 && Ps.z > sb[2] + 2e-4 && Ps.z < sb[5] - 2e-4;
     // the light index is wave-uniform: the sample's 72 bytes come through the scalar cache into
     // SGPRs instead of 64 identical vector loads
     for (uint32_t l = 0; l < nl; l++) {
@@ -173,7 +178,8 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
           if (sp.cast_shadow) {
             c_shadow++;
             // group bounds test + leaf bounds of the instance BVH, as culling
-            if (!has_negative_zero(Ln)) {
+            if (deep_inside) maybe_occluded = !has_negative_zero(Ln);
+            else if (!has_negative_zero(Ln)) {
               const V3 winv = mk(filter_rcp(Ln.x), filter_rcp(Ln.y), filter_rcp(Ln.z));
               const bool plain = plain_dir(Ln);
               if (g_single) {

@@ -277,6 +277,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         // lanes that can make progress without a second-stage result: at an inner node or a fresh leaf
         const unsigned long long busym = __ballot(have && !deep && cur != TRAV_DONE);
         if ((unsigned) __popcll(pendm) >= tune.leaf_wait || busym == 0ull) {
+          if (lane == (unsigned) __ffsll((long long) pendm) - 1u) { FJ_CURVE_STAT(2, 1); FJ_CURVE_STAT(3, __popcll(pendm)); }   // second-stage execs / lanes
                 if (carrying) {
             bool stop = false;
             const size_t sl = pend;
@@ -290,6 +291,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {
               const int pid = (int) FJ_G(uint32_t, P->prim_ids)[sl];
+              FJ_CURVE_STAT(4, 1);          // second-stage tests that hit
               if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
                 best.t = t; best.u = u; best.v = (double) sl; best.inst = ii; best.prim = pid;
                 stop = anyhit;
@@ -304,6 +306,183 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
             }
           }
         }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------- phase-scheduled walk (meshes)
+// The same walk for scenes without curve sets, scheduled like the lean any-hit walk
+// (fjgpu_dev_anyhit.h): a lane is in TURNOVER (no BLAS walk in progress: idle, finished, or between
+// the instances of its group), at an INNER node or at a LEAF, and every iteration the wave runs ONE
+// phase -- the one most lanes wait for; turnover once tune.refill lanes collected there or nothing
+// else can run -- instead of every phase in turn with whoever happens to be there.  The leaf phase
+// tests one triangle per lane and execution.  Same tests, same order per ray (instances in the
+// group's order, children near to far, the leaf's triangles in slot order), same tie rules.
+template <bool kCount, bool kMotion, class Policy>
+__device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
+{
+  const unsigned lane = __lane_id();
+  bool head_live = true;
+  uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
+  tune.grab = adaptive_grab(tune.grab, n);
+  bool have = false;
+  uint32_t idx = 0;
+  V3 o = mk(0, 0, 0), oo = o, od = o, d = o;
+  Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double tmin = 0, tmax = 0, rtime = 0;
+  Best best;
+  best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+  int ti = 0, tend = 0, ii = -1;           // cursor in the group's threaded instance BVH
+  int group = 0;
+  bool anyhit = false;
+  const DPrimSet *P = nullptr;
+  const DNode *nodes = nullptr;
+  uint32_t cur = TRAV_DONE;
+  int sp = 0;
+
+  for (;;) {
+    const bool fin = cur == TRAV_DONE;
+    const bool at_leaf = !fin && (cur & FJ_LEAF_FLAG);
+    const bool at_inner = !fin && !at_leaf;
+    const unsigned n_leaf = (unsigned) __popcll(__ballot(at_leaf)), n_inner = (unsigned) __popcll(__ballot(at_inner));
+    const bool can_fetch = head_live || next < range_end;
+    const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
+
+    if ((unsigned) __popcll(m_turn) >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
+      if (m_turn == 0ull) break;
+      // ---- turnover: fetch, enter the next instance, or retire
+      if (next >= range_end && head_live) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
+        base = __shfl(base, 0);
+        if (base >= n) head_live = false;
+        else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
+      }
+      const bool fetch = fin && !have;
+      const unsigned long long m_fetch = __ballot(fetch);
+      if (fetch) {
+        const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t) (m_fetch >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_fetch, 0u));
+        if (my < range_end) {
+          RayIn r;
+          r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
+          have = pol.fetch(my, &r);
+          idx = my;
+          o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          if (kMotion) rtime = r.time;
+          group = r.group;
+          ti = S.groups[group].first; tend = ti + S.groups[group].count;
+          best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
+          sp = 0;
+        }
+      }
+      next += (uint32_t) __popcll(m_fetch);
+      if (next > range_end) next = range_end;
+      if (fin && have) {
+        bool found = false;
+        const bool dead_ray = has_negative_zero(d);   // every box test of the reference fails (BoxRayIntersect's -0.0 quirk)
+        const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
+        const bool plain = plain_dir(d);
+        const bool single = S.groups[group].n_instances == 1;
+        const double *gsb = S.groups[group].sbounds;
+        while (!dead_ray && ti < tend) {
+          const DTNode *tn_ = &S.group_nodes[ti];
+          if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
+            double tq;
+            ti = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? ti + 1 : tn_->skip;
+            continue;
+          }
+          ii = tn_->inst;
+          ti++;
+          const DInstance *I = &S.instances[ii];
+          if (kCount) lc->insts++;
+          double tn;
+          const double tfar = anyhit ? tmax : fmin(tmax, best.t);
+          // the reference's own (possibly non-enclosing) instance box, full ray range
+          if (!box_ray_ref_fast(single ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+          if (kMotion && I->xform >= 0) {
+            double tm[12], tmi[12];
+            xform_at(&S.xforms[I->xform], rtime, tm, tmi);
+            oo = xpoint(tmi, o);
+            od = xvector(tmi, d);
+          } else {
+            oo = xpoint(I->Minv, o);
+            od = xvector(I->Minv, d);
+          }
+          if (has_negative_zero(od)) continue;
+          const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
+          P = &S.primsets[I->primset];
+          nodes = P->nodes;
+          if (P->n_prims == 0) continue;
+          if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+          s32 = slab32_setup(oo, inv, P->bounds);
+          found = true;
+          break;
+        }
+        if (found) { cur = P->root; sp = 0; }
+        else { pol.finish(idx, best); have = false; }
+      }
+      continue;
+    }
+
+    if (n_inner >= n_leaf) {
+      // ---- inner nodes; further steps without a new vote while enough lanes stay at inner nodes
+      for (uint32_t step = 0;; step++) {
+        const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
+        if (step > 0 && (step >= tune.steps || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner)) break;
+        if (in_now) {
+          const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
+          if (kCount) lc->nodes++;
+          const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+          const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
+          const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
+          const float tmin32 = f32_below(tmin), tmax32 = f32_above(tf2);
+          float t0, t1, t2, t3;
+          const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);
+          const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);
+          const bool h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
+          const bool h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
+          // near-to-far order is a heuristic only: f32 keys, misses sort last
+          float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY;
+          float k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
+          uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
+#define FJ_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? ka : kb; const uint32_t tr = sw ? ra : rb; ka = sw ? kb : ka; ra = sw ? rb : ra; kb = tk; rb = tr; }
+          FJ_CSWAP(k0, r0, k1, r1) FJ_CSWAP(k2, r2, k3, r3) FJ_CSWAP(k0, r0, k2, r2) FJ_CSWAP(k1, r1, k3, r3) FJ_CSWAP(k1, r1, k2, r2)
+#undef FJ_CSWAP
+          const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
+          if (nh == 0) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
+          else {
+            cur = r0;
+            if (nh > 3) stk.push(sp, r3);
+            if (nh > 2) stk.push(sp, r2);
+            if (nh > 1) stk.push(sp, r1);
+          }
+        }
+      }
+    } else {
+      // ---- leaves: ONE triangle per lane (FP64 Moller-Trumbore on the pre-gathered vertices)
+      if (at_leaf) {
+        const uint32_t first = (cur & 0x7fffffffu) >> 3;
+        const uint32_t more = cur & 7u;
+        bool stop = false;
+        double t, u = 0, v = 0;
+        if (kCount) lc->prims++;
+        V3 v0, v1, v2;
+        load_tri(P->tri_verts, P->tri_verts32, first, &v0, &v1, &v2);
+        if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
+          const FJ_GLOBAL double *w = FJ_G(double, P->tri_vel) + (size_t) first * 9;
+          v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
+        }
+        if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+          const int pid = (int) FJ_G(uint32_t, P->prim_ids)[first];
+          if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+            best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
+            stop = anyhit;
+          }
+        }
+        if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
+        else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
+        else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
       }
     }
   }
@@ -353,6 +532,29 @@ __global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : 
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
   traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc);
+  if (kCount) {
+    flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
+  }
+}
+
+// The phase-scheduled walk (traverse_phased) as the closest-hit kernel of mesh scenes whose secondary
+// rays are INCOHERENT (glass: two children per hit, pathtracing: diffuse bounces).  Measured, closest-hit
+// time per frame, this kernel (128 VGPRs, 4 waves) against k_trace_closest<false> (168, 3 waves): C4
+// 903 vs 1167 ms, C2 20.2 vs 21.3, C3 (coherent camera and mirror rays into one dense mesh) 31.3 vs 30.4
+// -- so the launcher picks by the scene's shaders.
+#ifndef FJ_PHASED_MINB
+#define FJ_PHASED_MINB 4
+#endif
+template <bool kCount>
+__global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(DScene S, const DRay *rays, const DPath *paths,
+    DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
+{
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  ClosestPolicy pol;
+  pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
+  LocalCounters lc = {0, 0, 0};
+  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

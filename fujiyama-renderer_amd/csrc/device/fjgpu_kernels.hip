@@ -154,9 +154,9 @@ static unsigned persistent_grid(unsigned long long blocks_needed, int blocks_per
 size_t persistent_threads() { return (size_t) persistent_grid(~0ull, PERSIST_BLOCKS_PER_CU_MAX) * BLOCK; }
 
 // blocks per CU of the lean any-hit walk: what its registers and LDS stack allow
-static int anyhit_blocks_per_cu()
+static int anyhit_blocks_per_cu(bool multi)
 {
-  int b = FJ_ANYHIT_MINB;
+  int b = multi ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB;
   if (const char *e = getenv("FJGPU_ANYHIT_BLOCKS")) b = atoi(e);
   if (b < 1) b = 1;
   if (b > PERSIST_BLOCKS_PER_CU_MAX) b = PERSIST_BLOCKS_PER_CU_MAX;
@@ -210,6 +210,10 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
   if (S.has_motion) {      // time-sampled instance transforms: one general instantiation
     if (count_events) FJ_LAUNCH_CLOSEST(true, true, true); else FJ_LAUNCH_CLOSEST(true, false, true);
   } else if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false); }
+  else if (S.incoherent_rays) {   // glass / pathtracing scenes: the phase-scheduled walk (see k_trace_closest_phased)
+    if (count_events) hipLaunchKernelGGL(k_trace_closest_phased<true>, grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+    else hipLaunchKernelGGL(k_trace_closest_phased<false>, grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+  }
   else { if (count_events) FJ_LAUNCH_CLOSEST(false, true, false); else FJ_LAUNCH_CLOSEST(false, false, false); }
 #undef FJ_LAUNCH_CLOSEST
   LAUNCH_CHECK();
@@ -263,9 +267,10 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
-    const dim3 grid(persistent_grid(1ull << 30, anyhit_blocks_per_cu()));
-    if (count_events) hipLaunchKernelGGL(k_shadow_anyhit<true>, grid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
-    else hipLaunchKernelGGL(k_shadow_anyhit<false>, grid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
+    if (S.multi_shadow_groups) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
+    else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
+#undef FJ_LAUNCH_ANYHIT
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
@@ -306,6 +311,14 @@ void debug_phase_stats()
   fprintf(stderr, "fjgpu phase slab32 validation: %llu box tests, %llu lost (must be 0), %llu extra\n", tests, lost, extra);
 #endif
 #ifdef FJ_PHASE_STATS
+  {
+    unsigned long long c[8];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_curve_stat), sizeof(c)) == hipSuccess && c[2]) {
+      fprintf(stderr, "fjgpu phase curves: second-stage execs %llu lanes %llu tests-hit %llu leaf-walks %llu nodes %llu\n", c[2], c[3], c[4], c[0], c[1]);
+      unsigned long long z[8] = {0};
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_curve_stat), z, sizeof(z));
+    }
+  }
   unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
   static const char *names[16] = {"iters", "entry_execs", "entry_lanes", "inner_execs", "inner_lanes", "leaf_execs", "leaf_lanes",

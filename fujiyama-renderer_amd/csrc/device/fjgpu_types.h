@@ -187,13 +187,17 @@ struct DScene {
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
+  int32_t incoherent_rays;     // some shader emits two children per hit or diffuse bounces (glass, pathtracing): the
+                               // closest-hit walk of such mesh scenes is the phase-scheduled one
+  int32_t pad_inc_;
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
   const fj_xform_desc *xforms; // instances with DInstance.xform >= 0
   const fj_xform_desc *cam_xform;   // null = static camera
   const double *time_tab;      // draw k of the per-tile time stream (sample index in the tile -> [0,1])
   double time_start, time_end; // Renderer sample_time_range
   int32_t has_motion;          // any time-sampled instance transform: traversal / shading evaluate them
-  int32_t pad_;
+  int32_t multi_shadow_groups; // a shadow target group of more than one instance can receive shadow rays (else every
+                               // shadow-queue entry names its instance: the leaner any-hit instantiation)
   // camera (static case): eye, matrix rows, uv_size
   double cam_M[12];
   double cam_uv_size[2];
