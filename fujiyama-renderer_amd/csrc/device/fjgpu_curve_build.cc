@@ -18,6 +18,14 @@
 
 namespace fjgpu {
 
+// largest ribbon radius within piece `sgm` of `S` equal parametric pieces (+ rounding slack)
+static double PieceRadius(double w0, double w1, int sgm, int S)
+{
+  const double va = (double) sgm / S, vb = (double) (sgm + 1) / S;
+  const double ra = .5 * ((1 - va) * w0 + va * w1), rb = .5 * ((1 - vb) * w0 + vb * w1);
+  return std::max(ra, rb) * (1 + 1e-9) + 1e-15;
+}
+
 static int split_depth_limit(const double *cp, double epsilon)
 {
   const int N = 4;
@@ -62,7 +70,7 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   // splits; a piece's box is the hull of ITS control points + the ribbon radius; every piece
   // refers to the same curve, whose full test runs once per ray (the traversal remembers the
   // curve it tested last), so the result is the reference's whichever piece was entered.
-  int seg_depth = 2;
+  int seg_depth = 3;      // (with per-piece radii: C5 3.06 s at 2, 2.63 s at 3, 2.58 s at 4 -- and twice the BLAS slots each step)
   if (const char *e = getenv("FJGPU_CURVE_SEGDEPTH")) seg_depth = std::max(0, std::min(4, atoi(e)));
   const int S = 1 << seg_depth;
   std::vector<PrimRef> refs((size_t) c.n_curves * S);
@@ -70,7 +78,6 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
     const int i0 = c.indices[i];
     if (i0 < 0 || i0 + 3 >= c.n_points) { *err = "curve index out of range"; return FJGPU_EINVAL; }
     const double w0 = c.width[i0], w1 = c.width[i0 + 3];
-    const double radius = .5 * (w0 > w1 ? w0 : w1);
     // pieces by repeated midpoint subdivision (control polygons; hull property).  With vertex
     // velocities the same subdivision of the end-of-shutter curve (P + velocity) bounds the
     // piece at time 1; positions are linear in time, so the two hulls bound the whole sweep.
@@ -100,6 +107,11 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
       subdivide(endcp, pieces_end);
     }
     for (int sgm = 0; sgm < S; sgm++) {
+      // the ribbon's radius within this piece: the width is linear in the curve parameter
+      // (split_bezier3 halves it, src/fj_curve.cc:488-508) and the test prunes and accepts with the
+      // widths of the sub-segment at hand, so a piece needs the larger of ITS two end radii, not the
+      // curve's (fur tapers from .003 to .0001: the tip pieces are 4-30 times thinner)
+      const double piece_radius = PieceRadius(w0, w1, sgm, S);
       double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
       for (int k = 0; k < 4; k++)
         for (int a = 0; a < 3; a++) {
@@ -117,7 +129,7 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
         // the ribbon test accepts points within `radius` of the curve in ray space; pad a
         // little more (and for the rounding of the subdivision) so the cull is never the
         // tighter test
-        const double pad = radius * 1.0000001 + 1e-12 + 1e-9 * (std::fabs(mn[a]) + std::fabs(mx[a]));
+        const double pad = piece_radius * 1.0000001 + 1e-12 + 1e-9 * (std::fabs(mn[a]) + std::fabs(mx[a]));
         r.bmin[a] = RoundDown2(mn[a] - pad);
         r.bmax[a] = RoundUp2(mx[a] + pad);
         r.c[a] = (float) (.5 * (mn[a] + mx[a]));
@@ -174,7 +186,7 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
       return std::sqrt(d2);
     };
     const double w0 = c.width[i0], w1 = c.width[i0 + 3];
-    const double radius = .5 * (w0 > w1 ? w0 : w1);
+    const double radius = PieceRadius(w0, w1, piece_of[s], S);
     double reach = std::max(dist_to_chord(b + 3), dist_to_chord(b + 6)) + radius;
     double slack = 0, scale = 0;
     for (int a = 0; a < 3; a++) {

@@ -22,7 +22,7 @@
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
 // tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
-struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
@@ -84,7 +84,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   // end up cheap or expensive and the slowest wave sets the kernel time.
   uint32_t next = 0, range_end = 0;        // wave-uniform
   tune.grab = adaptive_grab(tune.grab, n);
-  if (kCurves) tune.refill = tune.refill_curves;
+  if (kCurves) { tune.refill = tune.refill_curves; tune.steps = tune.steps_curves; }
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o, winv = o;

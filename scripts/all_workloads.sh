@@ -1,8 +1,7 @@
 #!/bin/bash
 # every workload at its default (full) size, one frame each: catches scale-only failures
 for w in teapot buddhas dragon furry ibl cornell motion arealights; do
-  extra=""
-  [ "$w" = cornell ] && extra="--spp 6 6"
+  extra="--no-pmc"
   timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --cpu-tiles 0 $extra 2>gpurun_out/all_$w.err | tail -1 | python -c "
 import json,sys
 try:

@@ -350,3 +350,48 @@ def test_hdr2mip_matches_the_reference_converter(shape, rle, tmp_path):
     si.NewTexture("tex1", hdr)
     line = si.text().strip()
     assert line.startswith("NewTexture tex1 ") and line.endswith(".mip") and open(line.split()[-1], "rb").read() == b
+
+
+REF_BUILT = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_BUILT, "PlasticShader.so")), reason="needs the reference build in oracle/_ref")
+def test_shader_dsos_built_by_the_reference_load_unchanged(tmp_path):
+    """north_star: "shader DSOs load unchanged".  The five shader DSOs of the reference BUILD
+    (oracle/_ref: compiled from /root/reference against the reference's own headers, linked against
+    its libscene.so) are copied next to a `libscene.so` that is libfjscene.so; SiOpenPlugin dlopens
+    them, every symbol they import resolves to the product's export of the same mangled name,
+    Initialize / create_instance / the property setters run, and the tables they bring are the
+    built-in ones."""
+    import shutil
+    L = host.lib()
+    L.fj_SiOpenPlugin.restype = C.c_long
+    L.fj_SiOpenPlugin.argtypes = [C.c_char_p]
+    L.fj_SiNewShader.restype = C.c_long
+    L.fj_SiNewShader.argtypes = [C.c_long]
+    L.fj_SiSetProperty3.argtypes = [C.c_long, C.c_char_p, C.c_double, C.c_double, C.c_double]
+    L.fj_scene_property_table.restype = C.c_int
+    L.fj_scene_property_table.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+
+    def table(name):
+        buf = C.create_string_buffer(8192)
+        return None if L.fj_scene_property_table(name.encode(), buf, len(buf)) < 0 else buf.value.decode()
+
+    names = ("PlasticShader", "GlassShader", "ConstantShader", "HairShader", "PathtracingShader")
+    L.fj_SiOpenScene()
+    builtin = {}
+    for n in names:
+        assert L.fj_SiOpenPlugin(n.encode()) >= 0
+        builtin[n] = table(n)
+    L.fj_SiCloseScene()
+    os.symlink(os.path.join(ffi.LIB_DIR, "libfjscene.so"), str(tmp_path / "libscene.so"))   # their DT_NEEDED, RUNPATH $ORIGIN
+    L.fj_SiOpenScene()
+    for n in names:
+        shutil.copy(os.path.join(REF_BUILT, n + ".so"), str(tmp_path))
+        pid = L.fj_SiOpenPlugin(str(tmp_path / n).encode())
+        assert pid >= 0, L.fj_scene_last_error()
+        assert table(n) == builtin[n]
+        sid = L.fj_SiNewShader(pid)
+        assert sid >= 0 and L.fj_SiSetProperty3(sid, b"diffuse", .1, .2, .3) == 0
+        assert L.fj_SiSetProperty3(sid, b"nonsense", 1, 2, 3) == -1
+    L.fj_SiCloseScene()
