@@ -164,8 +164,13 @@ def pmc_passes(args, kname):
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
             for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
                 for r in csv.DictReader(open(f)):
-                    # the production instantiation: first template argument (event counting) false
-                    if kname + "<false" not in r["Kernel_Name"]:
+                    # the production instantiation: the event-counting template argument is false
+                    # (k_shadow_anyhit<count, multi>, k_shadow_trace<curves, count, motion>)
+                    nm = r["Kernel_Name"]
+                    if kname == "k_shadow_anyhit":
+                        if "k_shadow_anyhit<false" not in nm:
+                            continue
+                    elif not any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false")):
                         continue
                     out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         return out or None
