@@ -61,8 +61,8 @@ def parse_args():
     ap.add_argument("--batch-tiles", type=int, default=0)
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="diagnostic: on ONE GPU render only the tiles rank 0 of an N-GPU job would own (per-rank cost)")
-    ap.add_argument("--device-build", action="store_true",
-                    help="build the BLAS on the GPU (LBVH: faster prepare, slower trace) instead of the host SAH build")
+    ap.add_argument("--device-build", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+                    help="build the BLAS on the GPU instead of the host SAH build: 1 locally-ordered clustering, 2 radix tree of the Morton codes")
     ap.add_argument("--rank-costs", type=int, default=0,
                     help="diagnostic: on ONE GPU time the tile share of EVERY rank of an N-GPU job (max over ranks = the N-GPU frame "
                          "time before the gather)")
@@ -155,7 +155,7 @@ def pmc_passes(args, kname):
     if args.spp:
         child += ["--spp"] + [str(v) for v in args.spp]
     if args.device_build:
-        child += ["--device-build"]
+        child += ["--device-build", str(args.device_build)]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for k, cs in enumerate(PMC_SETS):
@@ -173,6 +173,8 @@ def pmc_passes(args, kname):
                     elif not any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false")):
                         continue
                     out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    if r["Counter_Name"] == "SQ_WAVES":
+                        out["_launches"] = out.get("_launches", 0.0) + 1.0
         return out or None
     except Exception as e:  # noqa: BLE001
         sys.stderr.write("bench: rocprofv3 counter passes failed (%s): roofline.traffic is null\n" % e)
@@ -227,7 +229,7 @@ def main():
     host.run_scene_text(scene_text(), deferred=True)
     scene_ptr, render = host.get_desc()
     if args.device_build:
-        gpu.global_option("device_build", 1)
+        gpu.global_option("device_build", args.device_build)
     gs = gpu.Scene(scene_ptr, device=local_rank)
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     # the lean any-hit walk reads the quantised 64-byte twin of a node
@@ -324,7 +326,9 @@ def main():
         if pmc and pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES") and pmc.get("SQ_ACTIVE_INST_VALU"):
             props = torch.cuda.get_device_properties(device)
             simds = props.multi_processor_count * 4
-            elapsed_q = pmc["SQ_WAVE_CYCLES"] / pmc["SQ_WAVES"]          # persistent waves live for the whole launch
+            # persistent waves live for the whole launch: wave cycles / waves per launch = the time (in the
+            # counter's own unit) the kernel's launches of one frame were resident, summed over the launches
+            elapsed_q = pmc["SQ_WAVE_CYCLES"] * max(pmc.get("_launches", 1.0), 1.0) / pmc["SQ_WAVES"]
             busy = pmc["SQ_ACTIVE_INST_VALU"] / (simds * elapsed_q)
             lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
             issue = {"valu_busy": busy, "lane_efficiency": lane, "useful_valu_issue": busy * lane,
@@ -375,7 +379,7 @@ def main():
                        "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot",
                                              "furry": "furbunny"}.get(args.workload, args.workload),
                        "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
-                       "blas_build": "device LBVH" if args.device_build else "host binned SAH",
+                       "blas_build": ("host binned SAH", "device clustering (PLOC)", "device radix tree (LBVH)")[args.device_build],
                        "prepare_seconds": prep_seconds,
                        "counters_counting_frame_rank0": {"nodes": int(counted.nodes_visited), "prims": int(counted.prims_tested),
                                                          "insts": int(counted.insts_tested), "traced": int(counted.rays_traced),

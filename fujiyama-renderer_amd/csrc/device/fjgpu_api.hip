@@ -156,14 +156,14 @@ static const char *bad_render(const fj_render_desc *r)
   return nullptr;
 }
 
-static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip)
+static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
 
 int fjgpu_global_option(const char *name, long value)
 {
   if (!name) return fail(FJGPU_EINVAL, "bad option call");
-  if (std::string(name) == "device_build") { g_device_build = value != 0; return 0; }
+  if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
 
@@ -246,12 +246,12 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       e |= M.upload(m.indices, (size_t) m.n_faces * 3, &d.indices);
       e |= M.upload(m.face_group, m.face_group ? (size_t) m.n_faces : 0, &d.face_group);
       if (h.device_build) {
-        // BLAS on the device: Morton sort, radix tree, fit, collapse, triangle gather
+        // BLAS on the device: Morton sort, clustering (or radix tree + fit), collapse, triangle gather
         if (e) return fail(FJGPU_ENOMEM, "device allocation / upload failed while creating the scene");
         const auto tb0 = std::chrono::steady_clock::now();
         LbvhOut lo;
         std::string lerr;
-        if (LbvhBuildMesh(d.P, d.velocity, d.indices, m.n_faces, m.n_points, h.bounds, h.f32_exact, &lo, &lerr))
+        if (LbvhBuildMesh(d.P, d.velocity, d.indices, m.n_faces, m.n_points, h.bounds, h.f32_exact, hs.device_build_quality, &lo, &lerr))
           return fail(FJGPU_ENODEV, lerr);
         for (void *p : {(void *) lo.nodes, (void *) lo.prim_ids, (void *) lo.tri_verts, (void *) lo.tri_verts32, (void *) lo.tri_vel})
           if (p) M.ptrs.push_back(p);
@@ -443,7 +443,10 @@ static int build_host_scene(const fj_scene_desc *desc, fjgpu::HostScene *hs)
 {
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
-  const bool device_build = g_device_build || getenv("FJGPU_DEVICE_BUILD") != nullptr;
+  long device_mode = g_device_build;
+  if (const char *e = getenv("FJGPU_DEVICE_BUILD")) device_mode = atoi(e) == 2 ? 2 : 1;
+  const bool device_build = device_mode != 0;
+  hs->device_build_quality = device_mode == 2 ? 0 : 1;
   const int be = fjgpu::BuildHostScene(desc, hs, &err, device_build);
   if (getenv("FJGPU_VERBOSE"))
     fprintf(stderr, "fjgpu: host scene build (BLAS, transforms, lights) %.3f s\n",

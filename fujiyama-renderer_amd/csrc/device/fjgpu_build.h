@@ -57,6 +57,7 @@ struct HostScene {
   std::vector<DLightSample> light_samples;
   std::vector<DAreaLight> area_lights;        // [n_lights] when any rectangle / sphere light exists
   int n_meshes;
+  int device_build_quality;                   // fjgpu_lbvh.hip: 0 radix tree, 1 locally-ordered clustering
   int target_group;
   double cam_M[12];
   double cam_fov, cam_znear, cam_zfar;

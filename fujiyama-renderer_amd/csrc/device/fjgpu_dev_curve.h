@@ -42,32 +42,61 @@ __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * 
 // walk builds it ONCE when the ray enters a curve set and keeps its 12 numbers in LDS
 // ([k][thread], lane consecutive) -- two square roots and two divisions less per curve tested,
 // more than half of the first-stage test.
-#define FJ_RAYSPACE_DOUBLES (12 + 14)     // the frame + one cached node of the subdivision (curve_ray)
 #ifndef FJ_CURVE_CACHE_LEVEL
-#define FJ_CURVE_CACHE_LEVEL 1
+#define FJ_CURVE_CACHE_LEVEL 1            // 0: no cached node of the subdivision
 #endif
+#ifndef FJ_CURVE_FRAME_LDS
+#define FJ_CURVE_FRAME_LDS 1              // 0: the frame is rebuilt from the ray in every test (its 12 doubles of LDS go)
+#endif
+#define FJ_FRAME_DOUBLES (FJ_CURVE_FRAME_LDS ? 12 : 0)
+#define FJ_RAYSPACE_DOUBLES_ (FJ_FRAME_DOUBLES + (FJ_CURVE_CACHE_LEVEL > 0 ? 14 : 0))
+#define FJ_RAYSPACE_DOUBLES (FJ_RAYSPACE_DOUBLES_ > 0 ? FJ_RAYSPACE_DOUBLES_ : 1)
+struct RayFrame { V3 r0, r1, r2; double m03, m13, m23, ray_scale; };
+__device__ __forceinline__ RayFrame make_ray_frame(V3 oo, V3 od)
+{
+  RayFrame f;
+  // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
+  f.ray_scale = sqrt(dot(od, od));
+  const double sinv = 1. / f.ray_scale;
+  const V3 nd = od * sinv;
+  const double lx = nd.x, ly = nd.y, lz = nd.z;
+  const double d = sqrt(lx * lx + lz * lz);
+  const double d_inv = 1. / d;
+  f.r0 = mk(lz * d_inv, 0, -lx * d_inv);
+  f.r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
+  f.r2 = mk(lx, ly, lz);
+  const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
+  f.m03 = f.r0.x * nox + f.r0.y * noy + f.r0.z * noz;
+  f.m13 = f.r1.x * nox + f.r1.y * noy + f.r1.z * noz;
+  f.m23 = f.r2.x * nox + f.r2.y * noy + f.r2.z * noz;
+  return f;
+}
 struct RaySpace {
   double *lds;          // s_rayspace + threadIdx.x
-  __device__ __forceinline__ void set(V3 oo, V3 od) const
+  V3 oo, od;            // the ray in the instance's space (FJ_CURVE_FRAME_LDS == 0: the frame is rebuilt from it)
+  __device__ __forceinline__ void set(V3 oo_, V3 od_) const
   {
-    // nml_ray.dir = ray.dir / |ray.dir|  (Vector /= Real  ==  *= 1./s)
-    const double ray_scale = sqrt(dot(od, od));
-    const double sinv = 1. / ray_scale;
-    const V3 nd = od * sinv;
-    const double lx = nd.x, ly = nd.y, lz = nd.z;
-    const double d = sqrt(lx * lx + lz * lz);
-    const double d_inv = 1. / d;
-    const V3 r0 = mk(lz * d_inv, 0, -lx * d_inv);
-    const V3 r1 = mk(-lx * ly * d_inv, d, -ly * lz * d_inv);
-    const V3 r2 = mk(lx, ly, lz);
-    const double nox = -oo.x, noy = -oo.y, noz = -oo.z;
-    lds[0 * BLOCK] = r0.x; lds[1 * BLOCK] = r0.z;                          // r0.y = 0
-    lds[2 * BLOCK] = r1.x; lds[3 * BLOCK] = r1.y; lds[4 * BLOCK] = r1.z;
-    lds[5 * BLOCK] = r2.x; lds[6 * BLOCK] = r2.y; lds[7 * BLOCK] = r2.z;
-    lds[8 * BLOCK] = r0.x * nox + r0.y * noy + r0.z * noz;
-    lds[9 * BLOCK] = r1.x * nox + r1.y * noy + r1.z * noz;
-    lds[10 * BLOCK] = r2.x * nox + r2.y * noy + r2.z * noz;
-    lds[11 * BLOCK] = ray_scale;
+    if (!FJ_CURVE_FRAME_LDS) return;
+    const RayFrame f = make_ray_frame(oo_, od_);
+    lds[0 * BLOCK] = f.r0.x; lds[1 * BLOCK] = f.r0.z;                          // r0.y = 0
+    lds[2 * BLOCK] = f.r1.x; lds[3 * BLOCK] = f.r1.y; lds[4 * BLOCK] = f.r1.z;
+    lds[5 * BLOCK] = f.r2.x; lds[6 * BLOCK] = f.r2.y; lds[7 * BLOCK] = f.r2.z;
+    lds[8 * BLOCK] = f.m03;
+    lds[9 * BLOCK] = f.m13;
+    lds[10 * BLOCK] = f.m23;
+    lds[11 * BLOCK] = f.ray_scale;
+  }
+  __device__ __forceinline__ RayFrame frame() const
+  {
+    if (!FJ_CURVE_FRAME_LDS) return make_ray_frame(oo, od);
+    const double *m = lds;
+    RayFrame f;
+    f.r0 = mk(m[0 * BLOCK], 0, m[1 * BLOCK]);
+    f.r1 = mk(m[2 * BLOCK], m[3 * BLOCK], m[4 * BLOCK]);
+    f.r2 = mk(m[5 * BLOCK], m[6 * BLOCK], m[7 * BLOCK]);
+    f.m03 = m[8 * BLOCK]; f.m13 = m[9 * BLOCK]; f.m23 = m[10 * BLOCK];
+    f.ray_scale = m[11 * BLOCK];
+    return f;
   }
 };
 
@@ -75,11 +104,9 @@ struct RaySpace {
 __device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1,
     const RaySpace &rsp, double *ray_scale_out)
 {
-  const double *m = rsp.lds;
-  const V3 r0 = mk(m[0 * BLOCK], 0, m[1 * BLOCK]);
-  const V3 r1 = mk(m[2 * BLOCK], m[3 * BLOCK], m[4 * BLOCK]);
-  const V3 r2 = mk(m[5 * BLOCK], m[6 * BLOCK], m[7 * BLOCK]);
-  const double m03 = m[8 * BLOCK], m13 = m[9 * BLOCK], m23 = m[10 * BLOCK];
+  const RayFrame f = rsp.frame();
+  const V3 r0 = f.r0, r1 = f.r1, r2 = f.r2;
+  const double m03 = f.m03, m13 = f.m13, m23 = f.m23;
   Bz root;
   V3 p[4];
   for (int k = 0; k < 4; k++) {
@@ -91,7 +118,7 @@ __device__ __forceinline__ Bz curve_to_ray_space(const FJ_GLOBAL double *cpw, co
   }
   root.c0 = p[0]; root.c1 = p[1]; root.c2 = p[2]; root.c3 = p[3];
   root.w0 = w0; root.w1 = w1;
-  *ray_scale_out = m[11 * BLOCK];
+  *ray_scale_out = f.ray_scale;
   return root;
 }
 
@@ -151,8 +178,8 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   // of from the root.  Same splits, same operands: only the repetition is gone.  (C5, level of
   // the cached node 1 / 2 / 3: 5.19 / 5.26 / 5.46 s per frame, 5.41 s without.)
   const int CL = FJ_CURVE_CACHE_LEVEL;
-  const bool use_cache = depth > CL;
-  double *cache = rsp.lds + 12 * BLOCK;
+  const bool use_cache = CL > 0 && depth > CL;
+  double *cache = rsp.lds + FJ_FRAME_DOUBLES * BLOCK;
   uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
   while (j < nleaf) {

@@ -182,7 +182,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       }
       if (found) {
         cur = P->root; sp = 0; last_curve = 0xffffffffu;
-        if (kCurves && P->type == FJ_PRIMSET_CURVE) { RaySpace rsp; rsp.lds = stk.rayspace; rsp.set(oo, od); }
+        if (kCurves && P->type == FJ_PRIMSET_CURVE) { RaySpace rsp = {stk.rayspace, oo, od}; rsp.set(oo, od); }
       }
       else { pol.finish(idx, best); have = false; }
     }
@@ -238,7 +238,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           last_curve = cid;
           if (kCount) lc->prims++;
           const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
-          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace});
+          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace, oo, od});
           // the second stage is deferred: the lane remembers the curve and walks on (its result
           // only shortens the ray or ends it -- the walk stays correct without it); a lane that
           // already carries a deferred curve waits here instead
@@ -286,7 +286,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
             double t, u = 0;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
             if (curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
-                          (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace}, &t, &u) &&
+                          (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace, oo, od}, &t, &u) &&
                 (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {

@@ -19,8 +19,9 @@ struct LbvhOut {               // device allocations (hipMalloc) owned by the ca
 };
 
 // d_P / d_vel / d_idx: the mesh arrays already on the device; bounds: the primitive set's
-// padded bounds (Morton grid).  Returns 0, or -1 with *err set (nothing left allocated).
+// padded bounds (Morton grid); quality: 0 = radix tree of the Morton codes, 1 = locally-ordered
+// clustering (slower to build, traces like a SAH tree).  Returns 0, or -1 with *err set (nothing left allocated).
 int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, int n_faces, int n_points,
-    const double bounds[6], bool f32_exact, LbvhOut *out, std::string *err);
+    const double bounds[6], bool f32_exact, int quality, LbvhOut *out, std::string *err);
 
 #endif

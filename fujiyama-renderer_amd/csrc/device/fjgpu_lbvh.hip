@@ -1,6 +1,7 @@
-// fjgpu_lbvh.hip -- BLAS build ON THE DEVICE: linear BVH over Morton-sorted
-// triangles (Karras 2012), bottom-up fit, leaves of <= 4 triangles, then the same collapse to
-// 4-wide 128-byte nodes as the host builder.  Replaces build_accelerators()
+// fjgpu_lbvh.hip -- BLAS build ON THE DEVICE: a binary tree over Morton-sorted
+// triangles -- locally-ordered clustering with a surface-area distance (Meister & Bittner 2018;
+// quality 1, the default) or the plain radix tree of the Morton codes (Karras 2012; quality 0) --
+// leaves of <= 4 triangles, then the same collapse to 4-wide 128-byte nodes as the host builder.  Replaces build_accelerators()
 // (reference src/fj_scene_interface.cc:1161-1202; grid build src/fj_grid_accelerator.cc:69-160)
 // when the scene is created with the "device_build" option: 7.2 M triangles in tens of
 // milliseconds instead of 0.4 s on the host threads, at the price of a tree that is not
@@ -70,13 +71,23 @@ __global__ void __launch_bounds__(LB) k_prim(const double *P, const double *vel,
   vals[i] = (uint32_t) i;
 }
 
-struct Tree {                // binary radix tree over n sorted leaves: inner nodes 0 .. n-2
-  uint32_t *left, *right;    // child: inner index, or LEAFBIT | leaf index
-  uint32_t *parent;          // [2n-1]: inner i at i, leaf i at n-1+i
-  uint32_t *first, *last;    // leaf range of inner node
-  Box6 *box;                 // inner boxes
-  int *flag;
+// Binary tree over the n Morton-sorted leaves, whichever way it was formed.  Node ids: leaf k
+// (sorted position) = k, inner node m = n + m.
+struct BTree {
+  uint32_t *left, *right;    // [2n-1], inner entries used
+  uint32_t *count;           // [2n-1] leaves below
+  Box6 *box;                 // [2n-1]
+  uint32_t *parent;          // [2n-1] (radix-tree path only)
+  int *flag;                 // [n]    (radix-tree path only)
 };
+
+__global__ void __launch_bounds__(LB) k_leaf_nodes(const Box6 *boxes, const uint32_t *vals, int n, BTree T)
+{
+  const int i = blockIdx.x * LB + threadIdx.x;
+  if (i >= n) return;
+  T.box[i] = boxes[vals[i]];
+  T.count[i] = 1u;
+}
 
 __device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j)
 {
@@ -86,7 +97,8 @@ __device__ __forceinline__ int delta(const unsigned long long *keys, int n, int 
   return __clzll((long long) (a ^ b));
 }
 
-__global__ void __launch_bounds__(LB) k_hierarchy(const unsigned long long *keys, int n, Tree T)
+// ---- quality 0: binary radix tree (Karras 2012), one thread per inner node
+__global__ void __launch_bounds__(LB) k_hierarchy(const unsigned long long *keys, int n, BTree T)
 {
   const int i = blockIdx.x * LB + threadIdx.x;
   if (i >= n - 1) return;
@@ -106,34 +118,33 @@ __global__ void __launch_bounds__(LB) k_hierarchy(const unsigned long long *keys
   }
   const int gamma = i + s * d + (d < 0 ? -1 : 0);
   const int lo = i < j ? i : j, hi = i < j ? j : i;
-  const uint32_t lc = (lo == gamma) ? (LEAFBIT | (uint32_t) gamma) : (uint32_t) gamma;
-  const uint32_t rc = (hi == gamma + 1) ? (LEAFBIT | (uint32_t) (gamma + 1)) : (uint32_t) (gamma + 1);
-  T.left[i] = lc; T.right[i] = rc;
-  T.first[i] = (uint32_t) lo; T.last[i] = (uint32_t) hi;
-  T.parent[(lc & LEAFBIT) ? (n - 1 + (int) (lc & ~LEAFBIT)) : (int) lc] = (uint32_t) i;
-  T.parent[(rc & LEAFBIT) ? (n - 1 + (int) (rc & ~LEAFBIT)) : (int) rc] = (uint32_t) i;
-  if (i == 0) T.parent[0] = 0xffffffffu;
+  const uint32_t lc = (lo == gamma) ? (uint32_t) gamma : (uint32_t) (n + gamma);
+  const uint32_t rc = (hi == gamma + 1) ? (uint32_t) (gamma + 1) : (uint32_t) (n + gamma + 1);
+  T.left[n + i] = lc; T.right[n + i] = rc;
+  T.count[n + i] = (uint32_t) (hi - lo + 1);
+  T.parent[lc] = (uint32_t) (n + i);
+  T.parent[rc] = (uint32_t) (n + i);
+  if (i == 0) T.parent[n] = 0xffffffffu;
 }
 
-__device__ __forceinline__ Box6 child_box(const Tree &T, const Box6 *boxes, const uint32_t *vals, uint32_t ref)
+__device__ __forceinline__ Box6 box_union(const Box6 &a, const Box6 &b)
 {
-  return (ref & LEAFBIT) ? boxes[vals[ref & ~LEAFBIT]] : T.box[ref];
+  Box6 u;
+  for (int c = 0; c < 3; c++) { u.mn[c] = fminf(a.mn[c], b.mn[c]); u.mx[c] = fmaxf(a.mx[c], b.mx[c]); }
+  return u;
 }
 
 // bottom-up fit: the second thread to reach a node unions its children
-__global__ void __launch_bounds__(LB) k_fit(int n, Tree T, const Box6 *boxes, const uint32_t *vals)
+__global__ void __launch_bounds__(LB) k_fit(int n, BTree T)
 {
   const int i = blockIdx.x * LB + threadIdx.x;
   if (i >= n) return;
-  uint32_t p = T.parent[n - 1 + i];
+  uint32_t p = T.parent[i];
   while (p != 0xffffffffu) {
     __threadfence();
-    if (atomicAdd(&T.flag[p], 1) == 0) return;
+    if (atomicAdd(&T.flag[p - (uint32_t) n], 1) == 0) return;
     __threadfence();
-    const Box6 a = child_box(T, boxes, vals, T.left[p]), b = child_box(T, boxes, vals, T.right[p]);
-    Box6 u;
-    for (int c = 0; c < 3; c++) { u.mn[c] = fminf(a.mn[c], b.mn[c]); u.mx[c] = fmaxf(a.mx[c], b.mx[c]); }
-    T.box[p] = u;
+    T.box[p] = box_union(T.box[T.left[p]], T.box[T.right[p]]);
     p = T.parent[p];
   }
 }
@@ -144,23 +155,110 @@ __device__ __forceinline__ float half_area(const Box6 &b)
   return dx * dy + dy * dz + dz * dx;
 }
 
-// a subtree of <= 4 leaves is one leaf of the wide tree (its triangles are contiguous)
-__device__ __forceinline__ bool is_leaf_range(const Tree &T, uint32_t ref)
+// ---- quality 1: parallel locally-ordered clustering (Meister & Bittner 2018).  The clusters
+// stay in Morton order; every round each cluster looks PLOC_R neighbours to either side for the
+// one whose union with it has the smallest surface area, mutual choices merge, the array is
+// compacted.  Agglomerative with a surface-area distance: the tree quality of a top-down SAH
+// build without its serial passes.  Everything is decided by index arithmetic and exclusive
+// sums, so the tree -- and with it every counter a render reports -- is the same in every run.
+#define PLOC_R_MAX 32
+
+// ordering of candidate pairs with equal distance: by (lower index, higher index); the pair
+// that is globally smallest in (distance, this order) is always mutual, so every round merges
+__device__ __forceinline__ bool pair_before(int i, int j, int k)
 {
-  return (ref & LEAFBIT) || (T.last[ref] - T.first[ref] + 1u <= (uint32_t) FJ_MAX_LEAF_PRIMS);
-}
-__device__ __forceinline__ uint32_t leaf_ref_of(const Tree &T, uint32_t ref)
-{
-  if (ref & LEAFBIT) return FJ_LEAF_FLAG | ((ref & ~LEAFBIT) << 3);
-  return FJ_LEAF_FLAG | (T.first[ref] << 3) | (T.last[ref] - T.first[ref]);
+  const int a0 = i < j ? i : j, a1 = i < j ? j : i, b0 = i < k ? i : k, b1 = i < k ? k : i;
+  return a0 < b0 || (a0 == b0 && a1 < b1);
 }
 
-struct QEntry { uint32_t node2, node4; };
+__global__ void __launch_bounds__(LB) k_ploc_nearest(const uint32_t *C, int c, int radius, const Box6 *box, uint32_t *NN)
+{
+  __shared__ Box6 sb[LB + 2 * PLOC_R_MAX];
+  const int base = (int) (blockIdx.x * LB) - radius;
+  for (int t = threadIdx.x; t < LB + 2 * radius; t += LB) {
+    const int g = base + t;
+    if (g >= 0 && g < c) sb[t] = box[C[g]];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * LB + threadIdx.x;
+  if (i >= c) return;
+  const Box6 bi = sb[threadIdx.x + radius];
+  float best = FLT_MAX;
+  int bj = -1;
+  for (int d = -radius; d <= radius; d++) {
+    const int j = i + d;
+    if (d == 0 || j < 0 || j >= c) continue;
+    const float a = half_area(box_union(bi, sb[threadIdx.x + radius + d]));
+    if (bj < 0 || a < best || (a == best && pair_before(i, j, bj))) { best = a; bj = j; }
+  }
+  NN[i] = (uint32_t) bj;
+}
 
-// one level of the collapse: every queue entry is a binary inner node that becomes the wide
-// node `node4`; its inner grandchildren are appended to the next level's queue
-__global__ void __launch_bounds__(LB) k_collapse(Tree T, const Box6 *boxes, const uint32_t *vals, const QEntry *in, uint32_t n_in,
-    QEntry *out, uint32_t *n_out, uint32_t *n_nodes4, DNode *nodes4)
+// per cluster: low word 1 = it disappears (the higher index of a mutual pair), high word 1 = it
+// becomes the merged node (the lower index).  An exclusive sum of these gives both the compacted
+// position and the new node's id.
+__global__ void __launch_bounds__(LB) k_ploc_mark(const uint32_t *NN, int c, unsigned long long *marks)
+{
+  const int i = blockIdx.x * LB + threadIdx.x;
+  if (i >= c) return;
+  const int j = (int) NN[i];
+  unsigned long long m = 0;
+  if ((int) NN[j] == i) m = i < j ? (1ull << 32) : 1ull;
+  marks[i] = m;
+}
+
+__global__ void __launch_bounds__(LB) k_ploc_apply(const uint32_t *C, int c, const uint32_t *NN, const unsigned long long *marks,
+    const unsigned long long *sums, uint32_t next_node, BTree T, uint32_t *Cout, unsigned long long *total)
+{
+  const int i = blockIdx.x * LB + threadIdx.x;
+  if (i >= c) return;
+  const unsigned long long m = marks[i], s = sums[i];
+  if (i == c - 1) *total = s + m;
+  if (m == 1ull) return;
+  const uint32_t pos = (uint32_t) i - (uint32_t) (s & 0xffffffffull);
+  if (m == 0) { Cout[pos] = C[i]; return; }
+  const uint32_t p = next_node + (uint32_t) (s >> 32);
+  const uint32_t a = C[i], b = C[NN[i]];
+  T.left[p] = a; T.right[p] = b;
+  T.count[p] = T.count[a] + T.count[b];
+  T.box[p] = box_union(T.box[a], T.box[b]);
+  Cout[pos] = p;
+}
+
+// ---- collapse to 4-wide nodes, top-down one level per launch; the triangles of the subtree
+// under a queue entry take the slots [first, first + count) of the final order, so a subtree
+// of <= FJ_MAX_LEAF_PRIMS leaves is one leaf of the wide tree with contiguous triangles
+struct QEntry { uint32_t node2, node4, first; };
+
+__device__ __forceinline__ void write_leaf_order(const BTree &T, uint32_t n, const uint32_t *vals, uint32_t ref, uint32_t *dst)
+{
+  uint32_t stack[FJ_MAX_LEAF_PRIMS + 1];
+  int sp = 0;
+  stack[sp++] = ref;
+  while (sp > 0) {
+    const uint32_t r = stack[--sp];
+    if (r < n) { *dst++ = vals[r]; continue; }
+    stack[sp++] = T.right[r];
+    stack[sp++] = T.left[r];
+  }
+}
+
+// Leaf decision of the wide tree, the host builder's rule (fjgpu_build.cc): one or two triangles
+// always; three or four only when splitting them once more does not pay -- the children's
+// area-weighted triangle counts plus one node step (trav_cost triangle tests) against testing all.
+__device__ __forceinline__ bool becomes_leaf(const BTree &T, uint32_t n, uint32_t ref, float trav_cost)
+{
+  const uint32_t cnt = T.count[ref];
+  if (cnt > (uint32_t) FJ_MAX_LEAF_PRIMS) return false;
+  if (cnt <= 2u || ref < n) return true;
+  const uint32_t a = T.left[ref], b = T.right[ref];
+  const float area = half_area(T.box[ref]);
+  const float split = half_area(T.box[a]) * (float) T.count[a] + half_area(T.box[b]) * (float) T.count[b];
+  return split + trav_cost * area >= area * (float) cnt;
+}
+
+__global__ void __launch_bounds__(LB) k_collapse(BTree T, uint32_t n, const uint32_t *vals, const QEntry *in, uint32_t n_in,
+    QEntry *out, uint32_t *n_out, uint32_t *n_nodes4, DNode *nodes4, uint32_t *order, float trav_cost)
 {
   const uint32_t q = blockIdx.x * LB + threadIdx.x;
   if (q >= n_in) return;
@@ -169,19 +267,19 @@ __global__ void __launch_bounds__(LB) k_collapse(Tree T, const Box6 *boxes, cons
   Box6 bx[4];
   int k = 2;
   ref[0] = T.left[e.node2]; ref[1] = T.right[e.node2];
-  bx[0] = child_box(T, boxes, vals, ref[0]); bx[1] = child_box(T, boxes, vals, ref[1]);
+  bx[0] = T.box[ref[0]]; bx[1] = T.box[ref[1]];
   while (k < 4) {
     int pick = -1;
     float area = -1.f;
     for (int i = 0; i < k; i++) {
-      if (is_leaf_range(T, ref[i])) continue;
+      if (becomes_leaf(T, n, ref[i], trav_cost)) continue;
       const float a = half_area(bx[i]);
       if (a > area) { area = a; pick = i; }
     }
     if (pick < 0) break;
     const uint32_t p = ref[pick];
     ref[pick] = T.left[p]; ref[k] = T.right[p];
-    bx[pick] = child_box(T, boxes, vals, ref[pick]); bx[k] = child_box(T, boxes, vals, ref[k]);
+    bx[pick] = T.box[ref[pick]]; bx[k] = T.box[ref[k]];
     k++;
   }
   // larger children first (the any-hit walk visits hit children in slot order)
@@ -189,16 +287,23 @@ __global__ void __launch_bounds__(LB) k_collapse(Tree T, const Box6 *boxes, cons
     for (int b = a + 1; b < k; b++)
       if (half_area(bx[b]) > half_area(bx[a])) { const Box6 tb = bx[a]; bx[a] = bx[b]; bx[b] = tb; const uint32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr; }
   DNode w;
+  uint32_t off = e.first;
   for (int i = 0; i < 4; i++) {
     for (int c = 0; c < 3; c++) { w.box[i][2 * c] = i < k ? bx[i].mn[c] : FLT_MAX; w.box[i][2 * c + 1] = i < k ? bx[i].mx[c] : -FLT_MAX; }
     w.pad[i] = 0;
     if (i >= k) { w.child[i] = FJ_NO_CHILD; continue; }
-    if (is_leaf_range(T, ref[i])) { w.child[i] = leaf_ref_of(T, ref[i]); continue; }
-    const uint32_t slot = atomicAdd(n_nodes4, 1u);
-    w.child[i] = slot;
-    QEntry ne;
-    ne.node2 = ref[i]; ne.node4 = slot;
-    out[atomicAdd(n_out, 1u)] = ne;
+    const uint32_t cnt = T.count[ref[i]];
+    if (becomes_leaf(T, n, ref[i], trav_cost)) {
+      w.child[i] = FJ_LEAF_FLAG | (off << 3) | (cnt - 1u);
+      write_leaf_order(T, n, vals, ref[i], order + off);
+    } else {
+      const uint32_t slot = atomicAdd(n_nodes4, 1u);
+      w.child[i] = slot;
+      QEntry ne;
+      ne.node2 = ref[i]; ne.node4 = slot; ne.first = off;
+      out[atomicAdd(n_out, 1u)] = ne;
+    }
+    off += cnt;
   }
   nodes4[e.node4] = w;
 }
@@ -228,21 +333,27 @@ template <class T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void *
 #define LB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { *err = std::string("device BLAS build: ") + #expr + ": " + hipGetErrorString(e_); goto fail; } } while (0)
 
 int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, int n_faces, int n_points,
-    const double bounds[6], bool f32_exact, LbvhOut *out, std::string *err)
+    const double bounds[6], bool f32_exact, int quality, LbvhOut *out, std::string *err)
 {
   const int n = n_faces;
   std::memset(out, 0, sizeof(*out));
   Box6 *boxes = nullptr;
   unsigned long long *keys = nullptr, *keys2 = nullptr;
   uint32_t *vals = nullptr, *vals2 = nullptr;
-  void *tmp = nullptr;
-  Tree T = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void *tmp = nullptr, *scan_tmp = nullptr;
+  BTree T = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t *c0 = nullptr, *c1 = nullptr, *nn = nullptr;
+  unsigned long long *marks = nullptr, *sums = nullptr, *total = nullptr;
   QEntry *qa = nullptr, *qb = nullptr;
   uint32_t *counters = nullptr;     // [0] next-queue count, [1] wide nodes
   DNode *wide = nullptr;
+  uint32_t *order = nullptr;
   int *bad = nullptr;
   const unsigned grid = (unsigned) ((n + LB - 1) / LB);
   int levels = 0;
+  uint32_t root2 = 0;
+  float trav_cost = 1.2f;                        // a node step ~ 1.2 triangle tests (as fjgpu_build.cc)
+  if (const char *e = getenv("FJGPU_TRAV_COST")) trav_cost = (float) atof(e);
 
   if (n <= FJ_MAX_LEAF_PRIMS) {
     // a handful of triangles: the root is one leaf (no nodes)
@@ -280,24 +391,66 @@ int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, 
     LB_TRY(hipMalloc(&tmp, bytes ? bytes : 1));
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, vals, vals2, n, 0, 63, 0));
   }
-  LB_TRY(dalloc(&T.left, (size_t) n)); LB_TRY(dalloc(&T.right, (size_t) n)); LB_TRY(dalloc(&T.parent, (size_t) 2 * n));
-  LB_TRY(dalloc(&T.first, (size_t) n)); LB_TRY(dalloc(&T.last, (size_t) n)); LB_TRY(dalloc(&T.box, (size_t) n));
-  LB_TRY(dalloc(&T.flag, (size_t) n));
-  LB_TRY(hipMemset(T.flag, 0, sizeof(int) * (size_t) n));
-  hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(LB), 0, 0, keys2, n, T);
-  hipLaunchKernelGGL(k_fit, dim3(grid), dim3(LB), 0, 0, n, T, boxes, vals2);
+  LB_TRY(dalloc(&T.left, (size_t) 2 * n)); LB_TRY(dalloc(&T.right, (size_t) 2 * n)); LB_TRY(dalloc(&T.count, (size_t) 2 * n));
+  LB_TRY(dalloc(&T.box, (size_t) 2 * n));
+  hipLaunchKernelGGL(k_leaf_nodes, dim3(grid), dim3(LB), 0, 0, boxes, vals2, n, T);
+
+  if (quality <= 0) {
+    // binary radix tree over the Morton codes + bottom-up fit
+    LB_TRY(dalloc(&T.parent, (size_t) 2 * n)); LB_TRY(dalloc(&T.flag, (size_t) n));
+    LB_TRY(hipMemset(T.flag, 0, sizeof(int) * (size_t) n));
+    hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(LB), 0, 0, keys2, n, T);
+    hipLaunchKernelGGL(k_fit, dim3(grid), dim3(LB), 0, 0, n, T);
+    root2 = (uint32_t) n;
+  } else {
+    // locally-ordered clustering: rounds of nearest-neighbour search, mark, exclusive sum, merge + compact
+    int radius = 16;
+    if (const char *e = getenv("FJGPU_PLOC_RADIUS")) radius = atoi(e);
+    radius = radius < 1 ? 1 : (radius > PLOC_R_MAX ? PLOC_R_MAX : radius);
+    LB_TRY(dalloc(&c0, (size_t) n)); LB_TRY(dalloc(&c1, (size_t) n)); LB_TRY(dalloc(&nn, (size_t) n));
+    LB_TRY(dalloc(&marks, (size_t) n)); LB_TRY(dalloc(&sums, (size_t) n)); LB_TRY(dalloc(&total, 1));
+    size_t scan_bytes = 0;
+    LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, marks, sums, n, 0));
+    LB_TRY(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 1));
+    {
+      std::vector<uint32_t> ident((size_t) n);
+      for (int i = 0; i < n; i++) ident[i] = (uint32_t) i;
+      LB_TRY(hipMemcpy(c0, ident.data(), sizeof(uint32_t) * (size_t) n, hipMemcpyHostToDevice));
+    }
+    int c = n;
+    uint32_t next_node = (uint32_t) n;
+    int rounds = 0;
+    while (c > 1) {
+      const unsigned g = (unsigned) ((c + LB - 1) / LB);
+      hipLaunchKernelGGL(k_ploc_nearest, dim3(g), dim3(LB), 0, 0, c0, c, radius, T.box, nn);
+      hipLaunchKernelGGL(k_ploc_mark, dim3(g), dim3(LB), 0, 0, nn, c, marks);
+      size_t sb = scan_bytes;
+      LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, sb, marks, sums, c, 0));
+      hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(LB), 0, 0, c0, c, nn, marks, sums, next_node, T, c1, total);
+      unsigned long long ht = 0;
+      LB_TRY(hipMemcpy(&ht, total, sizeof(ht), hipMemcpyDeviceToHost));
+      const uint32_t merged = (uint32_t) (ht >> 32);
+      if (merged == 0 || merged != (uint32_t) (ht & 0xffffffffull)) { *err = "device BLAS build: clustering round merged nothing"; goto fail; }
+      next_node += merged;
+      c -= (int) merged;
+      std::swap(c0, c1);
+      rounds++;
+    }
+    LB_TRY(hipMemcpy(&root2, c0, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (getenv("FJGPU_VERBOSE") && n > 100000) fprintf(stderr, "fjgpu: clustering build: %d rounds, window radius %d\n", rounds, radius);
+  }
 
   // collapse, level by level from the root
   LB_TRY(dalloc(&qa, (size_t) n)); LB_TRY(dalloc(&qb, (size_t) n)); LB_TRY(dalloc(&counters, 2));
-  LB_TRY(dalloc(&wide, (size_t) n));
+  LB_TRY(dalloc(&wide, (size_t) n)); LB_TRY(dalloc(&order, (size_t) n));
   {
-    const QEntry root = {0u, 0u};
+    const QEntry root = {root2, 0u, 0u};
     const uint32_t init[2] = {0u, 1u};
     LB_TRY(hipMemcpy(qa, &root, sizeof(root), hipMemcpyHostToDevice));
     LB_TRY(hipMemcpy(counters, init, sizeof(init), hipMemcpyHostToDevice));
     uint32_t n_in = 1;
     while (n_in > 0) {
-      hipLaunchKernelGGL(k_collapse, dim3((n_in + LB - 1) / LB), dim3(LB), 0, 0, T, boxes, vals2, qa, n_in, qb, &counters[0], &counters[1], wide);
+      hipLaunchKernelGGL(k_collapse, dim3((n_in + LB - 1) / LB), dim3(LB), 0, 0, T, (uint32_t) n, vals2, qa, n_in, qb, &counters[0], &counters[1], wide, order, trav_cost);
       uint32_t hc[2];
       LB_TRY(hipMemcpy(hc, counters, sizeof(hc), hipMemcpyDeviceToHost));
       n_in = hc[0];
@@ -311,20 +464,22 @@ int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, 
   LB_TRY(dalloc(&out->nodes, out->n_nodes));
   LB_TRY(hipMemcpy(out->nodes, wide, sizeof(DNode) * out->n_nodes, hipMemcpyDeviceToDevice));
   out->root = 0;
-  out->prim_ids = vals2; vals2 = nullptr;
+  out->prim_ids = order; order = nullptr;
   if (f32_exact) LB_TRY(dalloc(&out->tri_verts32, (size_t) n * 9)); else LB_TRY(dalloc(&out->tri_verts, (size_t) n * 9));
   if (d_vel) LB_TRY(dalloc(&out->tri_vel, (size_t) n * 9));
   hipLaunchKernelGGL(k_gather, dim3(grid), dim3(LB), 0, 0, d_P, d_vel, d_idx, out->prim_ids, n, out->tri_verts32, out->tri_verts, out->tri_vel);
   LB_TRY(hipDeviceSynchronize());
   out->stack_need = 3 * levels + 1;      // <= 3 siblings pushed per level
-  for (void *p : {(void *) boxes, (void *) keys, (void *) keys2, (void *) vals, tmp, (void *) T.left, (void *) T.right, (void *) T.parent,
-                  (void *) T.first, (void *) T.last, (void *) T.box, (void *) T.flag, (void *) qa, (void *) qb, (void *) counters, (void *) wide, (void *) bad})
+  for (void *p : {(void *) boxes, (void *) keys, (void *) keys2, (void *) vals, (void *) vals2, tmp, scan_tmp, (void *) T.left, (void *) T.right,
+                  (void *) T.count, (void *) T.box, (void *) T.parent, (void *) T.flag, (void *) c0, (void *) c1, (void *) nn, (void *) marks,
+                  (void *) sums, (void *) total, (void *) qa, (void *) qb, (void *) counters, (void *) wide, (void *) bad})
     if (p) (void) hipFree(p);
   return 0;
 
 fail:
-  for (void *p : {(void *) boxes, (void *) keys, (void *) keys2, (void *) vals, (void *) vals2, tmp, (void *) T.left, (void *) T.right, (void *) T.parent,
-                  (void *) T.first, (void *) T.last, (void *) T.box, (void *) T.flag, (void *) qa, (void *) qb, (void *) counters, (void *) wide, (void *) bad,
+  for (void *p : {(void *) boxes, (void *) keys, (void *) keys2, (void *) vals, (void *) vals2, tmp, scan_tmp, (void *) T.left, (void *) T.right,
+                  (void *) T.count, (void *) T.box, (void *) T.parent, (void *) T.flag, (void *) c0, (void *) c1, (void *) nn, (void *) marks,
+                  (void *) sums, (void *) total, (void *) qa, (void *) qb, (void *) counters, (void *) wide, (void *) order, (void *) bad,
                   (void *) out->nodes, (void *) out->prim_ids, (void *) out->tri_verts, (void *) out->tri_verts32, (void *) out->tri_vel})
     if (p) (void) hipFree(p);
   std::memset(out, 0, sizeof(*out));

@@ -125,9 +125,10 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
 /* Process-wide options read by fjgpu_scene_create (which stands for the reference's
- * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" 0/1 -- build the BLAS of
- * meshes on the GPU (LBVH; tens of ms for millions of triangles) instead of the host's
- * binned-SAH build (slower to build, faster to trace: the default).  0 or FJGPU_EINVAL. */
+ * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" 0/1/2 -- 0 (default):
+ * the host's binned-SAH build; 1: build the BLAS of meshes on the GPU by locally-ordered clustering
+ * (surface-area agglomeration over the Morton order); 2: on the GPU as the radix tree of the Morton
+ * codes (fastest build, slowest tree).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
 
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).

@@ -304,13 +304,15 @@ def test_si_render_scene_end_to_end(asset_dir):
     assert st.rays.as_dict() == rc.as_dict() and st.render_seconds > 0
 
 
-def test_device_blas_build_gives_the_same_hits_and_pixels(asset_dir, golden_dir):
-    """BLAS built on the device (LBVH, fjgpu_lbvh.hip) instead of the host's binned-SAH tree:
-    closest hits do not depend on the culling structure, so t / ids stay bit-exact against the
-    reference grid vectors and a frame matches the oracle."""
+@pytest.mark.parametrize("mode", [1, 2], ids=["clustering", "radix_tree"])
+def test_device_blas_build_gives_the_same_hits_and_pixels(asset_dir, golden_dir, mode):
+    """BLAS built on the device (fjgpu_lbvh.hip: locally-ordered clustering, or the radix tree of
+    the Morton codes) instead of the host's binned-SAH tree: closest hits do not depend on the
+    culling structure, so t / ids stay bit-exact against the reference grid vectors and a frame
+    matches the oracle."""
     import test_oracle_golden as tg
     vec = golden_io.read_vectors(os.path.join(golden_dir, "ref_vectors.bin"))
-    gpu.global_option("device_build", 1)
+    gpu.global_option("device_build", mode)
     try:
         sp, _ = prepare(tg._mesh_scene(asset_dir))
         rays = np.load(os.path.join(golden_dir, "mesh_trace_rays.npy"))
