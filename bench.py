@@ -391,17 +391,22 @@ def main():
         if world == 1 and args.rank_costs > 1:
             # per-rank cost of an N-GPU job, every rank's tile share timed on this one GPU
             # (tile t -> rank t % N): the slowest share bounds the N-GPU frame before the gather
-            costs = []
+            costs, parts = [], []
             for rk in range(args.rank_costs):
                 tiles_r = fjdist.tiles_of_rank(n_tiles, rk, args.rank_costs)
                 gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)      # warm
                 t1 = time.perf_counter()
                 for _ in range(3):
-                    gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)
+                    rst = gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)
                 torch.cuda.synchronize(device)
                 costs.append((time.perf_counter() - t1) / 3 * 1e3)
+                parts.append({"closest": rst.closest_ms, "light_loop": rst.light_loop_ms, "shadow_walk": rst.shadow_walk_ms,
+                              "shade": rst.shade_ms, "gen": rst.gen_ms, "resolve": rst.resolve_ms, "device_total": rst.total_ms,
+                              "launches": int(rst.trace_launches), "batches": int(rst.batches)})
+            slow = max(range(len(costs)), key=lambda k: costs[k])
             out["config"]["rank_costs_ms"] = {"ranks": args.rank_costs, "per_rank": costs, "max": max(costs),
-                                              "speedup_before_gather": out["ms_per_step"] / max(costs)}
+                                              "speedup_before_gather": out["ms_per_step"] / max(costs),
+                                              "slowest_rank_kernels_ms": parts[slow]}
         if world == 1 and args.cpu_tiles != 0:
             # bounded CPU sample: a block of tiles in the middle of the frame, two tiles per
             # host core (the reference hands whole tiles to its worker threads)

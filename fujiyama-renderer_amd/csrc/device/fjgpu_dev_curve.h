@@ -46,7 +46,7 @@ __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * 
 #define FJ_CURVE_CACHE_LEVEL 1            // 0: no cached node of the subdivision
 #endif
 #ifndef FJ_CURVE_FRAME_LDS
-#define FJ_CURVE_FRAME_LDS 1              // 0: the frame is rebuilt from the ray in every test (its 12 doubles of LDS go)
+#define FJ_CURVE_FRAME_LDS 0              // 1: the frame is built once per (ray, instance) and kept in 12 doubles of LDS per lane
 #endif
 #define FJ_FRAME_DOUBLES (FJ_CURVE_FRAME_LDS ? 12 : 0)
 #define FJ_RAYSPACE_DOUBLES_ (FJ_FRAME_DOUBLES + (FJ_CURVE_CACHE_LEVEL > 0 ? 14 : 0))

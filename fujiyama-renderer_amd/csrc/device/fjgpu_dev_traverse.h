@@ -93,6 +93,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
   int ti = 0, tend = 0, ii = -1;           // cursor in the group's threaded instance BVH
+  int group = 0;
   bool single = false;                     // the group has one instance (its padded box is the test)
   const double *gsb = nullptr;
   bool anyhit = false, dead_ray = false, plain = false;
@@ -123,16 +124,21 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
           have = pol.fetch(my, &r);
           idx = my;
-          o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           if (kMotion) rtime = r.time;
+          group = r.group;
           const DGroup G = S.groups[r.group];
-          ti = G.first; tend = G.first + G.count; single = G.n_instances == 1;
-          gsb = S.groups[r.group].sbounds;
+          ti = G.first; tend = G.first + G.count;
           best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
           cur = TRAV_DONE; sp = 0;
-          dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
-          winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
-          plain = plain_dir(d);
+          if (!kCurves) {
+            o = r.o; d = r.d;
+            single = G.n_instances == 1;
+            gsb = S.groups[r.group].sbounds;
+            dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
+            winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
+            plain = plain_dir(d);
+          }
         }
       }
       next += (uint32_t) __popcll(idle);
@@ -145,6 +151,19 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     // ---- lanes between instances: enter the next instance or retire the ray
     if (have && cur == TRAV_DONE && (!kCurves || pend == 0xffffffffu)) {
       bool found = false;
+      if (kCurves) {
+        // the curve instantiation lives on registers (the ribbon test): what only this block needs
+        // of the world-space ray is read again from the queue instead of being carried through it
+        RayIn r;
+        r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
+        pol.fetch(idx, &r);
+        o = r.o; d = r.d;
+        single = S.groups[group].n_instances == 1;
+        gsb = S.groups[group].sbounds;
+        dead_ray = has_negative_zero(d);
+        winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
+        plain = plain_dir(d);
+      }
       while (!dead_ray && ti < tend) {
         const DTNode *tn_ = &S.group_nodes[ti];
         if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
@@ -514,7 +533,10 @@ struct ClosestPolicy {
 };
 
 #ifndef FJ_CURVE_MINB
-#define FJ_CURVE_MINB 2
+#define FJ_CURVE_MINB 3          // curve scenes: 168 VGPRs (with spills) and 52 KB of LDS per block, 3 waves per SIMD
+#endif
+#ifndef FJ_MOTION_MINB
+#define FJ_MOTION_MINB 2         // the general (time-sampled) instantiation
 #endif
 #ifndef FJ_CLOSEST_MINB
 #define FJ_CLOSEST_MINB 3
@@ -523,7 +545,7 @@ struct ClosestPolicy {
 #define FJ_SHADOW_MINB 1
 #endif
 template <bool kCurves, bool kCount, bool kMotion>
-__global__ void __launch_bounds__(BLOCK, (kCurves || kMotion) ? FJ_CURVE_MINB : FJ_CLOSEST_MINB) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
+__global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? FJ_CURVE_MINB : FJ_CLOSEST_MINB)) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];

@@ -163,12 +163,21 @@ __device__ __forceinline__ float half_area(const Box6 &b)
 // sums, so the tree -- and with it every counter a render reports -- is the same in every run.
 #define PLOC_R_MAX 32
 
-// ordering of candidate pairs with equal distance: by (lower index, higher index); the pair
-// that is globally smallest in (distance, this order) is always mutual, so every round merges
+// ordering of candidate pairs with equal distance: by a hash of the pair, then by (lower index,
+// higher index).  Symmetric in its two members, so the pair that is globally smallest in
+// (distance, this order) is always mutual and every round merges; hashed, because plain index order
+// turns a run of equal distances (regular tessellations) into a chain with one mutual pair at its end.
+__device__ __forceinline__ unsigned long long pair_key(int i, int j)
+{
+  const uint32_t a = (uint32_t) (i < j ? i : j), b = (uint32_t) (i < j ? j : i);
+  uint32_t h = a * 0x9e3779b1u ^ (b + 0x7f4a7c15u) * 0x85ebca6bu;
+  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+  return ((unsigned long long) h << 32) | a;      // (hash, lower index); the higher index follows from the window
+}
 __device__ __forceinline__ bool pair_before(int i, int j, int k)
 {
-  const int a0 = i < j ? i : j, a1 = i < j ? j : i, b0 = i < k ? i : k, b1 = i < k ? k : i;
-  return a0 < b0 || (a0 == b0 && a1 < b1);
+  const unsigned long long kj = pair_key(i, j), kk = pair_key(i, k);
+  return kj < kk || (kj == kk && j < k);
 }
 
 __global__ void __launch_bounds__(LB) k_ploc_nearest(const uint32_t *C, int c, int radius, const Box6 *box, uint32_t *NN)
