@@ -385,7 +385,8 @@ def main():
                                                          "insts": int(counted.insts_tested), "traced": int(counted.rays_traced),
                                                          "shadow_traversed": int(counted.shadow_traversed)},
                        "ms_last_frame_rank0": {"trace": s0.trace_ms, "shade": s0.shade_ms, "gen": s0.gen_ms,
-                                               "resolve": s0.resolve_ms, "total": s0.total_ms}},
+                                               "resolve": s0.resolve_ms, "total": s0.total_ms,
+                                               "ray_sort": s0.sort_ms, "rays_sorted": int(s0.rays_sorted)}},
             "roofline": roof,
         }
         if world == 1 and args.rank_costs > 1:

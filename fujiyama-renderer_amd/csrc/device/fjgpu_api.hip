@@ -20,6 +20,7 @@
 #include "fjgpu_build.h"
 #include "fjgpu_kernels.h"
 #include "fjgpu_lbvh.h"
+#include "fjgpu_raysort.h"
 
 namespace {
 
@@ -105,6 +106,11 @@ struct fjgpu_scene {
   double tri_record_bytes;         // 36 when every mesh is stored as f32 triangles, else 72
   size_t blas_nodes;
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
+  // ray-queue sort (fjgpu_raysort.hip): levels >= 1 of scenes with incoherent secondary rays
+  int ray_sort_bits = 0;           // grid bits per axis; 0 = rays are walked in queue order
+  double scene_box[6];             // union of the instances' world boxes (the sort's grid)
+  uint32_t *d_sort[4] = {nullptr, nullptr, nullptr, nullptr};   // keys, keys_alt, slots, perm (in the `work` arena)
+  void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; size_t sort_cap = 0;
   // frame-level buffers of fjgpu_render_frame_multi (lazily sized, freed with the scene)
   float *d_frame = nullptr; size_t d_frame_n = 0;      // this device's framebuffer
   float *d_slab = nullptr; size_t d_slab_n = 0;        // packed tiles: own ones (sender) / incoming (first device)
@@ -156,6 +162,8 @@ static const char *bad_render(const fj_render_desc *r)
   return nullptr;
 }
 
+static long g_ray_sort = -1;       // "ray_sort": grid bits per axis of the ray-queue sort (fjgpu_raysort.hip); 0 = off, -1 = by scene
+static long g_ray_sort_min = FJ_RAY_SORT_MIN;   // "ray_sort_min": smaller launches keep queue order
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
@@ -163,6 +171,8 @@ extern "C" {
 int fjgpu_global_option(const char *name, long value)
 {
   if (!name) return fail(FJGPU_EINVAL, "bad option call");
+  if (std::string(name) == "ray_sort") { g_ray_sort = value < -1 ? -1 : (value > 9 ? 9 : value); return 0; }
+  if (std::string(name) == "ray_sort_min") { g_ray_sort_min = value < 1 ? 1 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -434,6 +444,13 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   S.incoherent_rays = (sc->max_children >= 2 || sc->bounce_diffuse) ? 1 : 0;
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
   S.pad_inc_ = 0;
+  S.ray_perm = nullptr;
+  for (int k = 0; k < 3; k++) { sc->scene_box[k] = DBL_MAX; sc->scene_box[3 + k] = -DBL_MAX; }
+  for (const auto &I : hs.instances)
+    for (int k = 0; k < 3; k++) { sc->scene_box[k] = std::min(sc->scene_box[k], I.wbounds[k]); sc->scene_box[3 + k] = std::max(sc->scene_box[3 + k], I.wbounds[3 + k]); }
+  // default: scenes whose shaders scatter (diffuse bounces, two children per hit) sort their secondary rays
+  sc->ray_sort_bits = g_ray_sort >= 0 ? (int) g_ray_sort : (S.incoherent_rays && !S.has_curves && !S.has_motion ? FJ_RAY_SORT_BITS : 0);
+  if (const char *e = getenv("FJGPU_RAY_SORT")) sc->ray_sort_bits = std::max(0, std::min(9, atoi(e)));
   HIP_TRY(hipDeviceSynchronize());
   *out = sc.release();
   return 0;
@@ -535,7 +552,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     sc->work.reset(new DeviceBuffers());
     // the adaptive sampler's buffers lived in the old arena (a new arena may be allocated at the
     // old one's address, so the owner pointer alone does not tell)
-    sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
+    sc->sort_cap = 0; sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
     sc->d_aseen = sc->d_afinal = nullptr; sc->d_apstate = sc->d_acells = nullptr;
     DeviceBuffers &W = *sc->work;
     int e = 0;
@@ -587,6 +604,20 @@ int ensure_level(fjgpu_scene *sc, int level, size_t cap)
   DeviceBuffers &W = *sc->work;
   if (W.alloc(cap, &L.rays) || W.alloc(cap, &L.paths)) return -1;   // older, smaller buffers stay owned by `work`
   L.cap = cap;
+  return 0;
+}
+
+// scratch of the ray-queue sort for up to `cap` rays (lives in the work arena like the queues)
+int ensure_sort(fjgpu_scene *sc, size_t cap)
+{
+  if (sc->sort_cap >= cap) return 0;
+  DeviceBuffers &W = *sc->work;
+  for (int k = 0; k < 4; k++) if (W.alloc(cap, &sc->d_sort[k])) return -1;
+  sc->sort_tmp_bytes = ray_sort_temp_bytes((uint32_t) cap, sc->ray_sort_bits);
+  char *tmp = nullptr;
+  if (W.alloc(sc->sort_tmp_bytes, &tmp)) return -1;
+  sc->d_sort_tmp = tmp;
+  sc->sort_cap = cap;
   return 0;
 }
 
@@ -677,6 +708,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0;
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
     sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
+    sc->sort_cap = 0;
     bt = std::max<long>(1, bt / 2);
   }
   // adaptive grid: split / leaf byte per lattice cell of every level (4/3 of the finest level)
@@ -839,8 +871,21 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         const DRay *rays = sc->levels[level].rays + off;
         const DPath *paths = sc->levels[level].paths + off;
         (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
-        int e = timed(st, &acc.closest_ms, [&]() {
-          return launch_trace_closest(st, S, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
+        // secondary rays leave the shading kernel in emission order: walk them in (octant, cell) order
+        DScene St = S;
+        int e = 0;
+        if (sc->ray_sort_bits > 0 && level >= 1 && (long) n >= g_ray_sort_min) {
+          if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");
+          e = timed(st, &acc.sort_ms, [&]() {
+            return launch_ray_sort(st, rays, n, sc->scene_box, sc->ray_sort_bits, sc->d_sort[0], sc->d_sort[1], sc->d_sort[2], sc->d_sort[3],
+                sc->d_sort_tmp, sc->sort_tmp_bytes);
+          });
+          if (e) return e;
+          St.ray_perm = sc->d_sort[3];
+          acc.rays_sorted += n;
+        }
+        e = timed(st, &acc.closest_ms, [&]() {
+          return launch_trace_closest(st, St, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
         });
         if (e) return e;
         acc.trace_launches++; acc.closest_launches++;
@@ -979,6 +1024,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     acc.total_ms = ms;
     for (const Span &sp : spans)
       if (hipEventElapsedTime(&ms, sc->ev_pool[sp.a], sc->ev_pool[sp.b]) == hipSuccess) *sp.bucket += ms;
+    acc.closest_ms += acc.sort_ms;       // the sort is part of what the closest-hit side costs
     acc.trace_ms = acc.closest_ms + acc.light_loop_ms + acc.shadow_walk_ms;
   }
   (void) hipEventDestroy(ev_all[0]); (void) hipEventDestroy(ev_all[1]);

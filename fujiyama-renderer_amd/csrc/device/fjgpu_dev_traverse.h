@@ -514,8 +514,11 @@ struct ClosestPolicy {
   const DPath *paths;
   DHit *hits;
   int default_group;
-  __device__ bool fetch(uint32_t i, RayIn *r) const
+  // launch entry -> ray slot (DScene.ray_perm: the launch walks the queue in sorted order)
+  __device__ __forceinline__ uint32_t slot(uint32_t i) const { return S->ray_perm ? S->ray_perm[i] : i; }
+  __device__ bool fetch(uint32_t k, RayIn *r) const
   {
+    const uint32_t i = slot(k);
     const DRay q = rays[i];
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = q.tmin; r->tmax = q.tmax;
@@ -524,11 +527,11 @@ struct ClosestPolicy {
     r->anyhit = false;
     return true;
   }
-  __device__ void finish(uint32_t i, const Best &b) const
+  __device__ void finish(uint32_t k, const Best &b) const
   {
     DHit h;
     h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
-    hits[i] = h;
+    hits[slot(k)] = h;
   }
 };
 

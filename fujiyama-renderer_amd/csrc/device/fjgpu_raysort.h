@@ -1,0 +1,24 @@
+// fjgpu_raysort.h -- ray-queue sort in front of the closest-hit walk (fjgpu_raysort.hip)
+#ifndef FJGPU_RAYSORT_H
+#define FJGPU_RAYSORT_H
+
+#include <hip/hip_runtime.h>
+
+#include "fjgpu_types.h"
+
+#ifndef FJ_RAY_SORT_BITS
+#define FJ_RAY_SORT_BITS 7           // default grid of the sort: 2^7 cells per axis (24-bit keys, three radix passes)
+#endif
+#ifndef FJ_RAY_SORT_MIN
+#define FJ_RAY_SORT_MIN (1u << 16)   // smaller launches are walked in queue order (the sort's launches would cost more)
+#endif
+
+// bytes of scratch the radix sort of n (key, slot) pairs over 3 + 3 * bits key bits needs
+size_t ray_sort_temp_bytes(uint32_t n, int bits);
+
+// perm[k] = slot of the k-th ray in (direction octant, Morton cell of the origin in a 2^bits grid over
+// `box`) order.  keys / keys_alt / slots / perm: n words each; temp: ray_sort_temp_bytes(n, bits).
+int launch_ray_sort(hipStream_t st, const DRay *rays, uint32_t n, const double box[6], int bits,
+    uint32_t *keys, uint32_t *keys_alt, uint32_t *slots, uint32_t *perm, void *temp, size_t temp_bytes);
+
+#endif

@@ -190,6 +190,8 @@ struct DScene {
   int32_t incoherent_rays;     // some shader emits two children per hit or diffuse bounces (glass, pathtracing): the
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
   int32_t pad_inc_;
+  const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
+                               // (hits are written to the ray's own slot); null = queue order
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
   const fj_xform_desc *xforms; // instances with DInstance.xform >= 0
   const fj_xform_desc *cam_xform;   // null = static camera

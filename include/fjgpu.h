@@ -68,6 +68,8 @@ typedef struct fjgpu_stats {
   uint64_t shadow_prims;       /* triangle / curve tests of the shadow walk alone */
   uint64_t shadow_insts;       /* instance boxes tested by the shadow walk alone */
   uint32_t closest_launches, light_loop_launches, shadow_walk_launches, pad_;
+  double   sort_ms;            /* ray-queue sort in front of the closest-hit walk (option "ray_sort"; part of closest_ms) */
+  uint64_t rays_sorted;        /* rays that went through it */
 } fjgpu_stats;
 
 /* Number of visible HIP devices (0 when there is none). */
