@@ -21,6 +21,7 @@
 #include "fjgpu_kernels.h"
 #include "fjgpu_lbvh.h"
 #include "fjgpu_raysort.h"
+#include "fjgpu_tlas.h"
 
 namespace {
 
@@ -164,6 +165,8 @@ static const char *bad_render(const fj_render_desc *r)
 
 static long g_ray_sort = -1;       // "ray_sort": grid bits per axis of the ray-queue sort (fjgpu_raysort.hip); 0 = off, -1 = by scene
 static long g_ray_sort_min = FJ_RAY_SORT_MIN;   // "ray_sort_min": smaller launches keep queue order
+static long g_device_tlas = 1;     // "device_tlas": the instance level of every group is built on the device (fjgpu_tlas.hip)
+static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
@@ -173,6 +176,8 @@ int fjgpu_global_option(const char *name, long value)
   if (!name) return fail(FJGPU_EINVAL, "bad option call");
   if (std::string(name) == "ray_sort") { g_ray_sort = value < -1 ? -1 : (value > 9 ? 9 : value); return 0; }
   if (std::string(name) == "ray_sort_min") { g_ray_sort_min = value < 1 ? 1 : value; return 0; }
+  if (std::string(name) == "device_tlas") { g_device_tlas = value != 0; return 0; }
+  if (std::string(name) == "tlas_verify") { g_tlas_verify = value != 0; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -356,8 +361,33 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     }
     e |= M.upload(ai.data(), ai.size(), &S.any_insts);
   }
-  e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
-  e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
+  if (g_device_tlas && e == 0 && !hs.groups.empty()) {
+    // instance level on the device, from the instance table just uploaded
+    std::vector<int> mcount(hs.groups.size()), nfirst, ncount;
+    for (size_t g = 0; g < hs.groups.size(); g++) mcount[g] = hs.groups[g].n_instances;
+    DTNode *d_nodes = nullptr;
+    std::string terr;
+    if (TlasBuildDevice(S.instances, hs.group_members, hs.group_member_first, mcount, &nfirst, &ncount, &d_nodes, &terr))
+      return fail(FJGPU_ENODEV, terr);
+    M.ptrs.push_back(d_nodes);
+    size_t total = 0;
+    for (int c : ncount) total += (size_t) c;
+    if (g_tlas_verify) {
+      std::vector<DTNode> got(total);
+      HIP_TRY(hipMemcpy(got.data(), d_nodes, total * sizeof(DTNode), hipMemcpyDeviceToHost));
+      bool same = total == hs.group_nodes.size();
+      for (size_t g = 0; same && g < hs.groups.size(); g++) same = nfirst[g] == hs.groups[g].first && ncount[g] == hs.groups[g].count;
+      if (same && total) same = std::memcmp(got.data(), hs.group_nodes.data(), total * sizeof(DTNode)) == 0;
+      if (!same) return fail(FJGPU_ENODEV, "device TLAS build differs from the host's build");
+    }
+    std::vector<DGroup> groups = hs.groups;
+    for (size_t g = 0; g < groups.size(); g++) { groups[g].first = nfirst[g]; groups[g].count = ncount[g]; }
+    e |= M.upload(groups.data(), groups.size(), &S.groups);
+    S.group_nodes = d_nodes;
+  } else {
+    e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
+    e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
+  }
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
   S.cam_xform = nullptr;

@@ -491,61 +491,79 @@ int build_mesh(const fj_mesh_desc &m, HostPrimSet *ps, std::string *err, bool de
 
 int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err);   // fjgpu_curve_build.cc
 
-// Instance level of one group (replaces the reference's BVHAccelerator over ObjectInstances,
-// src/fj_bvh_accelerator.cc:79-107,253-334): object-median splits over the instances'
-// reference boxes, flattened depth first with skip links (DTNode).  Small groups stay a list.
+// Instance level of one group (the reference's BVHAccelerator over ObjectInstances,
+// src/fj_bvh_accelerator.cc:79-107,253-334).  The TOPOLOGY is the reference's own -- sort the range
+// by centroid on the cycling axis, split where find_median says -- because its depth-first leaf
+// order decides which instance keeps an exactly equal t (the first one visited).  It is stored as a
+// threaded list (DTNode): the leaves in that order, and an inner node with the union box in front
+// of every subtree of more than TLAS_FLAT leaves (smaller subtrees are scanned).  Equal centroids
+// (the reference's std::sort leaves their order open) are ordered by position in the group.
+// The device builds the same list with the same arithmetic (fjgpu_tlas.hip); this host version
+// serves scene builds without a device and the node-for-node check of the device build.
 namespace {
-void emit_group_nodes(const std::vector<DInstance> &instances, std::vector<int> &m, int begin, int end, std::vector<DTNode> *out)
+struct TlasItem { double c[3]; int slot; };
+
+int tlas_find_median(const std::vector<TlasItem> &it, const std::vector<int> &ord, int begin, int end, int axis)   // :313-334
+{
+  int low = begin, high = end - 1, mid = -1;
+  const double key = (it[ord[low]].c[axis] + it[ord[high]].c[axis]) / 2;
+  while (low != mid) {
+    mid = (low + high) / 2;
+    if (key < it[ord[mid]].c[axis]) high = mid;
+    else if (it[ord[mid]].c[axis] < key) low = mid;
+    else break;
+  }
+  return mid + 1;
+}
+
+void emit_group_nodes(const std::vector<DInstance> &instances, const std::vector<int> &members, const std::vector<TlasItem> &it,
+    std::vector<int> &ord, int begin, int end, int axis, std::vector<DTNode> *out)
 {
   const int n = end - begin;
-  if (n <= 4) {
-    for (int i = begin; i < end; i++) { DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = m[i]; leaf.skip = 0; out->push_back(leaf); }
+  if (n == 1) {
+    DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = members[ord[begin]]; leaf.skip = 0; out->push_back(leaf);
     return;
   }
-  double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-  double cmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, cmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-  for (int i = begin; i < end; i++) {
-    const double *b = instances[m[i]].wbounds;
-    for (int k = 0; k < 3; k++) {
-      mn[k] = std::min(mn[k], b[k]); mx[k] = std::max(mx[k], b[3 + k]);
-      const double c = .5 * (b[k] + b[3 + k]);
-      cmn[k] = std::min(cmn[k], c); cmx[k] = std::max(cmx[k], c);
-    }
-  }
-  int axis = 0;
-  for (int k = 1; k < 3; k++) if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-  const int mid = begin + n / 2;
-  std::nth_element(m.begin() + begin, m.begin() + mid, m.begin() + end, [&](int a, int b) {
-    const double *ba = instances[a].wbounds, *bb = instances[b].wbounds;
-    return ba[axis] + ba[3 + axis] < bb[axis] + bb[3 + axis];
+  std::sort(ord.begin() + begin, ord.begin() + end, [&](int a, int b) {
+    return it[a].c[axis] < it[b].c[axis] || (it[a].c[axis] == it[b].c[axis] && a < b);
   });
+  const int median = tlas_find_median(it, ord, begin, end, axis);
   const size_t me = out->size();
-  DTNode inner;
-  std::memset(&inner, 0, sizeof(inner));
-  inner.inst = -1;
-  for (int k = 0; k < 3; k++) {
-    // widened: the walk tests inner boxes with approximate reciprocals (culling only)
-    const double pad = 1e-9 * (std::fabs(mn[k]) + std::fabs(mx[k])) + 1e-12;
-    inner.box[k] = mn[k] - pad; inner.box[3 + k] = mx[k] + pad;
+  if (n > FJ_TLAS_FLAT) {
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int i = begin; i < end; i++) {
+      const double *b = instances[members[ord[i]]].wbounds;
+      for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], b[k]); mx[k] = std::max(mx[k], b[3 + k]); }
+    }
+    DTNode inner;
+    std::memset(&inner, 0, sizeof(inner));
+    inner.inst = -1;
+    for (int k = 0; k < 3; k++) {
+      // widened: the walk tests inner boxes with approximate reciprocals (culling only)
+      const double pad = 1e-9 * (std::fabs(mn[k]) + std::fabs(mx[k])) + 1e-12;
+      inner.box[k] = mn[k] - pad; inner.box[3 + k] = mx[k] + pad;
+    }
+    out->push_back(inner);
   }
-  out->push_back(inner);
-  // each half gets its own inner node only if it is worth one
-  for (int half = 0; half < 2; half++) {
-    const int b = half ? mid : begin, e = half ? end : mid;
-    emit_group_nodes(instances, m, b, e, out);
-  }
-  (*out)[me].skip = (int) out->size();
+  emit_group_nodes(instances, members, it, ord, begin, median, (axis + 1) % 3, out);
+  emit_group_nodes(instances, members, it, ord, median, end, (axis + 1) % 3, out);
+  if (n > FJ_TLAS_FLAT) (*out)[me].skip = (int) out->size();
 }
 }  // namespace
 
 void BuildGroupNodes(const std::vector<DInstance> &instances, const std::vector<int> &members, std::vector<DTNode> *out)
 {
-  std::vector<int> m = members;
-  if (m.size() <= 8) {          // a plain list in group order: the walk is the linear scan
-    for (int inst : m) { DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = inst; out->push_back(leaf); }
-    return;
+  const int n = (int) members.size();
+  if (n == 0) return;
+  std::vector<TlasItem> it(n);
+  std::vector<int> ord(n);
+  for (int i = 0; i < n; i++) {
+    const double *b = instances[members[i]].wbounds;
+    for (int k = 0; k < 3; k++) it[i].c[k] = .5 * (b[k] + b[3 + k]);       // Box::Centroid, src/fj_box.cc:63-66
+    it[i].slot = i;
+    ord[i] = i;
   }
-  emit_group_nodes(instances, m, 0, (int) m.size(), out);
+  emit_group_nodes(instances, members, it, ord, 0, n, 0, out);      // (skip links are indices into *out: DGroup.first included)
 }
 
 int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, bool device_mesh_build)
@@ -637,6 +655,8 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, boo
 
   out->groups.resize(d->n_groups);
   out->group_nodes.clear();
+  out->group_members.clear();
+  out->group_member_first.clear();
   for (int g = 0; g < d->n_groups; g++) {
     DGroup &G = out->groups[g];
     G.first = (int) out->group_nodes.size();
@@ -655,6 +675,8 @@ int BuildHostScene(const fj_scene_desc *d, HostScene *out, std::string *err, boo
         if (sid >= 0 && d->shaders[sid].type == FJ_SHADER_PLASTIC && d->shaders[sid].opacity < 1.f) G.all_opaque = 0;
       }
     }
+    out->group_member_first.push_back((int) out->group_members.size());
+    out->group_members.insert(out->group_members.end(), members.begin(), members.end());
     BuildGroupNodes(out->instances, members, &out->group_nodes);
     G.count = (int) out->group_nodes.size() - G.first;
     // Accelerator::ComputeBounds of a group: ObjectSet bounds + PADDING.  Only needed for

@@ -49,6 +49,9 @@ struct HostScene {
   std::vector<HostPrimSet> primsets;          // meshes first, then curve sets
   std::vector<DInstance> instances;
   std::vector<DGroup> groups;
+  std::vector<int> group_members;             // instance indices of every group, concatenated in group order (DGroup order;
+                                              // group g owns n_instances entries from group_member_first[g])
+  std::vector<int> group_member_first;
   std::vector<DTNode> group_nodes;            // threaded instance BVH of every group (DGroup.first / count)
   std::vector<fj_shader_desc> shaders;
   std::vector<fj_xform_desc> xforms;          // time-sampled instance transforms (DInstance.xform)

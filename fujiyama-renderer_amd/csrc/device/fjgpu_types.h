@@ -123,9 +123,12 @@ static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 
 // Instance level of a group: a THREADED bounding-volume hierarchy (depth-first node list with
 // skip links, no stack).  Walk: i = first; a leaf (inst >= 0) is a candidate instance, go to
-// i + 1; an inner node whose box the ray misses jumps to `skip`, else go to i + 1.  Groups of
-// up to 8 instances are stored as a plain list of leaves in group order (the walk then is the
-// linear scan).  Inner boxes are unions of the instances' reference boxes, slightly widened.
+// i + 1; an inner node whose box the ray misses jumps to `skip`, else go to i + 1.  The leaves are
+// in the depth-first order of the REFERENCE's instance BVH (src/fj_bvh_accelerator.cc:253-334: the
+// first instance visited keeps an exactly equal t); subtrees of up to FJ_TLAS_FLAT leaves have no
+// inner node (they are scanned).  Inner boxes are unions of the instances' reference boxes,
+// slightly widened.  Built on the device (fjgpu_tlas.hip) or, identically, on the host.
+#define FJ_TLAS_FLAT 4
 struct DTNode {
   double box[6];               // inner nodes only
   int32_t inst;                // instance index, or -1 for an inner node

@@ -354,6 +354,40 @@ def test_device_blas_build_gives_the_same_hits_and_pixels(asset_dir, golden_dir,
         gpu.global_option("device_build", 0)
 
 
+def test_device_tlas_equals_host_tlas_node_for_node(asset_dir):
+    """the instance level of every group is built on the device (fjgpu_tlas.hip: reference topology,
+    sort by centroid on the cycling axis + find_median, threaded depth first); option tlas_verify makes
+    scene creation compare it byte for byte with the host's build of the same list.  A frame rendered
+    with either list is the same frame, and it is the oracle's."""
+    scenes = [workloads.crowd(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", n=150),
+              workloads.crowd(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", n=777, nlights=2),
+              workloads.cornell(asset_dir, res=(48, 32), spp=(2, 2), mesh="tiny"),
+              workloads.buddhas(asset_dir, res=(64, 36), spp=(2, 2), mesh="tiny")]
+    gpu.global_option("tlas_verify", 1)
+    try:
+        for k, text in enumerate(scenes):
+            sp, rd = prepare(text)
+            gs = gpu.Scene(sp)                       # fails if the two builds differ
+            fb_dev, st_dev = gs.render_frame(rd)
+            gs.close()
+            gpu.global_option("device_tlas", 0)
+            gs = gpu.Scene(sp)
+            fb_host, st_host = gs.render_frame(rd)
+            gs.close()
+            gpu.global_option("device_tlas", 1)
+            assert st_dev.rays.as_dict() == st_host.rays.as_dict()
+            assert float(rel_err(fb_dev, fb_host).max()) <= 1e-6
+            if k == 0:
+                osc = oracle_ffi.OracleScene(sp)
+                ref, rc = osc.render(rd)
+                osc.close()
+                assert st_dev.rays.as_dict() == rc.as_dict()
+                assert float(rel_err(fb_dev, ref).max()) <= REL_TOL
+    finally:
+        gpu.global_option("tlas_verify", 0)
+        gpu.global_option("device_tlas", 1)
+
+
 def test_unsupported_features_fail_loudly(asset_dir):
     """features outside the device path: explicit error naming the feature, never a silent
     approximation or a CPU fallback"""
