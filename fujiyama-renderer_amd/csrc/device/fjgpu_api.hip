@@ -304,7 +304,15 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   DScene &S = sc->S;
   std::memset(&S, 0, sizeof(S));
   e |= M.upload(dps.data(), dps.size(), &S.primsets);
-  e |= M.upload(hs.instances.data(), hs.instances.size(), &S.instances);
+  {
+    std::vector<DInstance> di = hs.instances;
+    for (DInstance &I : di) {
+      const DPrimSet &P = dps[I.primset];
+      std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
+      I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
+    }
+    e |= M.upload(di.data(), di.size(), &S.instances);
+  }
   {
     // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
     // grid = 65536^3 cells over the primitive set's padded bounds

@@ -521,7 +521,9 @@ void emit_group_nodes(const std::vector<DInstance> &instances, const std::vector
 {
   const int n = end - begin;
   if (n == 1) {
-    DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = members[ord[begin]]; leaf.skip = 0; out->push_back(leaf);
+    DTNode leaf; std::memset(&leaf, 0, sizeof(leaf)); leaf.inst = members[ord[begin]]; leaf.skip = 0;
+    std::memcpy(leaf.box, instances[leaf.inst].wbounds, sizeof(leaf.box));
+    out->push_back(leaf);
     return;
   }
   std::sort(ord.begin() + begin, ord.begin() + end, [&](int a, int b) {

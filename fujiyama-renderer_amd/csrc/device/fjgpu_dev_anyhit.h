@@ -200,7 +200,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
               gi++;
               if (kCount) lc->insts++;
               // (a single-instance group's box: the light loop queued this ray BECAUSE that test passed)
-              if (!single && !box_ray_ref_fast(S.instances[tn_->inst].wbounds, o, d, winv, plain, tmin, tmax)) continue;
+              if (!single && !box_ray_ref_fast(tn_->box, o, d, winv, plain, tmin, tmax)) continue;
               inst = tn_->inst;
               break;
             }

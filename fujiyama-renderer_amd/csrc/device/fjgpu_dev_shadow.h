@@ -194,8 +194,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
                   continue;
                 }
                 ti++;
-                const DInstance *I = &S.instances[tn_->inst];
-                if (box_ray_ref_fast(I->wbounds, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
+                if (box_ray_ref_fast(tn_->box, Ps, Ln, winv, plain, .0001, distance)) { maybe_occluded = true; break; }
                 c_insts++;
               }
             }

@@ -151,6 +151,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     // ---- lanes between instances: enter the next instance or retire the ray
     if (have && cur == TRAV_DONE && (!kCurves || pend == 0xffffffffu)) {
       bool found = false;
+      uint32_t root = TRAV_DONE;
       if (kCurves) {
         // the curve instantiation lives on registers (the ribbon test): what only this block needs
         // of the world-space ray is read again from the queue instead of being carried through it
@@ -178,7 +179,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
         // the reference's own (possibly non-enclosing) instance box, full ray range
-        if (!box_ray_ref_fast(single ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+        if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
         if (kMotion && I->xform >= 0) {
           // ObjectInstance::RayIntersect evaluates a time-sampled transform at the ray's time
           double tm[12], tmi[12];
@@ -192,15 +193,16 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (has_negative_zero(od)) continue;
         const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
         P = &S.primsets[I->primset];
-        nodes = P->nodes;
-        if (P->n_prims == 0) continue;
-        if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-        s32 = slab32_setup(oo, inv, P->bounds);
+        nodes = I->pnodes;
+        if (I->pn_prims == 0) continue;
+        if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+        s32 = slab32_setup(oo, inv, I->pbounds);
+        root = I->proot;
         found = true;
         break;
       }
       if (found) {
-        cur = P->root; sp = 0; last_curve = 0xffffffffu;
+        cur = root; sp = 0; last_curve = 0xffffffffu;
         if (kCurves && P->type == FJ_PRIMSET_CURVE) { RaySpace rsp = {stk.rayspace, oo, od}; rsp.set(oo, od); }
       }
       else { pol.finish(idx, best); have = false; }
@@ -399,6 +401,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       if (next > range_end) next = range_end;
       if (fin && have) {
         bool found = false;
+        uint32_t root = TRAV_DONE;
         const bool dead_ray = has_negative_zero(d);   // every box test of the reference fails (BoxRayIntersect's -0.0 quirk)
         const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
         const bool plain = plain_dir(d);
@@ -418,7 +421,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           double tn;
           const double tfar = anyhit ? tmax : fmin(tmax, best.t);
           // the reference's own (possibly non-enclosing) instance box, full ray range
-          if (!box_ray_ref_fast(single ? gsb : I->wbounds, o, d, winv, plain, tmin, tmax)) continue;
+          if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
           if (kMotion && I->xform >= 0) {
             double tm[12], tmi[12];
             xform_at(&S.xforms[I->xform], rtime, tm, tmi);
@@ -431,14 +434,15 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           if (has_negative_zero(od)) continue;
           const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
           P = &S.primsets[I->primset];
-          nodes = P->nodes;
-          if (P->n_prims == 0) continue;
-          if (!slab(P->bounds, P->bounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-          s32 = slab32_setup(oo, inv, P->bounds);
+          nodes = I->pnodes;
+          if (I->pn_prims == 0) continue;
+          if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
+          s32 = slab32_setup(oo, inv, I->pbounds);
+          root = I->proot;
           found = true;
           break;
         }
-        if (found) { cur = P->root; sp = 0; }
+        if (found) { cur = root; sp = 0; }
         else { pol.finish(idx, best); have = false; }
       }
       continue;

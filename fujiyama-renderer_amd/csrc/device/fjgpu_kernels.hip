@@ -170,7 +170,7 @@ static TravTune trav_tune()
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
     t.refill_curves = env("FJGPU_TRAV_REFILL_CURVES", 16);   // the ribbon-test instantiations (C5: 16 / 24 / 32 / 40 -> 2.59 / 2.63 / 2.81 / ~3 s)
-    t.steps_curves = env("FJGPU_TRAV_STEPS_CURVES", 4);      // ... and their inner steps per iteration (2 / 3 / 4 -> 2.77 / 2.63 / 2.56 s)
+    t.steps_curves = env("FJGPU_TRAV_STEPS_CURVES", 6);      // ... and their inner steps per iteration (2 / 3 / 4 -> 2.77 / 2.63 / 2.56 s; at 3 waves 4 / 6 -> 2.19 / 2.15 s)
     t.steps = env("FJGPU_TRAV_STEPS", 3);
     t.grab = env("FJGPU_TRAV_GRAB", 256);
     // lean any-hit walk: up to `anyhit_steps` inner steps per iteration, the 2nd and later ones only

@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(TB) k_tlas_emit(const DInstance *inst, const i
   }
   for (int i = tid; i < N; i += TB) {
     DTNode nd;
-    for (int k = 0; k < 6; k++) nd.box[k] = 0.;
     nd.inst = members[off + ord[i]];
+    for (int k = 0; k < 6; k++) nd.box[k] = inst[nd.inst].wbounds[k];
     nd.skip = 0;
     nodes[first + i + hist[i + 1]] = nd;     // hist[i + 1] = #(inner nodes starting at or before i)
   }

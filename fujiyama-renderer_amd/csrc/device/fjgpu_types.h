@@ -101,7 +101,10 @@ struct DInstance {
   int32_t reflect_target, refract_target, shadow_target;
   int32_t xform;               // time-sampled transform: index into DScene.xforms (M / Minv above hold
                                // the time-0 matrices); -1 = static
-  int32_t pad[2];
+  int32_t pn_prims;            // copies of the primitive set's entry data (DPrimSet bounds / nodes / root / n_prims,
+  uint32_t proot;              // filled at upload): entering an instance costs ONE dependent load after the
+  double pbounds[6];           // instance-level node instead of instance -> primitive set
+  const DNode *pnodes;
 };
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
@@ -130,7 +133,8 @@ static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 // slightly widened.  Built on the device (fjgpu_tlas.hip) or, identically, on the host.
 #define FJ_TLAS_FLAT 4
 struct DTNode {
-  double box[6];               // inner nodes only
+  double box[6];               // inner node: union box (widened); leaf: the instance's reference box (DInstance.wbounds:
+                               // a ray that misses it never touches the instance record)
   int32_t inst;                // instance index, or -1 for an inner node
   int32_t skip;                // inner nodes: index of the node after this subtree
 };
