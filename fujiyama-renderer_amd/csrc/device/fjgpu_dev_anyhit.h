@@ -64,9 +64,21 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   return true;
 }
 
+#ifndef FJ_XCD_HEADS
+#define FJ_XCD_HEADS 1                  // 0: one global head
+#endif
+// the XCD this wave runs on (0..7); speed only: any value gives the same result
+__device__ __forceinline__ uint32_t xcc_id()
+{
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xfu;
+}
+#ifndef FJ_ANYHIT_POSTPONE
+#define FJ_ANYHIT_POSTPONE 1
+#endif
 #ifdef FJ_PHASE_STATS
 // debug build only: wave-level phase executions and the lanes active in them
-__device__ unsigned long long g_phase[16];
 #define PH(i, v) do { ph[i] += (unsigned long long) (v); } while (0)
 #else
 #define PH(i, v) do { } while (0)
@@ -79,7 +91,7 @@ __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 // entry names its instance (the instance-BVH walk and its registers are compiled out).
 template <bool kCount, bool kMulti>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
-    uint32_t n, uint32_t *head, uint32_t *s_stack, LocalCounters *lc)
+    uint32_t n, uint32_t *head, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
   // Per-lane traversal stack: FJ_STACK_LDS_ANYHIT entries in LDS ([depth][thread]), deeper ones
@@ -97,6 +109,11 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   bool head_live = true;                   // wave-uniform: the global head still has entries
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
   tune.grab = adaptive_grab(tune.grab, n);
+#if FJ_XCD_HEADS
+  // queue regions by XCD (DCounters.shadow_xcd_head): region r = [r * per, (r + 1) * per), per a multiple of the claim
+  const uint32_t per = ((n / 8u + TRAV_GRAB) / TRAV_GRAB) * TRAV_GRAB;
+  uint32_t region = xcc_id() & 7u, regions_left = 8u;
+#endif
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
   V3 oo = mk(0, 0, 0), od = oo;            // object-space ray (f64: the triangle test's operands)
@@ -110,6 +127,13 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   int gi = 0, gend = 0;                    // cursor in the group's instance BVH; gi < 0: ~instance, settled by the light loop
   uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base (triangles: f32 records, see fjgpu_api.hip)
   uint32_t cur = TRAV_DONE;
+#if FJ_ANYHIT_POSTPONE
+  // a POSTPONED leaf: a lane that reaches a leaf while its stack is not empty sets the leaf aside and
+  // walks on, so it has work in whichever phase the wave runs next (any hit ends the ray and 7 of 8
+  // rays reach the light: the order of the tests is free, nothing is wasted but the inner steps an
+  // occluded ray takes before its postponed leaf is tested)
+  uint32_t pleaf = TRAV_DONE;
+#endif
   int sp = 0;
   const double tmin = .0001;
 #ifdef FJ_PHASE_STATS
@@ -118,9 +142,16 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 
   for (;;) {
     PH(0, 1);
+#if FJ_ANYHIT_POSTPONE
+    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+    const bool fin = cur == TRAV_DONE && pleaf == TRAV_DONE;
+    const bool at_inner = cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG);
+    const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
+#else
     const bool fin = cur == TRAV_DONE;
     const bool at_leaf = !fin && (cur & FJ_LEAF_FLAG);
     const bool at_inner = !fin && !at_leaf;
+#endif
     const unsigned long long m_leaf = __ballot(at_leaf), m_inner = __ballot(at_inner);
     const unsigned n_leaf = (unsigned) __popcll(m_leaf), n_inner = (unsigned) __popcll(m_inner);
     // lanes for which a turnover does something: a ray to retire / move on, or a new one to fetch
@@ -132,6 +163,17 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (m_turn == 0ull) break;           // nothing in flight, nothing left to fetch
       PH(1, 1); PH(2, n_turn);
       // ---- turnover: retire, fetch, enter
+#if FJ_XCD_HEADS
+      while (next >= range_end && head_live) {
+        const uint32_t lo = region * per, hi = (n - lo < per) ? n : lo + per;     // (lo < n whenever this region holds entries)
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&xheads[region * 32u], (uint32_t) TRAV_GRAB);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lo < n && base < hi - lo) { next = lo + base; range_end = (hi - next < TRAV_GRAB) ? hi : next + TRAV_GRAB; }
+        else if (--regions_left == 0u) head_live = false;
+        else region = (region + 1u) & 7u;
+      }
+#else
       if (next >= range_end && head_live) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
@@ -139,6 +181,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         if (base >= n) head_live = false;
         else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
       }
+#endif
       bool fetch = false;
       if (fin) {
         fetch = true;
@@ -300,14 +343,23 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (nh > 3) push(sp, r3);
           }
         }
+#if FJ_ANYHIT_POSTPONE
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+#endif
       }
       }
     } else {
       // ---- leaves: ONE triangle per lane; the first hit inside [tmin, tmax] ends the ray
       PH(5, 1); PH(6, n_leaf);
       if (at_leaf) {
-        const uint32_t first = (cur & 0x7fffffffu) >> 3;
-        const uint32_t more = cur & 7u;
+#if FJ_ANYHIT_POSTPONE
+        const bool from_p = pleaf != TRAV_DONE;        // the postponed leaf first: its slot frees
+        const uint32_t lf = from_p ? pleaf : cur;
+#else
+        const uint32_t lf = cur;
+#endif
+        const uint32_t first = (lf & 0x7fffffffu) >> 3;
+        const uint32_t more = lf & 7u;
         double t, u, v;
         if (kCount) lc->prims++;
         const double tmax = squeue[idx].tmax;
@@ -316,8 +368,14 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         FJ_SCHED_FENCE();
         if (tri_ray_fenced(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
+#if FJ_ANYHIT_POSTPONE
+          pleaf = TRAV_DONE;
+#endif
           PH(10, 1);
         }
+#if FJ_ANYHIT_POSTPONE
+        else if (from_p) pleaf = more ? (FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u)) : TRAV_DONE;
+#endif
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (sp == 0) ? TRAV_DONE : pop(sp);
       }
@@ -351,7 +409,7 @@ __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYH
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, s_stack, &lc);
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

@@ -22,6 +22,10 @@
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
 // tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
+#ifdef FJ_PHASE_STATS
+// debug builds only: wave-level phase executions / tail lengths (printed by debug_phase_stats)
+__device__ unsigned long long g_phase[16];
+#endif
 struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
@@ -105,8 +109,15 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
   uint32_t pend = 0xffffffffu;            // BLAS slot of a curve whose second-stage test is deferred (the lane walks on)
   int sp = 0;
+#ifdef FJ_PHASE_STATS
+  unsigned long long it_all = 0, it_tail = 0;   // wave iterations; ... after the queue ran dry for this wave
+#endif
 
   for (;;) {
+#ifdef FJ_PHASE_STATS
+    it_all++;
+    if (!head_live && next >= range_end) it_tail++;
+#endif
     // ---- refill idle lanes from the wave's slice
     const unsigned long long idle = __ballot(!have);
     if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL)) {
@@ -143,7 +154,12 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       }
       next += (uint32_t) __popcll(idle);
       if (__ballot(have) == 0ull) {
-        if (next >= range_end && !head_live) break;
+        if (next >= range_end && !head_live) {
+#ifdef FJ_PHASE_STATS
+          if (lane == 0) { atomicMax(&g_phase[12], it_tail); atomicAdd(&g_phase[13], it_tail); atomicAdd(&g_phase[14], it_all); atomicAdd(&g_phase[15], 1ull); }
+#endif
+          break;
+        }
         continue;               // only padding slots were fetched / slice exhausted: claim more
       }
     }

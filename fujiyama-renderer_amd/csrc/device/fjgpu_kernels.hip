@@ -248,6 +248,7 @@ uint32_t shadow_queue_padding()          // every resident wave may leave one pa
 void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 {
   (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
+  (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head), st);
 }
 
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
@@ -323,7 +324,7 @@ void debug_phase_stats()
   unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
   static const char *names[16] = {"iters", "entry_execs", "entry_lanes", "inner_execs", "inner_lanes", "leaf_execs", "leaf_lanes",
-      "tri_execs", "tri_lanes", "", "hits", "refills", "", "", "", ""};
+      "tri_execs", "tri_lanes", "", "hits", "refills", "tail_iters_max", "tail_iters_sum", "walk_iters_sum", "walk_waves"};
   for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-12s %llu\n", names[i], h[i]);
   unsigned long long z[16] = {0};
   (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
