@@ -64,16 +64,6 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   return true;
 }
 
-#ifndef FJ_XCD_HEADS
-#define FJ_XCD_HEADS 1                  // 0: one global head
-#endif
-// the XCD this wave runs on (0..7); speed only: any value gives the same result
-__device__ __forceinline__ uint32_t xcc_id()
-{
-  uint32_t x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  return x & 0xfu;
-}
 #ifndef FJ_ANYHIT_POSTPONE
 #define FJ_ANYHIT_POSTPONE 1
 #endif
@@ -91,7 +81,7 @@ __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 // entry names its instance (the instance-BVH walk and its registers are compiled out).
 template <bool kCount, bool kMulti>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
-    uint32_t n, uint32_t *head, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
+    uint32_t n, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
   // Per-lane traversal stack: FJ_STACK_LDS_ANYHIT entries in LDS ([depth][thread]), deeper ones
@@ -109,11 +99,8 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   bool head_live = true;                   // wave-uniform: the global head still has entries
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
   tune.grab = adaptive_grab(tune.grab, n);
-#if FJ_XCD_HEADS
-  // queue regions by XCD (DCounters.shadow_xcd_head): region r = [r * per, (r + 1) * per), per a multiple of the claim
-  const uint32_t per = ((n / 8u + TRAV_GRAB) / TRAV_GRAB) * TRAV_GRAB;
-  uint32_t region = xcc_id() & 7u, regions_left = 8u;
-#endif
+  QueueClaim qc;                           // queue regions by XCD (DCounters.shadow_xcd_head)
+  qc.init(xheads, n, tune.grab);
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
   V3 oo = mk(0, 0, 0), od = oo;            // object-space ray (f64: the triangle test's operands)
@@ -163,25 +150,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (m_turn == 0ull) break;           // nothing in flight, nothing left to fetch
       PH(1, 1); PH(2, n_turn);
       // ---- turnover: retire, fetch, enter
-#if FJ_XCD_HEADS
-      while (next >= range_end && head_live) {
-        const uint32_t lo = region * per, hi = (n - lo < per) ? n : lo + per;     // (lo < n whenever this region holds entries)
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&xheads[region * 32u], (uint32_t) TRAV_GRAB);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (lo < n && base < hi - lo) { next = lo + base; range_end = (hi - next < TRAV_GRAB) ? hi : next + TRAV_GRAB; }
-        else if (--regions_left == 0u) head_live = false;
-        else region = (region + 1u) & 7u;
-      }
-#else
-      if (next >= range_end && head_live) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
-        base = __shfl(base, 0);
-        if (base >= n) head_live = false;
-        else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
-      }
-#endif
+      if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
       bool fetch = false;
       if (fin) {
         fetch = true;
@@ -409,7 +378,7 @@ __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYH
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
   const uint32_t n = cnt->shadow_count;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_head, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

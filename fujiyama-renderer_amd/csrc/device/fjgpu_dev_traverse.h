@@ -42,6 +42,49 @@ __device__ __forceinline__ uint32_t adaptive_grab(uint32_t grab, uint32_t n)
   return want >= grab ? grab : (want < 16u ? 16u : want);
 }
 
+// Claims of a persistent walk, per XCD.  The queue is cut into 8 regions with a head each
+// (DCounters.*_xcd_head, one per 128-byte line); the waves of XCD x start in region x -- their L2 then
+// holds the nodes that ONE stretch of the queue walks, not those of eight, and a head has an eighth of
+// the pullers -- and move on to the next region when theirs is empty.  Everything here is wave-uniform.
+#ifndef FJ_XCD_HEADS
+#define FJ_XCD_HEADS 1                  // 0: one region
+#endif
+__device__ __forceinline__ uint32_t xcc_id()      // the XCD this wave runs on (0..7); speed only: any value gives the same result
+{
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xfu;
+}
+struct QueueClaim {
+  uint32_t *heads;
+  uint32_t n, per, grab, region, left;
+  __device__ __forceinline__ void init(uint32_t *heads_, uint32_t n_, uint32_t grab_)
+  {
+    heads = heads_; n = n_; grab = grab_;
+    const uint32_t parts = FJ_XCD_HEADS ? 8u : 1u;
+    per = ((n / parts + grab) / grab) * grab;       // a multiple of the claim; parts * per >= n
+    region = FJ_XCD_HEADS ? (xcc_id() & 7u) : 0u;
+    left = parts;
+  }
+  // the next slice [*next, *range_end) of the queue; false: the queue is empty
+  __device__ __forceinline__ bool claim(unsigned lane, uint32_t *next, uint32_t *range_end)
+  {
+    while (left) {
+      const uint32_t lo = region * per;
+      if (lo < n) {
+        const uint32_t hi = (n - lo < per) ? n : lo + per;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&heads[region * 32u], grab);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base < hi - lo) { *next = lo + base; *range_end = (hi - *next < grab) ? hi : *next + grab; return true; }
+      }
+      left--;
+      region = (region + 1u) & 7u;
+    }
+    return false;
+  }
+};
+
 struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
@@ -88,6 +131,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   // end up cheap or expensive and the slowest wave sets the kernel time.
   uint32_t next = 0, range_end = 0;        // wave-uniform
   tune.grab = adaptive_grab(tune.grab, n);
+  QueueClaim qc;
+  qc.init(head, n, tune.grab);
   if (kCurves) { tune.refill = tune.refill_curves; tune.steps = tune.steps_curves; }
   bool have = false;
   uint32_t idx = 0;
@@ -120,13 +165,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 #endif
     // ---- refill idle lanes from the wave's slice
     const unsigned long long idle = __ballot(!have);
-    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL)) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
-      base = __shfl(base, 0);
-      if (base >= n) head_live = false;
-      else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
-    }
+    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL))
+      head_live = qc.claim(lane, &next, &range_end);
     if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
       if (!have) {
         const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
@@ -363,6 +403,8 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
   bool head_live = true;
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
   tune.grab = adaptive_grab(tune.grab, n);
+  QueueClaim qc;
+  qc.init(head, n, tune.grab);
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o;
@@ -389,13 +431,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
     if ((unsigned) __popcll(m_turn) >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
       if (m_turn == 0ull) break;
       // ---- turnover: fetch, enter the next instance, or retire
-      if (next >= range_end && head_live) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, (uint32_t) TRAV_GRAB);
-        base = __shfl(base, 0);
-        if (base >= n) head_live = false;
-        else { next = base; range_end = (n - base < TRAV_GRAB) ? n : base + TRAV_GRAB; }
-      }
+      if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
       const bool fetch = fin && !have;
       const unsigned long long m_fetch = __ballot(fetch);
       if (fetch) {
@@ -576,7 +612,7 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc);
+  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -599,7 +635,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_head, make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc);
+  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

@@ -203,7 +203,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  (void) hipMemsetAsync(&cnt->trace_head, 0, sizeof(uint32_t), st);
+  (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head), st);
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
   // (the event counters cost registers and issue slots: counting is its own instantiation)
   const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));

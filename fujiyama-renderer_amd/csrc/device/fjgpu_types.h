@@ -281,10 +281,11 @@ struct DCounters {
   uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (line 3)
   uint32_t cull_head;          // light loop: next unclaimed light record of the current launch
   uint32_t pad3_[30];
-  // the lean any-hit walk claims per XCD: the shadow queue is cut into 8 regions, the waves of XCD x
+  // the persistent walks claim per XCD (QueueClaim, fjgpu_dev_traverse.h): the shadow queue is cut into 8 regions, the waves of XCD x
   // start in region x (their L2 then holds the nodes of ONE stretch of the queue, not of eight) and
   // move on to the next region when theirs is empty; one head per 128-byte line
   uint32_t shadow_xcd_head[8][32];
+  uint32_t trace_xcd_head[8][32];     // the same for the closest-hit walk
 };
 
 #endif
