@@ -130,7 +130,14 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" 0/1/2 -- 0 (default):
  * the host's binned-SAH build; 1: build the BLAS of meshes on the GPU by locally-ordered clustering
  * (surface-area agglomeration over the Morton order); 2: on the GPU as the radix tree of the Morton
- * codes (fastest build, slowest tree).  0 or FJGPU_EINVAL. */
+ * codes (fastest build, slowest tree).
+ * "device_tlas" 1/0 (default 1): the instance level of every group (the reference's BVHAccelerator over
+ * ObjectInstances, src/fj_bvh_accelerator.cc:253-334) is built on the GPU; 0: by the host's builder (the
+ * same list).  "tlas_verify" 0/1: scene creation also builds it on the host and fails on any byte that differs.
+ * "ray_sort" -1..9: grid bits per axis of the ray-queue sort in front of the closest-hit walk (rays of
+ * recursion level >= 1 in direction-octant / origin-cell order); 0 = off, -1 (default) = 7 bits in scenes
+ * whose shaders scatter (glass, pathtracing), off elsewhere.  "ray_sort_min": launches of fewer rays keep
+ * queue order (default 65536).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
 
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).
