@@ -64,6 +64,9 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   return true;
 }
 
+#ifndef FJ_ANYHIT_SIGNED_SLABS
+#define FJ_ANYHIT_SIGNED_SLABS 1
+#endif
 #ifndef FJ_ANYHIT_POSTPONE
 #define FJ_ANYHIT_POSTPONE 1
 #endif
@@ -262,8 +265,19 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
         if (kCount) lc->nodes++;
         const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], e = nd[3];
-        float tq;
         // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
+#if FJ_ANYHIT_SIGNED_SLABS
+        const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
+        const bool h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32);
+        FJ_SCHED_FENCE();
+        const bool h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32);
+        FJ_SCHED_FENCE();
+        const bool h2 = slab32q_test(w1.z, w1.w, w2.x, s32, shx, shy, shz, tmin32, tmax32) && e.z != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32) && e.w != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+#else
+        float tq;
         const bool h0 = slab32_test(unpack_q(w0.x), unpack_q(w0.y), unpack_q(w0.z), s32, tmin32, tmax32, &tq);
         FJ_SCHED_FENCE();
         const bool h1 = slab32_test(unpack_q(w0.w), unpack_q(w1.x), unpack_q(w1.y), s32, tmin32, tmax32, &tq);
@@ -272,6 +286,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         FJ_SCHED_FENCE();
         const bool h3 = slab32_test(unpack_q(w2.y), unpack_q(w2.z), unpack_q(w2.w), s32, tmin32, tmax32, &tq) && e.w != FJ_NO_CHILD;
         FJ_SCHED_FENCE();
+#endif
 #ifdef FJ_EXP_SLAB_VALIDATE
         {   // every box the f64 test accepts on the DECODED box must be accepted by the f32 test
           const DAnyInst *Av = &S.any_insts[vinst];

@@ -160,6 +160,28 @@ __device__ __forceinline__ bool slab32_test(fj_v2f px, fj_v2f py, fj_v2f pz, con
   *tnear = tn;
   return tn <= tf;
 }
+// The same test on a QUANTISED box with the direction signs of the ray used up front: wx wy wz are the
+// (min, max) words of one child; sh* = 16 where the ray runs towards smaller coordinates on that axis
+// (slab32_shift), else 0.  Rotating the word by sh puts the NEAR plane in the low half, so one packed
+// fma per axis yields (entry, exit) directly -- fma(b, i, l) is monotonic in b, hence
+// min(fma(min, i, l), fma(max, i, l)) IS fma(near, i, l) and likewise for the exit side: the same
+// numbers as slab32_test, 4 instead of 6 instructions per axis.
+__device__ __forceinline__ uint32_t slab32_shift(float i) { return (__float_as_uint(i) >> 31) << 4; }
+__device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t wz, const Slab32 s, uint32_t shx, uint32_t shy, uint32_t shz,
+    float tmin32, float tmax32)
+{
+  const fj_v2f px = unpack_q(__builtin_amdgcn_alignbit(wx, wx, shx));
+  const fj_v2f py = unpack_q(__builtin_amdgcn_alignbit(wy, wy, shy));
+  const fj_v2f pz = unpack_q(__builtin_amdgcn_alignbit(wz, wz, shz));
+  fj_v2f cx, cy, cz;
+  cx.x = s.x.l; cx.y = s.x.h; cy.x = s.y.l; cy.y = s.y.h; cz.x = s.z.l; cz.y = s.z.h;
+  const fj_v2f tx = __builtin_elementwise_fma(px, (fj_v2f) (s.x.i), cx);
+  const fj_v2f ty = __builtin_elementwise_fma(py, (fj_v2f) (s.y.i), cy);
+  const fj_v2f tz = __builtin_elementwise_fma(pz, (fj_v2f) (s.z.i), cz);
+  const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), tmin32);
+  const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax32);
+  return tn <= tf;
+}
 // f32 bounds of an f64 ray range: down / up to the neighbouring float
 __device__ __forceinline__ float f32_below(double x) { const float f = (float) x; return (double) f <= x ? f : nextafterf(f, -INFINITY); }
 __device__ __forceinline__ float f32_above(double x) { const float f = (float) x; return (double) f >= x ? f : nextafterf(f, INFINITY); }

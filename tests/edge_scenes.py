@@ -5,7 +5,7 @@ from fujiyama_renderer_amd.fujiyama import SceneInterface
 
 
 def custom_scene(asset_dir, res=(64, 48), spp=(2, 2), lights=3, floor_props=(), obj_shader="plastic_shader",
-                  obj_props=(), ren_props=(), textures=(), with_object=True, dome=True):
+                  obj_props=(), ren_props=(), textures=(), with_object=True, dome=True, twins=0):
     a = synth.ensure_assets(asset_dir, ("tiny",))
     si = SceneInterface(parse_args=False)
     si.OpenPlugin("plastic_shader", "PlasticShader")
@@ -40,6 +40,22 @@ def custom_scene(asset_dir, res=(64, 48), spp=(2, 2), lights=3, floor_props=(), 
         si.SetProperty1("obj1", "transform_order", 4)      # ORDER_TRS
         si.SetProperty1("obj1", "rotate_order", 7)          # ORDER_XZY
         si.AssignShader("obj1", "DEFAULT_SHADING_GROUP", "obj_shader")
+    # `twins` more instances of the object's mesh under the SAME transform, each with a colour of its own:
+    # every hit on the object is an exact tie in t between instances, so the picture shows which instance
+    # the instance level visits first (the reference: depth-first order of its BVH over the instances)
+    for k in range(twins):
+        sh = "twin_shader%d" % (k + 1)
+        si.NewShader(sh, "plastic_shader")
+        si.SetProperty3(sh, "diffuse", *[(.9, .1, .1), (.1, .9, .1), (.1, .1, .9), (.9, .9, .1)][k % 4])
+        si.SetProperty3(sh, "reflect", 0, 0, 0)
+        name = "twin%d" % (k + 1)
+        si.NewObjectInstance(name, "obj_mesh")
+        si.SetProperty3(name, "rotate", 10, 25, -5)
+        si.SetProperty3(name, "scale", .9, 1.2, .8)
+        si.SetProperty3(name, "translate", .3, .1, -.4)
+        si.SetProperty1(name, "transform_order", 4)
+        si.SetProperty1(name, "rotate_order", 7)
+        si.AssignShader(name, "DEFAULT_SHADING_GROUP", sh)
     if dome:
         si.NewObjectInstance("dome1", "dome_mesh")
         si.SetProperty3("dome1", "scale", .5, .5, .5)
@@ -77,4 +93,7 @@ EDGE_CASES = {
     "ragged_frame_and_region": dict(res=(70, 50), ren_props=(("render_region", (3, 5, 66, 47)),)),
     "no_jitter_wide_filter": dict(ren_props=(("sample_jitter", (0,)), ("filterwidth", (3, 3)), ("pixelsamples", (3, 2)))),
     "empty_hit_free_scene": dict(with_object=False, dome=False, lights=1),
+    # exact ties in t ACROSS instances: the first instance visited in the reference BVH's depth-first order keeps the hit
+    "coincident_instances_2": dict(twins=2, lights=2),
+    "coincident_instances_5": dict(twins=5, lights=2, with_object=False),
 }
