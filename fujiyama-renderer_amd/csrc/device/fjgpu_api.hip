@@ -305,15 +305,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   std::memset(&S, 0, sizeof(S));
   e |= M.upload(dps.data(), dps.size(), &S.primsets);
   {
-    std::vector<DInstance> di = hs.instances;
-    for (DInstance &I : di) {
-      const DPrimSet &P = dps[I.primset];
-      std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
-      I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
-    }
-    e |= M.upload(di.data(), di.size(), &S.instances);
-  }
-  {
     // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
     // grid = 65536^3 cells over the primitive set's padded bounds
     std::vector<std::array<double, 6>> qgrid(dps.size());
@@ -330,6 +321,18 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (M.alloc(n_nodes, &q)) { e = 1; continue; }
       if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
       P.qnodes = q;
+    }
+    {
+      // the instance table, each record with a copy of its primitive set's entry data
+      std::vector<DInstance> di = hs.instances;
+      for (DInstance &I : di) {
+        const DPrimSet &P = dps[I.primset];
+        std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
+        I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
+        I.pqnodes = P.qnodes;
+        for (int k = 0; k < 3; k++) { I.qorigin[k] = qgrid[I.primset][k]; I.qcell[k] = qgrid[I.primset][3 + k]; }
+      }
+      e |= M.upload(di.data(), di.size(), &S.instances);
     }
     // flat per-instance records of that walk (static mesh instances): node and triangle arrays
     // as 32-bit offsets from the lowest of their addresses

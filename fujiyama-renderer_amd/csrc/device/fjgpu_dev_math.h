@@ -168,7 +168,7 @@ __device__ __forceinline__ bool slab32_test(fj_v2f px, fj_v2f py, fj_v2f pz, con
 // numbers as slab32_test, 4 instead of 6 instructions per axis.
 __device__ __forceinline__ uint32_t slab32_shift(float i) { return (__float_as_uint(i) >> 31) << 4; }
 __device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t wz, const Slab32 s, uint32_t shx, uint32_t shy, uint32_t shz,
-    float tmin32, float tmax32)
+    float tmin32, float tmax32, float *tnear = nullptr)
 {
   const fj_v2f px = unpack_q(__builtin_amdgcn_alignbit(wx, wx, shx));
   const fj_v2f py = unpack_q(__builtin_amdgcn_alignbit(wy, wy, shy));
@@ -180,6 +180,7 @@ __device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t 
   const fj_v2f tz = __builtin_elementwise_fma(pz, (fj_v2f) (s.z.i), cz);
   const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), tmin32);
   const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax32);
+  if (tnear) *tnear = tn;
   return tn <= tf;
 }
 // f32 bounds of an f64 ray range: down / up to the neighbouring float

@@ -46,6 +46,9 @@ __device__ __forceinline__ uint32_t adaptive_grab(uint32_t grab, uint32_t n)
 // (DCounters.*_xcd_head, one per 128-byte line); the waves of XCD x start in region x -- their L2 then
 // holds the nodes that ONE stretch of the queue walks, not those of eight, and a head has an eighth of
 // the pullers -- and move on to the next region when theirs is empty.  Everything here is wave-uniform.
+#ifndef FJ_CLOSEST_QNODES
+#define FJ_CLOSEST_QNODES 1              // 0: the closest-hit walk reads the 128-byte f32 nodes in every instantiation
+#endif
 #ifndef FJ_XCD_HEADS
 #define FJ_XCD_HEADS 1                  // 0: one region
 #endif
@@ -252,7 +255,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         nodes = I->pnodes;
         if (I->pn_prims == 0) continue;
         if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-        s32 = slab32_setup(oo, inv, I->pbounds);
+        if (FJ_CLOSEST_QNODES && !kCurves) { nodes = (const DNode *) I->pqnodes; s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell); }
+        else s32 = slab32_setup(oo, inv, I->pbounds);
         root = I->proot;
         found = true;
         break;
@@ -269,18 +273,32 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
       if (__ballot(inner) == 0ull) break;
         if (inner) {
-        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
         if (kCount) lc->nodes++;
-        // 128-byte node: seven 16-byte loads (4 child boxes as (min, max) pairs + 4 child refs)
-        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
-        const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
         const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
         const float tmin32 = f32_below(tmin), tmax32 = f32_above(tf2);
         float t0, t1, t2, t3;
-        const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);                          // slot 0 always exists
-        const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);                          // slot 1 always exists
-        const bool h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
-        const bool h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
+        bool h0, h1, h2, h3;
+        fj_v4u e;
+        if (FJ_CLOSEST_QNODES && !kCurves) {
+          // 64-byte quantised node (DNodeQ): four 16-byte loads, sign-aware packed slab tests (slab32q_test)
+          const FJ_GLOBAL fj_v4u *nq = (const FJ_GLOBAL fj_v4u *) ((const DNodeQ *) nodes + cur);
+          const fj_v4u w0 = nq[0], w1 = nq[1], w2 = nq[2];
+          e = nq[3];
+          const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
+          h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32, &t0);
+          h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32, &t1);
+          h2 = slab32q_test(w1.z, w1.w, w2.x, s32, shx, shy, shz, tmin32, tmax32, &t2) && e.z != FJ_NO_CHILD;
+          h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32, &t3) && e.w != FJ_NO_CHILD;
+        } else {
+        const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
+        // 128-byte node: seven 16-byte loads (4 child boxes as (min, max) pairs + 4 child refs)
+        const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+        e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
+        h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);                          // slot 0 always exists
+        h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);                          // slot 1 always exists
+        h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
+        h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
+        }
         // near-to-far order is a heuristic only: f32 keys, misses sort last
         float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY;
         float k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
@@ -489,7 +507,8 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           nodes = I->pnodes;
           if (I->pn_prims == 0) continue;
           if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-          s32 = slab32_setup(oo, inv, I->pbounds);
+          if (FJ_CLOSEST_QNODES) { nodes = (const DNode *) I->pqnodes; s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell); }
+          else s32 = slab32_setup(oo, inv, I->pbounds);
           root = I->proot;
           found = true;
           break;
@@ -506,17 +525,30 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
         if (step > 0 && (step >= tune.steps || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner)) break;
         if (in_now) {
-          const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
           if (kCount) lc->nodes++;
-          const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
-          const fj_v4u e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
           const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
           const float tmin32 = f32_below(tmin), tmax32 = f32_above(tf2);
           float t0, t1, t2, t3;
-          const bool h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);
-          const bool h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);
-          const bool h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
-          const bool h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
+          bool h0, h1, h2, h3;
+          fj_v4u e;
+          if (FJ_CLOSEST_QNODES) {
+            const FJ_GLOBAL fj_v4u *nq = (const FJ_GLOBAL fj_v4u *) ((const DNodeQ *) nodes + cur);
+            const fj_v4u w0 = nq[0], w1 = nq[1], w2 = nq[2];
+            e = nq[3];
+            const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
+            h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32, &t0);
+            h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32, &t1);
+            h2 = slab32q_test(w1.z, w1.w, w2.x, s32, shx, shy, shz, tmin32, tmax32, &t2) && e.z != FJ_NO_CHILD;
+            h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32, &t3) && e.w != FJ_NO_CHILD;
+          } else {
+          const FJ_GLOBAL fj_v4f *nd = (const FJ_GLOBAL fj_v4f *) (nodes + cur);
+          const fj_v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5];
+          e = ((const FJ_GLOBAL fj_v4u *) nd)[6];
+          h0 = slab32_test(q0.xy, q0.zw, q1.xy, s32, tmin32, tmax32, &t0);
+          h1 = slab32_test(q1.zw, q2.xy, q2.zw, s32, tmin32, tmax32, &t1);
+          h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
+          h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
+          }
           // near-to-far order is a heuristic only: f32 keys, misses sort last
           float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY;
           float k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;

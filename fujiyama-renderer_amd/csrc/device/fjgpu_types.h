@@ -105,6 +105,8 @@ struct DInstance {
   uint32_t proot;              // filled at upload): entering an instance costs ONE dependent load after the
   double pbounds[6];           // instance-level node instead of instance -> primitive set
   const DNode *pnodes;
+  const DNodeQ *pqnodes;       // meshes: the quantised twin of the node array and its grid (plane = qorigin + q * qcell):
+  double qorigin[3], qcell[3]; // the closest-hit walk of scenes without curve sets reads these 64-byte nodes too
 };
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
