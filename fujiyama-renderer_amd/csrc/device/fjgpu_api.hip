@@ -98,6 +98,10 @@ struct fjgpu_scene {
   std::vector<hipEvent_t> ev_pool; // per-launch timing events (resolved at the end of the frame: no host sync per launch)
   DShadowRay *d_squeue;
   size_t squeue_cap;
+  uint32_t *d_join = nullptr; size_t join_cap = 0;   // DScene.shadow_join (work arena)
+  bool split_overflowed = false;   // the last render call overflowed a queue while rays were split
+  uint32_t split_kfac = 1;         // queue entries the host allows per (light record, light) pair when rays are split
+  bool split_shadow = false;       // the lean any-hit walk serves shadow groups of several instances: rays are queued per candidate instance
   DCounters *d_cnt;
   TileDesc *d_tiles;
   double *d_jit, *d_tim;
@@ -167,6 +171,9 @@ static long g_ray_sort = -1;       // "ray_sort": grid bits per axis of the ray-
 static long g_ray_sort_min = FJ_RAY_SORT_MIN;   // "ray_sort_min": smaller launches keep queue order
 static long g_device_tlas = 1;     // "device_tlas": the instance level of every group is built on the device (fjgpu_tlas.hip)
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
+static long g_split_shadow = 0;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
+                                   // (off by default: C2's any-hit walk 91 -> 56 ms, but the light loop that must now list EVERY candidate
+                                   // instead of stopping at the first 18 -> 52 ms: 134 ms per frame either way)
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
@@ -178,6 +185,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "ray_sort_min") { g_ray_sort_min = value < 1 ? 1 : value; return 0; }
   if (std::string(name) == "device_tlas") { g_device_tlas = value != 0; return 0; }
   if (std::string(name) == "tlas_verify") { g_tlas_verify = value != 0; return 0; }
+  if (std::string(name) == "split_shadow") { g_split_shadow = value != 0; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -486,6 +494,16 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
   S.pad_inc_ = 0;
   S.ray_perm = nullptr;
+  S.shadow_join = nullptr;
+  sc->split_shadow = S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base && g_split_shadow;
+  if (const char *e = getenv("FJGPU_SPLIT_SHADOW"))
+    sc->split_shadow = atoi(e) != 0 && S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base;
+  {
+    int kmax = 1;
+    for (const auto &g : hs.groups) kmax = std::max(kmax, g.n_instances);
+    sc->split_kfac = (uint32_t) std::min(kmax, 4);     // (more candidates than that per ray on average: overflow -> fallback)
+    if (const char *e = getenv("FJGPU_SPLIT_KFAC")) sc->split_kfac = (uint32_t) std::max(1, atoi(e));
+  }
   for (int k = 0; k < 3; k++) { sc->scene_box[k] = DBL_MAX; sc->scene_box[3 + k] = -DBL_MAX; }
   for (const auto &I : hs.instances)
     for (int k = 0; k < 3; k++) { sc->scene_box[k] = std::min(sc->scene_box[k], I.wbounds[k]); sc->scene_box[3 + k] = std::max(sc->scene_box[3 + k], I.wbounds[3 + k]); }
@@ -608,6 +626,10 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     }
     sc->squeue_cap = std::min<size_t>(rays * 8, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
+    // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
+    // owns at least two queue entries
+    sc->d_join = nullptr; sc->join_cap = 0;
+    if (sc->split_shadow) { sc->join_cap = sc->squeue_cap / 2 + 1; e |= W.alloc(sc->join_cap, &sc->d_join); }
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
     if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }
@@ -667,10 +689,28 @@ int ensure_sort(fjgpu_scene *sc, size_t cap)
 
 extern "C" {
 
+static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *tile_ids, int n_tiles,
+    float *d_fb, void *hip_stream, fjgpu_stats *stats);
+
 int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *tile_ids, int n_tiles,
     float *d_fb, void *hip_stream, fjgpu_stats *stats)
 {
   if (!sc || !r || !d_fb) return fail(FJGPU_EINVAL, "null argument");
+  sc->split_overflowed = false;
+  int e = render_tiles_once(sc, r, tile_ids, n_tiles, d_fb, hip_stream, stats);
+  if (e == FJGPU_ENOMEM && sc->split_overflowed) {
+    // rays queued once per candidate instance outgrew the host's bound on the shadow queue (a scene whose
+    // instance boxes overlap many times over): this scene goes back to whole rays and the tiles are rendered again
+    if (getenv("FJGPU_VERBOSE")) fprintf(stderr, "fjgpu: shadow queue overflow with split rays: rendering again without the split\n");
+    sc->split_shadow = false;
+    e = render_tiles_once(sc, r, tile_ids, n_tiles, d_fb, hip_stream, stats);
+  }
+  return e;
+}
+
+static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *tile_ids, int n_tiles,
+    float *d_fb, void *hip_stream, fjgpu_stats *stats)
+{
   const bool adaptive = r->sampler_type == 1;          // Renderer::SetSamplerType, src/fj_renderer.cc:487-499
   if (r->sampler_type != 0 && !adaptive) return fail(FJGPU_EINVAL, "unknown sampler_type");
   if (adaptive && (r->adaptive_max_subdivision < 0 || r->adaptive_max_subdivision > 8 || !(r->adaptive_subdivision_threshold >= 0)))
@@ -784,6 +824,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   swp.pre_resolve = (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) ? 1 : 0;   // the lean any-hit walk consumes the queue
   swp.cast_shadow = r->cast_shadow;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
+  swp.join_capacity = (swp.pre_resolve && sc->split_shadow && sc->d_join) ? (uint32_t) sc->join_cap : 0u;
+  S.shadow_join = swp.join_capacity ? sc->d_join : nullptr;
+  S.shadow_queue_cap = (uint32_t) sc->squeue_cap;
   ResolveParams rp;
   rp.xres = r->xres; rp.yres = r->yres; rp.rate_x = r->rate_x; rp.rate_y = r->rate_y;
   rp.npx_x = r->rate_x + 2 * margin[0]; rp.npx_y = r->rate_y + 2 * margin[1];
@@ -884,7 +927,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     // shadow-ray queue of this batch: the light loops of every level append, one traversal
     // launch consumes it (flush) at the end of the batch or when it could overflow
     const uint64_t sq_cap = sc->squeue_cap, sq_pad = shadow_queue_padding();
-    const uint64_t nl_q = (uint64_t) std::max(1, sc->n_light_samples);
+    const uint64_t nl_q = (uint64_t) std::max(1, sc->n_light_samples) * (S.shadow_join ? sc->split_kfac : 1u);
     uint64_t sq_bound = 0;             // upper bound of the entries reserved so far
     bool sq_dirty = false;
     shadow_queue_reset(sst, sc->d_cnt);
@@ -942,7 +985,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
         if (e) return e;
         DCounters hc;
         if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-        if (hc.overflow) return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option");
+        if (hc.overflow) { sc->split_overflowed = S.shadow_join != nullptr; return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); }
         if (hc.light_count) {
           // shading has completed (the host just synchronised with it): no event needed.
           // The queue holds hc.shadow_count entries so far (exact when the shadow work runs on
@@ -1044,7 +1087,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     if (rc) break;
     DCounters hc;
     if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1; break; }
-    if (hc.overflow) { rc = fail(FJGPU_ENOMEM, "wavefront queue overflow: lower the batch_tiles option"); break; }
+    if (hc.overflow) { sc->split_overflowed = S.shadow_join != nullptr; rc = fail(FJGPU_ENOMEM, "wavefront queue overflow: lower the batch_tiles option"); break; }
     acc.rays.shadow += hc.rays[CXT_SHADOW_RAY];
     acc.rays.diffuse += hc.rays[CXT_DIFFUSE_RAY];
     acc.rays.reflect += hc.rays[CXT_REFLECT_RAY];

@@ -162,11 +162,20 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           else {
             // reached the light: add c (an opaque occluder would have added c * (1 - Os) = 0)
             const DShadowRay *q = &squeue[idx];
-            float *acc = s_accum + 4 * (size_t) q->sample;
-            const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
-            if (r0 != 0.f) atomicAdd(acc + 0, r0);
-            if (r1 != 0.f) atomicAdd(acc + 1, r1);
-            if (r2 != 0.f) atomicAdd(acc + 2, r2);
+            // one of k entries of a ray with k candidate instances: the light is added by the entry that completes
+            // the count of those that reached it (DScene.shadow_join)
+            bool add = true;
+            if (!kMulti && S.shadow_join) {
+              const uint32_t slot1 = q->tindex;
+              if (slot1) { const uint32_t old = atomicAdd(&S.shadow_join[slot1 - 1u], 1u); add = ((old & 0xffffu) + 1u) == (old >> 16); }
+            }
+            if (add) {
+              float *acc = s_accum + 4 * (size_t) q->sample;
+              const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
+              if (r0 != 0.f) atomicAdd(acc + 0, r0);
+              if (r1 != 0.f) atomicAdd(acc + 1, r1);
+              if (r2 != 0.f) atomicAdd(acc + 2, r2);
+            }
             have = false;
           }
         }
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYH
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
-  const uint32_t n = cnt->shadow_count;
+  const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
   traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
   if (kCount) {

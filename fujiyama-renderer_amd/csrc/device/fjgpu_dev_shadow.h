@@ -25,8 +25,11 @@
 #ifndef FJ_CULL_MINB
 #define FJ_CULL_MINB 1
 #endif
-template <bool kHair, bool kArea>
-__global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
+#ifndef FJ_CULL_MINB_PLAIN
+#define FJ_CULL_MINB_PLAIN 3      // point lights, no hair: 166 VGPRs as written; the split instantiation is held to the same 3 waves
+#endif
+template <bool kHair, bool kArea, bool kSplit>
+__global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CULL_MINB_PLAIN) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   unsigned long long c_insts = 0, c_shadow = 0;
@@ -99,6 +102,15 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
     for (uint32_t l = 0; l < nl; l++) {
       bool emit = false;
       DShadowRay q;
+      // split mode (DScene.shadow_join): a ray into a group of several instances is queued once per instance
+      // whose box it passes; the lane enumerates them over the rounds below
+      bool pending = false;
+      int tcur = 0;
+      uint32_t ncand = 0, first_slot = 0xffffffffu, jslot1 = 0;
+      V3 winv_s = mk(0, 0, 0), Ln_s = winv_s;
+      bool plain_s = false;
+      double dist_s = 0;
+      float k_s[3] = {0.f, 0.f, 0.f};
       if (active) {
         const DLightSample LS = S.light_samples[l];
         V3 Pl = mk(LS.P[0], LS.P[1], LS.P[2]);
@@ -186,7 +198,11 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
                 maybe_occluded = box_ray_ref_fast(sb, Ps, Ln, winv, plain, .0001, distance);
                 if (!maybe_occluded) c_insts++;
               }
-              for (int ti = g_first; !g_single && ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
+              if (kSplit && !g_single && sp.join_capacity) {
+                pending = true; tcur = g_first; winv_s = winv; plain_s = plain; Ln_s = Ln; dist_s = distance;
+                k_s[0] = k[0]; k_s[1] = k[1]; k_s[2] = k[2];
+              }
+              for (int ti = g_first; !g_single && !pending && ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
                 const DTNode *tn_ = &S.group_nodes[ti];
                 if (tn_->inst < 0) {
                   double tq;
@@ -206,10 +222,54 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
             q.tmax = distance;
             q.c[0] = W[0] * k[0]; q.c[1] = W[1] * k[1]; q.c[2] = W[2] * k[2];
             // (lean any-hit walk: a single-instance group's only candidate is settled here)
-            q.sample = r_sample; q.group = (sp.pre_resolve && g_single) ? ~g_inst : R.group; q.tindex = R.uid & 0xfffffu;
-          } else {
+            // (tindex: the sample's slot in the time table for the general walk; in split mode the join slot, 0 = none)
+            q.sample = r_sample; q.group = (sp.pre_resolve && g_single) ? ~g_inst : R.group; q.tindex = (kSplit && sp.join_capacity) ? 0u : (R.uid & 0xfffffu);
+          } else if (!kSplit || !pending) {
             sum[0] += k[0]; sum[1] += k[1]; sum[2] += k[2];
           }
+        }
+      }
+      for (;;) {
+      // ---- split mode: the lane's next candidate instance, if any
+      bool need_slot = false;
+      if (kSplit && pending) {
+        int cand = -1;
+        while (tcur < g_first + g_count) {                   // threaded instance BVH (DTNode), resumed where it stopped
+          const DTNode *tn_ = &S.group_nodes[tcur];
+          if (tn_->inst < 0) {
+            double tq;
+            tcur = slab(tn_->box, tn_->box + 3, Ps, winv_s, .0001, dist_s, &tq) ? tcur + 1 : tn_->skip;
+            continue;
+          }
+          tcur++;
+          if (box_ray_ref_fast(tn_->box, Ps, Ln_s, winv_s, plain_s, .0001, dist_s)) { cand = tn_->inst; break; }
+          c_insts++;
+        }
+        if (cand >= 0) {
+          ncand++;
+          emit = true;
+          q.o[0] = Ps.x; q.o[1] = Ps.y; q.o[2] = Ps.z;
+          q.d[0] = Ln_s.x; q.d[1] = Ln_s.y; q.d[2] = Ln_s.z;
+          q.tmax = dist_s;
+          q.c[0] = W[0] * k_s[0]; q.c[1] = W[1] * k_s[1]; q.c[2] = W[2] * k_s[2];
+          q.sample = r_sample; q.group = ~cand; q.tindex = jslot1;
+          need_slot = ncand == 2;
+        } else {
+          pending = false;
+          if (ncand == 0) { sum[0] += k_s[0]; sum[1] += k_s[1]; sum[2] += k_s[2]; }     // no instance box in the way
+        }
+      }
+      // a second candidate: the ray gets a join slot (one atomic per wave), its first entry is told
+      const unsigned long long m_slot = kSplit ? __ballot(need_slot) : 0ull;
+      if (kSplit && m_slot) {
+        uint32_t base = 0;
+        if (lane == (unsigned) __ffsll((long long) m_slot) - 1u) base = atomicAdd(&cnt->join_count, (uint32_t) __popcll(m_slot));
+        base = __shfl(base, __ffsll((long long) m_slot) - 1);
+        if (need_slot) {
+          jslot1 = base + (uint32_t) __popcll(m_slot & ((1ull << lane) - 1ull)) + 1u;
+          if (jslot1 > sp.join_capacity) { cnt->overflow = 1; jslot1 = 1; }
+          q.tindex = jslot1;
+          if (first_slot < sp.queue_capacity) squeue[first_slot].tindex = jslot1;
         }
       }
       // ---- compaction into the wave's current chunk (ballot + prefix popcount)
@@ -230,9 +290,14 @@ __global__ void __launch_bounds__(BLOCK, FJ_CULL_MINB) k_shadow_cull(DScene S, S
           const uint32_t slot = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
           if (slot < sp.queue_capacity) squeue[slot] = q;
           else cnt->overflow = 1;
+          if (kSplit && ncand == 1) first_slot = slot;
         }
         chunk_used += need;
       }
+      emit = false;
+      if (!kSplit || __ballot(pending) == 0ull) break;
+      }
+      if (kSplit && ncand >= 2) S.shadow_join[jslot1 - 1u] = ncand << 16;
     }
     if (active) {
       float *acc = s_accum + 4 * (size_t) r_sample;

@@ -39,6 +39,7 @@ struct ShadowParams {
   double cos_half_pi, cos_pi;  // cos(PI/2.), cos(PI) evaluated by the host libm
   uint32_t pre_resolve;        // 1: queue entries of single-instance groups carry ~instance (lean any-hit walk)
   uint32_t queue_capacity;     // entries of the shadow-ray queue
+  uint32_t join_capacity;      // slots of DScene.shadow_join (0: shadow rays into groups of several instances stay whole)
   int32_t cast_shadow;
 };
 

@@ -247,7 +247,7 @@ uint32_t shadow_queue_padding()          // every resident wave may leave one pa
 
 void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 {
-  (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
+  (void) hipMemsetAsync(&cnt->shadow_count, 0, 3 * sizeof(uint32_t), st);   // shadow_count + shadow_head + join_count
   (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head), st);
 }
 
@@ -257,10 +257,12 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
   if (e <= b) return 0;
   const unsigned long long threads = (unsigned long long) (e - b);       // one light record per lane
   (void) hipMemsetAsync(&cnt->cull_head, 0, sizeof(uint32_t), st);
-#define FJ_LAUNCH_CULL(HAIR, AREA) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
-  if (S.has_area) FJ_LAUNCH_CULL(true, true);          // general instantiation
-  else if (S.has_hair) FJ_LAUNCH_CULL(true, false);
-  else FJ_LAUNCH_CULL(false, false);
+#define FJ_LAUNCH_CULL(HAIR, AREA, SPLIT) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA, SPLIT>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
+  // (SPLIT: rays into groups of several instances are queued once per candidate instance, DScene.shadow_join)
+  const bool split = sp.join_capacity != 0 && S.shadow_join != nullptr;
+  if (S.has_area) { if (split) FJ_LAUNCH_CULL(true, true, true); else FJ_LAUNCH_CULL(true, true, false); }          // general instantiation
+  else if (S.has_hair) FJ_LAUNCH_CULL(true, false, false);
+  else { if (split) FJ_LAUNCH_CULL(false, false, true); else FJ_LAUNCH_CULL(false, false, false); }
 #undef FJ_LAUNCH_CULL
   LAUNCH_CHECK();
   return 0;
@@ -270,7 +272,8 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 {
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
 #define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
-    if (S.multi_shadow_groups) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
+    // (with DScene.shadow_join every queue entry names its instance: the instantiation without the instance-level walk)
+    if (S.multi_shadow_groups && !S.shadow_join) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
     else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
 #undef FJ_LAUNCH_ANYHIT
   } else {

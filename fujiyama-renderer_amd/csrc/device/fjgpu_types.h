@@ -183,6 +183,13 @@ struct DScene {
   const DTexture *textures;
   const DLightSample *light_samples;
   DLightHair *lrec_hair;       // work buffer (set per render call) or null
+  uint32_t shadow_queue_cap;   // entries of the shadow-ray queue (a walk never reads past it, whatever the slot counter says)
+  uint32_t pad_sq_;
+  uint32_t *shadow_join;       // work buffer or null.  Lean any-hit walk with shadow groups of several instances: a ray
+                               // whose world-space test passes k >= 2 instance boxes is queued k times, once per
+                               // instance, and all k entries name one slot here (DShadowRay.tindex = slot + 1; 0 = a
+                               // single entry): (k << 16) | number of entries that reached the light so far.  The
+                               // entry that completes the count adds the light; an occluded entry adds nothing.
   const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
   const DAnyInst *any_insts;       // [n_instances] (static mesh instances; the lean any-hit walk)
   const char *blas_base;           // lowest address of any BLAS node / triangle array (DAnyInst offsets); null: the
@@ -279,7 +286,8 @@ struct DCounters {
   uint32_t pad1_[28];
   uint32_t shadow_count;       // slots reserved in the shadow-ray queue                      (line 2)
   uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
-  uint32_t pad2_[30];
+  uint32_t join_count;         // join slots handed out to shadow rays with several candidate instances (DScene.shadow_join)
+  uint32_t pad2_[29];
   uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (line 3)
   uint32_t cull_head;          // light loop: next unclaimed light record of the current launch
   uint32_t pad3_[30];

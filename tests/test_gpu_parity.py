@@ -388,6 +388,28 @@ def test_device_tlas_equals_host_tlas_node_for_node(asset_dir):
         gpu.global_option("device_tlas", 1)
 
 
+def test_shadow_rays_split_per_candidate_instance(asset_dir):
+    """shadow groups of several instances, lean any-hit walk: a ray whose world-space test passes k instance
+    boxes is queued k times (one entry per instance, one join slot), and the entry that completes the count
+    of unoccluded ones adds the light (option split_shadow); off (the default), the walk steps through the
+    group's instance level itself.  Either way: the oracle's ray counts and pixels."""
+    for text in (workloads.crowd(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", n=40),
+                 workloads.buddhas(asset_dir, res=(96, 54), spp=(2, 2), mesh="tiny")):
+        frames = []
+        for split in (1, 0):
+            gpu.global_option("split_shadow", split)
+            try:
+                fb, st, ref, rc = render_both(text)
+            finally:
+                gpu.global_option("split_shadow", 0)
+            assert st.rays.as_dict() == rc.as_dict()
+            assert float(rel_err(fb, ref).max()) <= REL_TOL
+            frames.append((fb, st))
+        # more queue entries than rays that survived the cull when rays were split
+        assert frames[0][1].shadow_traversed >= frames[1][1].shadow_traversed
+        assert float(rel_err(frames[0][0], frames[1][0]).max()) <= 1e-5
+
+
 def test_unsupported_features_fail_loudly(asset_dir):
     """features outside the device path: explicit error naming the feature, never a silent
     approximation or a CPU fallback"""
