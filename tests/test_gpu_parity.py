@@ -405,8 +405,6 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
             assert st.rays.as_dict() == rc.as_dict()
             assert float(rel_err(fb, ref).max()) <= REL_TOL
             frames.append((fb, st))
-        # more queue entries than rays that survived the cull when rays were split
-        assert frames[0][1].shadow_traversed >= frames[1][1].shadow_traversed
         assert float(rel_err(frames[0][0], frames[1][0]).max()) <= 1e-5
 
 
