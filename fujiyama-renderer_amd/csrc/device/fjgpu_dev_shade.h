@@ -273,7 +273,7 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
 // so `Cs = local + sum_k w_k * C_child_k` unrolls into per-path products
 // (DESIGN.md 6).
 #ifndef FJ_SHADE_MINB
-#define FJ_SHADE_MINB 1           // resident blocks per CU the register budget is cut for
+#define FJ_SHADE_MINB 3           // resident blocks per CU the register budget is cut for (169 VGPRs as written = 2 waves; 164 = 3: C3 15.8 -> 14.8 ms, C4 269 -> 258)
 #endif
 template <bool kMotion>
 __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,

@@ -633,7 +633,7 @@ struct ClosestPolicy {
 #define FJ_CLOSEST_MINB 3
 #endif
 #ifndef FJ_SHADOW_MINB
-#define FJ_SHADOW_MINB 1
+#define FJ_SHADOW_MINB 3          // the general shadow walk of mesh scenes (translucent occluders): 166 VGPRs, 3 waves
 #endif
 template <bool kCurves, bool kCount, bool kMotion>
 __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? FJ_CURVE_MINB : FJ_CLOSEST_MINB)) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
