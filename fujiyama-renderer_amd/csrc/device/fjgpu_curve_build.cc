@@ -70,8 +70,8 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   // splits; a piece's box is the hull of ITS control points + the ribbon radius; every piece
   // refers to the same curve, whose full test runs once per ray (the traversal remembers the
   // curve it tested last), so the result is the reference's whichever piece was entered.
-  int seg_depth = 3;      // (with per-piece radii: C5 3.06 s at 2, 2.63 s at 3, 2.58 s at 4 -- and twice the BLAS slots each step)
-  if (const char *e = getenv("FJGPU_CURVE_SEGDEPTH")) seg_depth = std::max(0, std::min(4, atoi(e)));
+  int seg_depth = 4;      // (with per-piece radii: C5 3.06 s at 2, 2.63 s at 3, 2.58 s at 4; at 3 waves per SIMD 2.56 / 2.14 / 2.06 / 2.14 s at 2 / 3 / 4 / 5 -- and twice the BLAS slots each step)
+  if (const char *e = getenv("FJGPU_CURVE_SEGDEPTH")) seg_depth = std::max(0, std::min(5, atoi(e)));
   const int S = 1 << seg_depth;
   std::vector<PrimRef> refs((size_t) c.n_curves * S);
   for (int i = 0; i < c.n_curves; i++) {

@@ -333,7 +333,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           last_curve = cid;
           if (kCount) lc->prims++;
           const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
-          deep = curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace, oo, od});
+          // (FJ_CURVE_FIRST_STAGE 0: a slot that passes its capsule goes to the second stage at once; that stage starts with the same test)
+          deep = !FJ_CURVE_FIRST_STAGE ? true :
+                 curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace, oo, od});
           // the second stage is deferred: the lane remembers the curve and walks on (its result
           // only shortens the ray or ends it -- the walk stays correct without it); a lane that
           // already carries a deferred curve waits here instead
