@@ -26,7 +26,7 @@
 // debug builds only: wave-level phase executions / tail lengths (printed by debug_phase_stats)
 __device__ unsigned long long g_phase[16];
 #endif
-struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
@@ -525,7 +525,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       // ---- inner nodes; further steps without a new vote while enough lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
-        if (step > 0 && (step >= tune.steps || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner)) break;
+        if (step > 0 && (step >= tune.steps_phased || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner_phased)) break;
         if (in_now) {
           if (kCount) lc->nodes++;
           const double tf2 = anyhit ? tmax : fmin(tmax, best.t);

@@ -165,7 +165,7 @@ static int anyhit_blocks_per_cu(bool multi)
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -178,6 +178,10 @@ static TravTune trav_tune()
     // keeps the fixed 3: incoherent rays (C4) and curve leaves (C5) lost 2-7 % with it)
     t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 4);
     t.min_inner = env("FJGPU_TRAV_MININNER", 24);
+    // the phase-scheduled closest-hit walk (incoherent rays): C4 closest-hit side 758 / 748 ms at 3 / 5 steps, 766 / 758 / 739 at
+    // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
+    t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
+    t.min_inner_phased = env("FJGPU_TRAV_MININNER_PHASED", 12);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
