@@ -171,9 +171,8 @@ static long g_ray_sort = -1;       // "ray_sort": grid bits per axis of the ray-
 static long g_ray_sort_min = FJ_RAY_SORT_MIN;   // "ray_sort_min": smaller launches keep queue order
 static long g_device_tlas = 1;     // "device_tlas": the instance level of every group is built on the device (fjgpu_tlas.hip)
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
-static long g_split_shadow = 0;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
-                                   // (off by default: C2's any-hit walk 91 -> 56 ms, but the light loop that must now list EVERY candidate
-                                   // instead of stopping at the first 18 -> 52 ms: 134 ms per frame either way)
+static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
+                                   // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
@@ -501,7 +500,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   {
     int kmax = 1;
     for (const auto &g : hs.groups) kmax = std::max(kmax, g.n_instances);
-    sc->split_kfac = (uint32_t) std::min(kmax, 4);     // (more candidates than that per ray on average: overflow -> fallback)
+    sc->split_kfac = (uint32_t) std::min(kmax, 2);     // (more entries than that per (record, light) pair on average: overflow -> fallback;
+                                                       //  C2 has 0.84; light-loop time at a bound of 2 / 3 / 4: 41 / 43 / 45 ms)
     if (const char *e = getenv("FJGPU_SPLIT_KFAC")) sc->split_kfac = (uint32_t) std::max(1, atoi(e));
   }
   for (int k = 0; k < 3; k++) { sc->scene_box[k] = DBL_MAX; sc->scene_box[3 + k] = -DBL_MAX; }
@@ -624,7 +624,8 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
       sc->d_lhair[k] = nullptr;
       if (sc->S.has_hair) e |= W.alloc(rays, &sc->d_lhair[k]);
     }
-    sc->squeue_cap = std::min<size_t>(rays * 8, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
+    // (rays queued once per candidate instance: room for twice the entries, or the light loop runs in many short launches)
+    sc->squeue_cap = std::min<size_t>(rays * (sc->split_shadow ? 16 : 8), sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
     // owns at least two queue entries

@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
       // whose box it passes; the lane enumerates them over the rounds below
       bool pending = false;
       int tcur = 0;
-      uint32_t ncand = 0, first_slot = 0xffffffffu, jslot1 = 0;
+      uint32_t ncand = 0, jslot1 = 0, nb = 0, be = 0;
+      int cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
       V3 winv_s = mk(0, 0, 0), Ln_s = winv_s;
       bool plain_s = false;
       double dist_s = 0;
@@ -230,11 +231,12 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
         }
       }
       for (;;) {
-      // ---- split mode: the lane's next candidate instance, if any
+      // ---- split mode: candidates are collected four at a time in ONE pass over the group's instance level (every
+      // lane walks the whole level, so the walk is uniform across the wave), then queued one per round
       bool need_slot = false;
-      if (kSplit && pending) {
-        int cand = -1;
-        while (tcur < g_first + g_count) {                   // threaded instance BVH (DTNode), resumed where it stopped
+      if (kSplit && pending && be == nb) {
+        nb = 0; be = 0;
+        while (tcur < g_first + g_count && nb < 4u) {        // threaded instance BVH (DTNode), resumed where it stopped
           const DTNode *tn_ = &S.group_nodes[tcur];
           if (tn_->inst < 0) {
             double tq;
@@ -242,24 +244,20 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
             continue;
           }
           tcur++;
-          if (box_ray_ref_fast(tn_->box, Ps, Ln_s, winv_s, plain_s, .0001, dist_s)) { cand = tn_->inst; break; }
-          c_insts++;
+          if (box_ray_ref_fast(tn_->box, Ps, Ln_s, winv_s, plain_s, .0001, dist_s)) {
+            if (nb == 0u) cb0 = tn_->inst; else if (nb == 1u) cb1 = tn_->inst; else if (nb == 2u) cb2 = tn_->inst; else cb3 = tn_->inst;
+            nb++;
+          } else c_insts++;
         }
-        if (cand >= 0) {
-          ncand++;
-          emit = true;
-          q.o[0] = Ps.x; q.o[1] = Ps.y; q.o[2] = Ps.z;
-          q.d[0] = Ln_s.x; q.d[1] = Ln_s.y; q.d[2] = Ln_s.z;
-          q.tmax = dist_s;
-          q.c[0] = W[0] * k_s[0]; q.c[1] = W[1] * k_s[1]; q.c[2] = W[2] * k_s[2];
-          q.sample = r_sample; q.group = ~cand; q.tindex = jslot1;
-          need_slot = ncand == 2;
-        } else {
+        if (nb == 0u) {
           pending = false;
-          if (ncand == 0) { sum[0] += k_s[0]; sum[1] += k_s[1]; sum[2] += k_s[2]; }     // no instance box in the way
+          if (ncand == 0u) { sum[0] += k_s[0]; sum[1] += k_s[1]; sum[2] += k_s[2]; }     // no instance box in the way
+        } else {
+          need_slot = jslot1 == 0u && ncand + nb >= 2u;
+          ncand += nb;
         }
       }
-      // a second candidate: the ray gets a join slot (one atomic per wave), its first entry is told
+      // a second candidate: the ray gets a join slot (one atomic per wave) before any of its entries is written
       const unsigned long long m_slot = kSplit ? __ballot(need_slot) : 0ull;
       if (kSplit && m_slot) {
         uint32_t base = 0;
@@ -268,9 +266,18 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
         if (need_slot) {
           jslot1 = base + (uint32_t) __popcll(m_slot & ((1ull << lane) - 1ull)) + 1u;
           if (jslot1 > sp.join_capacity) { cnt->overflow = 1; jslot1 = 1; }
-          q.tindex = jslot1;
-          if (first_slot < sp.queue_capacity) squeue[first_slot].tindex = jslot1;
         }
+      }
+      if (kSplit && pending && be < nb) {
+        const int cand = be == 0u ? cb0 : (be == 1u ? cb1 : (be == 2u ? cb2 : cb3));
+        be++;
+        emit = true;
+        q.o[0] = Ps.x; q.o[1] = Ps.y; q.o[2] = Ps.z;
+        q.d[0] = Ln_s.x; q.d[1] = Ln_s.y; q.d[2] = Ln_s.z;
+        q.tmax = dist_s;
+        q.c[0] = W[0] * k_s[0]; q.c[1] = W[1] * k_s[1]; q.c[2] = W[2] * k_s[2];
+        q.sample = r_sample; q.group = ~cand; q.tindex = jslot1;
+        if (be == nb && tcur >= g_first + g_count) pending = false;
       }
       // ---- compaction into the wave's current chunk (ballot + prefix popcount)
       const unsigned long long mask = __ballot(emit);
@@ -290,7 +297,6 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
           const uint32_t slot = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
           if (slot < sp.queue_capacity) squeue[slot] = q;
           else cnt->overflow = 1;
-          if (kSplit && ncand == 1) first_slot = slot;
         }
         chunk_used += need;
       }

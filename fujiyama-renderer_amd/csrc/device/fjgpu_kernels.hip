@@ -251,7 +251,8 @@ uint32_t shadow_queue_padding()          // every resident wave may leave one pa
 
 void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 {
-  (void) hipMemsetAsync(&cnt->shadow_count, 0, 3 * sizeof(uint32_t), st);   // shadow_count + shadow_head + join_count
+  (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
+  (void) hipMemsetAsync(&cnt->join_count, 0, sizeof(uint32_t), st);
   (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head), st);
 }
 

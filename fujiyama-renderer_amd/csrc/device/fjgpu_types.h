@@ -286,8 +286,7 @@ struct DCounters {
   uint32_t pad1_[28];
   uint32_t shadow_count;       // slots reserved in the shadow-ray queue                      (line 2)
   uint32_t shadow_head;        // persistent shadow traversal: next unclaimed queue index (shadow stream)
-  uint32_t join_count;         // join slots handed out to shadow rays with several candidate instances (DScene.shadow_join)
-  uint32_t pad2_[29];
+  uint32_t pad2_[30];
   uint32_t trace_head;         // persistent closest-hit traversal: next unclaimed queue index (line 3)
   uint32_t cull_head;          // light loop: next unclaimed light record of the current launch
   uint32_t pad3_[30];
@@ -296,6 +295,8 @@ struct DCounters {
   // move on to the next region when theirs is empty; one head per 128-byte line
   uint32_t shadow_xcd_head[8][32];
   uint32_t trace_xcd_head[8][32];     // the same for the closest-hit walk
+  uint32_t join_count;         // join slots handed out to shadow rays with several candidate instances (DScene.shadow_join);
+  uint32_t pad4_[31];          // on a line of its own: one atomic per wave and light
 };
 
 #endif

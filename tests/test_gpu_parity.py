@@ -391,7 +391,7 @@ def test_device_tlas_equals_host_tlas_node_for_node(asset_dir):
 def test_shadow_rays_split_per_candidate_instance(asset_dir):
     """shadow groups of several instances, lean any-hit walk: a ray whose world-space test passes k instance
     boxes is queued k times (one entry per instance, one join slot), and the entry that completes the count
-    of unoccluded ones adds the light (option split_shadow); off (the default), the walk steps through the
+    of unoccluded ones adds the light (option split_shadow, the default); off, the walk steps through the
     group's instance level itself.  Either way: the oracle's ray counts and pixels."""
     for text in (workloads.crowd(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", n=40),
                  workloads.buddhas(asset_dir, res=(96, 54), spp=(2, 2), mesh="tiny")):
@@ -401,7 +401,7 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
             try:
                 fb, st, ref, rc = render_both(text)
             finally:
-                gpu.global_option("split_shadow", 0)
+                gpu.global_option("split_shadow", 1)
             assert st.rays.as_dict() == rc.as_dict()
             assert float(rel_err(fb, ref).max()) <= REL_TOL
             frames.append((fb, st))
