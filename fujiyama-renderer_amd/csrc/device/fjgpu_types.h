@@ -48,7 +48,9 @@ static_assert(sizeof(DNodeQ) == 64, "DNodeQ must be 64 bytes");
 #ifndef FJ_STACK_LDS_ANYHIT
 #define FJ_STACK_LDS_ANYHIT 24
 #endif
+#ifndef FJ_STACK_LDS_MIN
 #define FJ_STACK_LDS_MIN 24          // smallest of the three (sizes the global overflow area)
+#endif
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
 struct DPrimSet {
