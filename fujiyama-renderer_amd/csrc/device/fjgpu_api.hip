@@ -764,13 +764,18 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   long bt = sc->batch_tiles;
   if (bt <= 0) {
     const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
-    const size_t target = std::min<size_t>((size_t) 160 << 20, (size_t) (.4 * (double) free_now) / per_sample);
+    // (a scene without lights queues no shadow rays: the fifth of the HBM that queue may take goes to the ray queues --
+    // C4, nine recursion levels: 1010 -> 994 ms per frame.  Walking a whole level in one launch with per-level hit
+    // buffers and chunking only the shading was measured too: 130 -> ~50 closest-hit launches per frame, 1005 ms: dropped)
+    const double share = sc->n_light_samples == 0 ? .6 : .4;
+    const size_t target = std::min<size_t>((size_t) 160 << 20, (size_t) (share * (double) free_now) / per_sample);
     bt = std::max<long>(1, (long) (target / full_tile_samples));
   }
   bt = std::min<long>(bt, (long) ids.size());
   bt = std::min<long>(bt, (long) (((size_t) 1 << 31) / full_tile_samples));   // sample slots are 32-bit
   if (bt < 1) bt = 1;
   sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
+  if (sc->n_light_samples == 0) sc->squeue_max = (size_t) 4 << 20;
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
   size_t cap_samples = 0, cap_rays = 0;
   for (;;) {
