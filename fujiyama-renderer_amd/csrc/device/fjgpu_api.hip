@@ -570,6 +570,24 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   delete scene;
 }
 
+int fjgpu_host_instance_level(const fj_scene_desc *desc, int group, int32_t *out_inst, int32_t *out_skip, double *out_box, int cap)
+{
+  if (!desc || group < 0 || group >= desc->n_groups) return fail(FJGPU_EINVAL, "bad instance-level query");
+  fjgpu::HostScene hs;
+  std::string err;
+  // (meshes are not needed for the instance level: their BLAS build is bypassed like in a device build)
+  const int e = fjgpu::BuildHostScene(desc, &hs, &err, true);
+  if (e) return fail(e, err);
+  const DGroup &G = hs.groups[group];
+  for (int k = 0; k < G.count && k < cap; k++) {
+    const DTNode &nd = hs.group_nodes[G.first + k];
+    if (out_inst) out_inst[k] = nd.inst;
+    if (out_skip) out_skip[k] = nd.inst < 0 ? nd.skip - G.first : 0;
+    if (out_box) std::memcpy(out_box + 6 * (size_t) k, nd.box, sizeof(nd.box));
+  }
+  return G.count;
+}
+
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
 {
   if (!scene || !name || !value) return fail(FJGPU_EINVAL, "bad query call");

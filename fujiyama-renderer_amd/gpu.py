@@ -142,6 +142,22 @@ class MultiScene(object):
         return fb, list(st)
 
 
+def host_instance_level(scene_desc_ptr, group):
+    """(inst [n], skip [n], box [n, 6]) of the group's instance level as the host builder lays it out; no device needed"""
+    L = lib()
+    L.fjgpu_host_instance_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.fjgpu_host_instance_level.restype = C.c_int
+    n = L.fjgpu_host_instance_level(scene_desc_ptr, group, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    inst = np.zeros(n, dtype=np.int32)
+    skip = np.zeros(n, dtype=np.int32)
+    box = np.zeros((n, 6), dtype=np.float64)
+    _check(min(0, L.fjgpu_host_instance_level(scene_desc_ptr, group, inst.ctypes.data_as(C.c_void_p), skip.ctypes.data_as(C.c_void_p),
+                                              box.ctypes.data_as(C.c_void_p), n)))
+    return inst, skip, box
+
+
 def global_option(name, value):
     """process-wide option of the core, e.g. global_option("device_build", 1)"""
     _check(lib().fjgpu_global_option(name.encode(), int(value)))

@@ -142,6 +142,14 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
 
+/* Inspection, no device needed: the instance level of `group` as the HOST builder lays it out (the device builds
+ * the same list, option "tlas_verify") -- a depth-first node list, node k: out_inst[k] = instance index or -1 for an
+ * inner node, out_skip[k] = index (within this list) of the node after an inner node's subtree, out_box[6 k..] = the
+ * instance's reference box / the inner node's widened union box.  The leaves are in the depth-first order of the
+ * reference's BVHAccelerator over the group's instances (src/fj_bvh_accelerator.cc:253-334).  Writes at most `cap`
+ * nodes (any out pointer may be NULL); returns the node count, or a negative error. */
+int fjgpu_host_instance_level(const fj_scene_desc *desc, int group, int32_t *out_inst, int32_t *out_skip, double *out_box, int cap);
+
 /* Facts about the built device scene (for measurement: record sizes of the actual layout).
  * "node_record_bytes" (128; "anyhit_node_record_bytes" 64: the lean any-hit walk reads the quantised
  * twin of a node), "tri_record_bytes" (36 when every mesh is stored as exact f32

@@ -395,3 +395,78 @@ def test_shader_dsos_built_by_the_reference_load_unchanged(tmp_path):
         assert sid >= 0 and L.fj_SiSetProperty3(sid, b"diffuse", .1, .2, .3) == 0
         assert L.fj_SiSetProperty3(sid, b"nonsense", 1, 2, 3) == -1
     L.fj_SiCloseScene()
+
+
+def _reference_bvh_leaf_order(boxes):
+    """BVHAccelerator::build over primitive boxes, restated: build_bvh sorts the range by centroid on the
+    cycling axis (std::sort; stable for the few elements of a range here) and splits it where find_median says
+    (src/fj_bvh_accelerator.cc:253-334); returns the leaves in depth-first (left first) order and, for every
+    subtree, its (first leaf position, size)."""
+    cent = [[.5 * (b[k] + b[3 + k]) for k in range(3)] for b in boxes]       # Box::Centroid, src/fj_box.cc:63-66
+    order = list(range(len(boxes)))
+    subtrees = []
+
+    def find_median(begin, end, axis):
+        low, high, mid = begin, end - 1, -1
+        key = (cent[order[low]][axis] + cent[order[high]][axis]) / 2
+        while low != mid:
+            mid = (low + high) // 2
+            c = cent[order[mid]][axis]
+            if key < c:
+                high = mid
+            elif c < key:
+                low = mid
+            else:
+                break
+        return mid + 1
+
+    def build(begin, end, axis):
+        subtrees.append((begin, end - begin))
+        if end - begin == 1:
+            return
+        order[begin:end] = sorted(order[begin:end], key=lambda i: (cent[i][axis], i))
+        m = find_median(begin, end, axis)
+        build(begin, m, (axis + 1) % 3)
+        build(m, end, (axis + 1) % 3)
+
+    build(0, len(boxes), 0)
+    return order, subtrees
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 12, 40, 150, 777])
+def test_instance_level_is_the_reference_bvh_in_depth_first_order(n, asset_dir):
+    """the instance level of a group (fjgpu_build.cc: BuildGroupNodes; the device builds the same list): its
+    leaves are the depth-first leaf order of the reference's BVH over the instances -- restated above, independent
+    of the builder --, an inner node with the union box sits in front of every subtree of more than 4 leaves,
+    and its skip link points behind that subtree"""
+    host.run_scene_text(workloads.crowd(asset_dir, res=(32, 24), spp=(1, 1), mesh="tiny", n=n, nlights=1), deferred=True)
+    sp, _ = host.get_desc()
+    best = None
+    for g in range(64):                      # the group with the most instances (the crowd's trace target)
+        try:
+            inst, skip, box = gpu.host_instance_level(sp, g)
+        except gpu.GpuError:
+            break
+        if best is None or (inst >= 0).sum() > (best[0] >= 0).sum():
+            best = (inst, skip, box)
+    inst, skip, box = best
+    leaves = np.flatnonzero(inst >= 0)
+    assert len(leaves) >= n
+    # leaf boxes in GROUP order (the builder breaks centroid ties by position in the group): instance ids ascend with it
+    by_inst = {int(inst[k]): box[k] for k in leaves}
+    ids = sorted(by_inst)
+    order, subtrees = _reference_bvh_leaf_order([by_inst[i] for i in ids])
+    assert [int(inst[k]) for k in leaves] == [ids[j] for j in order]
+    # inner nodes: exactly the subtrees of more than 4 leaves, in depth-first order, with union boxes and skip links
+    want_inner = [(b, sz) for (b, sz) in subtrees if sz > 4]
+    inner = np.flatnonzero(inst < 0)
+    assert len(inner) == len(want_inner)
+    leaf_pos = {int(k): j for j, k in enumerate(leaves)}
+    for k, (b, sz) in zip(inner, want_inner):
+        under = [int(x) for x in leaves if k < x < skip[k]]
+        assert [leaf_pos[x] for x in under] == list(range(b, b + sz))
+        lo = np.min(box[under][:, :3], axis=0)
+        hi = np.max(box[under][:, 3:], axis=0)
+        assert np.all(box[k][:3] <= lo) and np.all(box[k][3:] >= hi)
+        assert np.all(lo - box[k][:3] <= 1e-8 * (np.abs(lo) + np.abs(hi)) + 1e-11)
+        assert skip[k] == leaves[b + sz - 1] + 1          # the node after the subtree's last leaf
