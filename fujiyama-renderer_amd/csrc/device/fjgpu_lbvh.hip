@@ -161,7 +161,7 @@ __device__ __forceinline__ float half_area(const Box6 &b)
 // compacted.  Agglomerative with a surface-area distance: the tree quality of a top-down SAH
 // build without its serial passes.  Everything is decided by index arithmetic and exclusive
 // sums, so the tree -- and with it every counter a render reports -- is the same in every run.
-#define PLOC_R_MAX 32
+#define PLOC_R_MAX 128
 
 // ordering of candidate pairs with equal distance: by a hash of the pair, then by (lower index,
 // higher index).  Symmetric in its two members, so the pair that is globally smallest in
