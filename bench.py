@@ -15,10 +15,13 @@ outside the timed region, like the reference's build_accelerators()
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
-objects: "roofline" (dominant kernel = the trace kernels, algorithmic bytes per
-launch / HIP-event duration against the 8 TB/s HBM3E peak) and "cpu_baseline"
-(the compiled reference -- or the CPU restatement -- timed on the host cores on
-a bounded tile sample of the same workload).
+objects: "roofline" -- for the kernel that takes the largest share of the frame BY
+MEASURED TIME (HIP events): its HBM traffic from rocprofv3's FETCH_SIZE / WRITE_SIZE
+(calibrated on the walks' own access pattern, profiles/*_fetch_size_calibration.json)
+over its time against the 8 TB/s HBM3E peak, its VALU issue utilisation, and -- kept
+apart, never divided by the HBM peak -- the algorithmic bytes of SURVEY 8(d) -- and
+"cpu_baseline" (the compiled reference -- or the CPU restatement -- timed on the
+host cores on a bounded tile sample of the same workload).
 """
 import argparse
 import json
@@ -71,13 +74,36 @@ def parse_args():
     return ap.parse_args()
 
 
-def algorithmic_bytes(st, s_node, s_prim, s_node_walk=None):
+def algorithmic_bytes(st, s_node_closest, s_prim, s_node_shadow):
+    """SURVEY 8(d) bytes of one frame's traversal side: every walk's nodes at the record size THAT walk reads"""
     closest = st.rays_traced - st.rays.shadow
-    nodes = st.nodes_visited * s_node
-    if s_node_walk is not None:        # the shadow walk's nodes at its own record size
-        nodes = (st.nodes_visited - st.shadow_nodes) * s_node + st.shadow_nodes * s_node_walk
+    nodes = (st.nodes_visited - st.shadow_nodes) * s_node_closest + st.shadow_nodes * s_node_shadow
     return (nodes + st.prims_tested * s_prim + st.insts_tested * S_INST +
             closest * (S_RAY_IN + S_HIT_OUT) + st.shadow_traversed * S_SHADOW)
+
+
+def closest_algorithmic_bytes(st, s_node_closest, s_prim):
+    closest = st.rays_traced - st.rays.shadow
+    return ((st.nodes_visited - st.shadow_nodes) * s_node_closest + (st.prims_tested - st.shadow_prims) * s_prim +
+            (st.insts_tested - st.shadow_insts) * S_INST + closest * (S_RAY_IN + S_HIT_OUT))
+
+
+def fetch_calibration():
+    """factor = bytes a kernel needed / (rocprofv3 FETCH_SIZE x 1024), measured on this chip for random 64-byte record
+    gathers (the node fetch of the walks) by scripts/fetch_calibration.py; the newest committed file under profiles/.
+    Without one the guide's streaming-read factor 2 is used and the line says so."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fetch_size_calibration.json"))):
+        try:
+            k = json.load(open(f))["kernels"]
+            best = {"factor": float(k["k_calib_gather64"]["factor_needed_over_FETCH_SIZE"]), "source": os.path.relpath(f, ROOT),
+                    "factor_stream": float(k["k_calib_stream"]["factor_needed_over_FETCH_SIZE"]),
+                    "factor_gather36": float(k.get("k_calib_gather36", {}).get("factor_needed_over_FETCH_SIZE") or 0) or None,
+                    "pattern": "random 64-byte records, 4 x global_load_dwordx4 per lane, 4 GiB array"}
+        except Exception:  # noqa: BLE001
+            continue
+    return best or {"factor": 2.0, "source": "MI355X_MICROARCH.md (streaming reads; NOT calibrated for gathers)", "pattern": None}
 
 
 def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays):
@@ -111,7 +137,11 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
             seconds = struct.unpack("<d", head[16:24])[0]
             return {"value": sample_rays / seconds / 1e6, "unit": "Mray/s",
                     "cores": min(os.cpu_count() or 1, len(sample_ids)), "host_cores": os.cpu_count() or 1, "cpu_model": cpu_model(),
-                    "kind": "reference", "sample": desc, "seconds": seconds, "rays": int(sample_rays)}
+                    "kind": "reference", "sample": desc, "seconds": seconds, "rays": int(sample_rays),
+                    "threads_spawned": os.cpu_count() or 1,
+                    "note": "the reference's use_max_thread default spawns one worker per hardware thread; at most one per tile of the "
+                            "sample (= `cores`) is ever busy.  The sample is a block around the image centre, denser than the frame "
+                            "average: a rate on that block, not a frame rate"}
         except Exception as e:  # fall through to the port
             sys.stderr.write("cpu_baseline: reference run failed (%s); using the CPU restatement\n" % e)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -130,6 +160,21 @@ PMC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",),
              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
 
 
+def kernel_matcher(kname):
+    """production instantiation (event-counting template argument false) of a traversal kernel, by its mangled-free name"""
+    def match(nm):
+        if kname == "k_shadow_anyhit":
+            return "k_shadow_anyhit<false" in nm
+        if kname == "k_shadow_trace":
+            return any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false"))
+        if kname == "k_trace_closest_phased":
+            return "k_trace_closest_phased<false" in nm
+        if kname == "k_trace_closest":
+            return any(("k_trace_closest<%s, false" % c) in nm for c in ("true", "false"))
+        return kname in nm
+    return match
+
+
 def pmc_passes(args, kname):
     """Hardware counters of the dominant kernel for THIS build, measured now: one rocprofv3
     --kernel-trace --pmc pass per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass,
@@ -146,6 +191,7 @@ def pmc_passes(args, kname):
     if not os.path.exists(exe):
         return None
     out, tmp = {}, tempfile.mkdtemp(prefix="fjpmc_", dir="/tmp")
+    match = kernel_matcher(kname)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-tiles", "0", "--no-pmc",
              "--workload", args.workload]
     if args.mesh:
@@ -166,11 +212,7 @@ def pmc_passes(args, kname):
                 for r in csv.DictReader(open(f)):
                     # the production instantiation: the event-counting template argument is false
                     # (k_shadow_anyhit<count, multi>, k_shadow_trace<curves, count, motion>)
-                    nm = r["Kernel_Name"]
-                    if kname == "k_shadow_anyhit":
-                        if "k_shadow_anyhit<false" not in nm:
-                            continue
-                    elif not any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false")):
+                    if not match(r["Kernel_Name"]):
                         continue
                     out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     if r["Counter_Name"] == "SQ_WAVES":
@@ -232,8 +274,10 @@ def main():
         gpu.global_option("device_build", args.device_build)
     gs = gpu.Scene(scene_ptr, device=local_rank)
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
-    # the lean any-hit walk reads the quantised 64-byte twin of a node
+    # the lean any-hit walk reads the quantised 64-byte twin of a node; so does the closest-hit walk of scenes
+    # without curve sets / motion (fjgpu_dev_traverse.h)
     s_node_walk = gs.query("anyhit_node_record_bytes") if gs.query("lean_anyhit") else s_node
+    s_node_closest = gs.query("closest_node_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
     if os.environ.get("FJGPU_OVERLAP"):            # experiment switch: light loop + shadow walk on a second stream
@@ -282,7 +326,7 @@ def main():
     # ---------------- aggregate over ranks
     rays_local = float(sum(s.rays.total() for s in stats))
     trace_ms_local = float(sum(s.trace_ms for s in stats))
-    alg_bytes_local = float(algorithmic_bytes(counted, s_node, s_prim, s_node_walk)) * len(stats)
+    alg_bytes_local = float(algorithmic_bytes(counted, s_node_closest, s_prim, s_node_walk)) * len(stats)
     launches_local = float(sum(s.trace_launches for s in stats))
     agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
     mx = agg.clone()
@@ -295,34 +339,49 @@ def main():
     if rank == 0:
         s0 = stats[-1]
         per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
-        # roofline of the DOMINANT KERNEL on rank 0 -- the shadow walk (k_shadow_anyhit, or
-        # k_shadow_trace for scenes with translucent occluders / curves / motion): the algorithmic
-        # bytes of its launches (its own event counts from the counting frame x record sizes) over
-        # the summed HIP-event durations of exactly those launches in the timed frames.
+        # ---- roofline of the DOMINANT KERNEL on rank 0: the traversal kernel with the largest share of the
+        # frame by MEASURED time (HIP events of exactly its launches in the timed frames)
         nf = len(stats)
-        walk_alg = float(counted.shadow_nodes * s_node_walk + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
-                         counted.shadow_traversed * S_SHADOW) * nf
-        walk_ms = float(sum(s.shadow_walk_ms for s in stats))
-        walk_nl = float(sum(s.shadow_walk_launches for s in stats))
-        achieved = walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
-        kname = "k_shadow_anyhit" if gs.query("lean_anyhit") else "k_shadow_trace"
-        # ... and of the whole traversal side (closest-hit walk + light loop + shadow walk), as before
-        alg = float(algorithmic_bytes(counted, s_node, s_prim, s_node_walk)) * nf
+        shadow_name = "k_shadow_anyhit" if gs.query("lean_anyhit") else "k_shadow_trace"
+        closest_name = "k_trace_closest_phased" if int(gs.query("closest_kernel")) == 1 else "k_trace_closest"
+        cand = {
+            shadow_name: {"ms": float(sum(s.shadow_walk_ms for s in stats)), "launches": float(sum(s.shadow_walk_launches for s in stats)),
+                          "alg": float(counted.shadow_nodes * s_node_walk + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
+                                       counted.shadow_traversed * S_SHADOW) * nf,
+                          "rays": float(counted.shadow_traversed) * nf},
+            closest_name: {"ms": float(sum(s.closest_ms - s.sort_ms for s in stats)), "launches": float(sum(s.closest_launches for s in stats)),
+                           "alg": float(closest_algorithmic_bytes(counted, s_node_closest, s_prim)) * nf,
+                           "rays": float(counted.rays_traced - counted.rays.shadow) * nf},
+        }
+        kname = max(cand, key=lambda k: cand[k]["ms"])
+        K = cand[kname]
+        walk_ms, walk_nl, walk_alg = K["ms"], K["launches"], K["alg"]
+        frame_ms_sum = max(1e-9, float(sum(s.total_ms for s in stats)))
+        # the whole traversal side (closest-hit walk + light loop + shadow walk), algorithmic figure only
+        alg = float(algorithmic_bytes(counted, s_node_closest, s_prim, s_node_walk)) * nf
         tms = float(sum(s.trace_ms for s in stats))
         nl = float(sum(s.trace_launches for s in stats))
-        # Hardware counters of the SAME build, measured now by rocprofv3 child passes of this
-        # script (pmc_passes): HBM traffic = 2 x FETCH_SIZE (gfx950 tallies a 128-byte request at
-        # 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KB; VALU issue = ACTIVE_INST_VALU
-        # quad-cycles / (SIMDs x elapsed quad-cycles); lane efficiency = THREAD_CYCLES_VALU /
-        # (64 x ACTIVE_INST_VALU).
-        traffic, traffic_src, pmc, issue = None, None, None, None
+        # Hardware counters of the SAME build, measured now by rocprofv3 child passes of this script
+        # (pmc_passes): HBM-side traffic = cal x FETCH_SIZE + WRITE_SIZE (both in KB), cal = the factor
+        # scripts/fetch_calibration.py measured on this chip for random 64-byte record gathers
+        # (profiles/r*_fetch_size_calibration.json; MI355X_MICROARCH.md "HBM": calibrate on your own pattern);
+        # VALU issue = ACTIVE_INST_VALU quad-cycles / (SIMDs x elapsed quad-cycles); lane efficiency =
+        # THREAD_CYCLES_VALU / (64 x ACTIVE_INST_VALU).
+        cal = fetch_calibration()
+        traffic, pmc, issue, hbm = None, None, None, None
         if world == 1 and not args.no_pmc and args.as_rank_of <= 1:
             pmc = pmc_passes(args, kname)
         launches_per_frame = walk_nl / nf if nf else 1.0
-        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and launches_per_frame:
+        avg_ms = walk_ms / walk_nl if walk_nl else None
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and launches_per_frame and avg_ms:
             # (per frame in the child -> per launch of this run)
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / launches_per_frame
-            traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE doubled: gfx950)"
+            traffic = (cal["factor"] * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / launches_per_frame
+            gbps = traffic / (avg_ms * 1e-3) / 1e9
+            hbm = {"GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS, "traffic_bytes_per_launch": traffic,
+                   "FETCH_SIZE_KB_per_frame": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_per_frame": pmc["WRITE_SIZE"],
+                   "fetch_size_factor": cal["factor"], "fetch_size_factor_source": cal["source"], "calibration_pattern": cal["pattern"],
+                   "traffic_over_algorithmic": traffic / (walk_alg / walk_nl) if walk_alg else None,
+                   "note": "bytes the L2s requested from the fabric (Infinity Cache hits are in it: an upper bound of DRAM traffic)"}
         if pmc and pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES") and pmc.get("SQ_ACTIVE_INST_VALU"):
             props = torch.cuda.get_device_properties(device)
             simds = props.multi_processor_count * 4
@@ -335,32 +394,44 @@ def main():
                      "waves_waiting_on_memory": pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
                      "waves_stalled_at_issue": pmc.get("SQ_WAIT_INST_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
                      "valu_wave_instructions_per_frame": pmc.get("SQ_INSTS_VALU"), "simds": simds,
-                     "note": "FP64 / packed-FP32 VALU issue is the bound that binds this walk: 4 cycles per wave instruction, "
-                             "one VALU per SIMD; the HBM side is hbm_counters"}
-        avg_ms = walk_ms / walk_nl if walk_nl else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src,
-                "note": "achieved = algorithmic bytes of SURVEY 8(d) (what the walk must READ, mostly served by L1 / L2) over "
-                        "the kernel's HIP-event time; hbm_counters = what came from HBM; valu_issue = the bound that binds",
-                "hbm_counters": ({"GBps": traffic / (avg_ms * 1e-3) / 1e9, "frac_of_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                  "traffic_over_algorithmic": traffic / (walk_alg / walk_nl)} if traffic and avg_ms else None),
-                "valu_issue": issue,
-                "kernel": kname, "launches": int(walk_nl),
-                "avg_launch_ms": avg_ms,
-                "algorithmic_bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
-                "share_of_frame": walk_ms / max(1e-9, float(sum(s.total_ms for s in stats))),
-                "bytes_per_ray": walk_alg / max(1.0, float(counted.shadow_traversed) * nf),
-                "record_bytes": {"node": s_node, "node_shadow_walk": s_node_walk, "tri": s_prim, "instance_box": S_INST, "ray_in": S_RAY_IN,
-                                 "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW},
-                "kernel_ms_per_frame_rank0": {"k_trace_closest": float(sum(s.closest_ms for s in stats)) / nf,
+                     "note": "one VALU per SIMD, 4 cycles per wave instruction (FP64 and packed FP32 alike): busy = share of "
+                             "the chip's VALU issue cycles this kernel used, lane_efficiency = active lanes per issued instruction"}
+        # `frac` is a utilisation of a hardware peak measured by counters, <= 1 by construction: the HBM-side
+        # bandwidth of this kernel over the 8 TB/s peak.  Which resource is nearer its roof is said beside it
+        # (`binding_resource`: "valu" when the VALU issue utilisation is the larger fraction).  The algorithmic
+        # bytes of SURVEY 8(d) are reported under `algorithmic` and never priced against the HBM peak.
+        bound, frac, achieved, peak, unit = "hbm", None, None, HBM_PEAK_GBPS, "GB/s"
+        if hbm:
+            achieved = min(hbm["GBps"], HBM_PEAK_GBPS)
+            frac = achieved / HBM_PEAK_GBPS
+        binding = None
+        if issue and frac is not None:
+            binding = "valu" if issue["valu_busy"] > frac else "hbm"
+        roof = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac,
+                "traffic": traffic, "traffic_unit": "bytes per launch (fabric side of L2, calibrated FETCH_SIZE + WRITE_SIZE)",
+                "kernel": kname, "launches": int(walk_nl), "avg_launch_ms": avg_ms,
+                "share_of_frame": walk_ms / frame_ms_sum,
+                "picked_by": "largest measured HIP-event time among the traversal kernels",
+                "binding_resource": binding,
+                "hbm_counters": hbm, "valu_issue": issue,
+                "algorithmic": {"bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
+                                "GBps": walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
+                                "bytes_per_ray": walk_alg / max(1.0, K["rays"]),
+                                "note": "SURVEY 8(d): event counts of this kernel (counting frame) x record sizes = the bytes the walk "
+                                        "must READ; caches serve most of them, so this is data turned over, not an HBM fraction",
+                                "record_bytes": {"node_closest_walk": s_node_closest, "node_shadow_walk": s_node_walk, "tri": s_prim,
+                                                 "instance_box": S_INST, "ray_in": S_RAY_IN, "hit_out": S_HIT_OUT, "shadow_ray": S_SHADOW},
+                                "all_traversal_kernels": {"kernel": closest_name + "+k_shadow_cull+" + shadow_name, "launches": int(nl),
+                                                          "GBps": alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
+                                                          "bytes_per_frame": alg / nf,
+                                                          "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * nf)}},
+                "kernel_ms_per_frame_rank0": {closest_name: cand[closest_name]["ms"] / nf,
+                                              "ray_sort": float(sum(s.sort_ms for s in stats)) / nf,
                                               "k_shadow_cull": float(sum(s.light_loop_ms for s in stats)) / nf,
-                                              kname: walk_ms / nf},
-                "all_traversal_kernels": {"kernel": "k_trace_closest+k_shadow_cull+" + kname, "launches": int(nl),
-                                          "achieved": alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0,
-                                          "frac": (alg / (tms * 1e-3) / 1e9 if tms > 0 else 0.0) / HBM_PEAK_GBPS,
-                                          "algorithmic_bytes_per_frame": alg / nf,
-                                          "bytes_per_ray": alg / max(1.0, float(counted.rays_traced) * nf)}}
+                                              shadow_name: cand[shadow_name]["ms"] / nf,
+                                              "k_shade": float(sum(s.shade_ms for s in stats)) / nf,
+                                              "k_gen_camera": float(sum(s.gen_ms for s in stats)) / nf,
+                                              "k_resolve": float(sum(s.resolve_ms for s in stats)) / nf}}
         # rays that actually walk a BLAS (camera / reflect / ... closest-hit rays + the shadow rays
         # that survive the instance-box cull), next to the SlTrace-event count of the metric
         walked = float(sum((s.rays.total() - s.rays.shadow) for s in stats)) + float(counted.shadow_traversed) * nf

@@ -88,7 +88,6 @@ struct fjgpu_scene {
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   int max_children;                // most child rays one shading event can emit in this scene
   bool bounce_diffuse, bounce_reflect, bounce_refract;   // bounce types some shader of the scene emits
-  bool uses_sample_uid;            // sample times / random streams are keyed by (tile id << 20) + sample index
   DHit *d_hits;
   DLightRec *d_lrecs[2];           // double buffered: the shadow stream consumes one while shading fills the other
   DLightHair *d_lhair[2];          // only when the scene has a HairShader
@@ -120,6 +119,7 @@ struct fjgpu_scene {
   float *d_frame = nullptr; size_t d_frame_n = 0;      // this device's framebuffer
   float *d_slab = nullptr; size_t d_slab_n = 0;        // packed tiles: own ones (sender) / incoming (first device)
   int32_t *d_rects = nullptr; size_t d_rects_n = 0;    // tile rectangles of a slab
+  fjgpu_batch_fn batch_fn = nullptr; void *batch_user = nullptr;   // fjgpu_set_batch_callback
 };
 
 static int grow(void **p, size_t *have, size_t want, size_t elem)
@@ -173,6 +173,7 @@ static long g_device_tlas = 1;     // "device_tlas": the instance level of every
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
+static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
 
 extern "C" {
@@ -185,6 +186,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "device_tlas") { g_device_tlas = value != 0; return 0; }
   if (std::string(name) == "tlas_verify") { g_tlas_verify = value != 0; return 0; }
   if (std::string(name) == "split_shadow") { g_split_shadow = value != 0; return 0; }
+  if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -233,7 +235,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
 
   std::unique_ptr<fjgpu_scene> sc(new fjgpu_scene());
   sc->device = device;
-  sc->batch_tiles = 0;
+  sc->batch_tiles = g_batch_tiles;
   sc->count_events = 0;     // traversal event counters are opt-in ("count_nodes"): they cost registers
   sc->count_all_shadow = 1;
   sc->work_samples = sc->work_rays = 0;
@@ -310,7 +312,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   }
   DScene &S = sc->S;
   std::memset(&S, 0, sizeof(S));
-  e |= M.upload(dps.data(), dps.size(), &S.primsets);
   {
     // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
     // grid = 65536^3 cells over the primitive set's padded bounds
@@ -329,6 +330,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
       P.qnodes = q;
     }
+    e |= M.upload(dps.data(), dps.size(), &S.primsets);      // (after the loop above: DPrimSet.qnodes is set)
     {
       // the instance table, each record with a copy of its primitive set's entry data
       std::vector<DInstance> di = hs.instances;
@@ -473,10 +475,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   sc->n_light_samples = S.n_light_samples;
   sc->max_children = 0;
   sc->bounce_diffuse = sc->bounce_reflect = sc->bounce_refract = false;
-  sc->uses_sample_uid = S.has_motion || S.cam_xform != nullptr || S.has_area;
   for (int i = 0; i < desc->n_shaders; i++) {
     const fj_shader_desc &sh = desc->shaders[i];
-    if (sh.type == FJ_SHADER_PATHTRACING) sc->uses_sample_uid = true;
     auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
     int k = 0;
     if (sh.type == FJ_SHADER_PLASTIC) { k = sh.do_reflect ? 1 : 0; if (k) sc->bounce_reflect = true; }
@@ -599,7 +599,21 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
   // 1: shadow rays are walked by k_shadow_anyhit (every occluder opaque, no curves, no motion), 0: by k_shadow_trace
   if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion && scene->S.blas_base) ? 1 : 0; return 0; }
+  // which closest-hit kernel walks this scene (launch_trace_closest): 0 k_trace_closest<false, *, false>, 1 k_trace_closest_phased,
+  // 2 k_trace_closest<true, *, false> (curve sets), 3 k_trace_closest<true, *, true> (time-sampled transforms / vertex velocities)
+  if (n == "closest_kernel") { *value = scene->S.has_motion ? 3 : (scene->S.has_curves ? 2 : (scene->S.incoherent_rays ? 1 : 0)); return 0; }
+  // ... and the node record it reads: the 64-byte quantised twin unless the ribbon test / motion instantiation runs
+  if (n == "closest_node_record_bytes") { *value = (double) ((scene->S.has_motion || scene->S.has_curves || !FJ_CLOSEST_QNODES) ? sizeof(DNode) : sizeof(DNodeQ)); return 0; }
+  if (n == "has_curves") { *value = scene->S.has_curves; return 0; }
+  if (n == "has_motion") { *value = scene->S.has_motion; return 0; }
   return fail(FJGPU_EINVAL, "unknown query " + n);
+}
+
+int fjgpu_set_batch_callback(fjgpu_scene *scene, fjgpu_batch_fn fn, void *user)
+{
+  if (!scene) return fail(FJGPU_EINVAL, "null scene");
+  scene->batch_fn = fn; scene->batch_user = fn ? user : nullptr;
+  return 0;
 }
 
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
@@ -759,12 +773,6 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
       ? (size_t) (a_div * (r->tile_w + 2 * margin[0]) + 1) * (size_t) (a_div * (r->tile_h + 2 * margin[1]) + 1)
       : (size_t) (r->rate_x * r->tile_w + 2 * margin[0]) * (r->rate_y * r->tile_h + 2 * margin[1]);
 
-  if (sc->uses_sample_uid && all.size() > 4096)
-    return fail(FJGPU_EUNSUPPORTED, "frames of more than 4096 tiles are not supported for scenes with motion blur, area lights or "
-        "PathtracingShader: their random streams are keyed by a 12-bit tile id (use a larger tilesize)");
-  if (sc->uses_sample_uid && full_tile_samples > ((size_t) 1 << 20))
-    return fail(FJGPU_EUNSUPPORTED, "tiles of more than 2^20 samples (tilesize x pixelsamples) are not supported for scenes with "
-        "motion blur, area lights or PathtracingShader: their per-sample times and random streams are keyed by a 20-bit sample index");
   // Batch size.  The persistent traversal kernels pay a tail per launch (ray costs are
   // heavy tailed: the last waves finish long after the average one), so launches should be
   // few and large: up to 160 M samples per batch -- a whole 1080p / 64 spp frame, ~80 GB of
@@ -781,7 +789,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   if (sc->levels.size() < (size_t) deepest + 1) sc->levels.resize((size_t) deepest + 1, fjgpu_scene::Level{nullptr, nullptr, 0});
   long bt = sc->batch_tiles;
   if (bt <= 0) {
-    const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0);
+    const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
+        ((sc->ray_sort_bits > 0 && deepest >= 1) ? 24 : 0);       // (the ray sort's keys, slots, permutation and scratch)
     // (a scene without lights queues no shadow rays: the fifth of the HBM that queue may take goes to the ray queues --
     // C4, nine recursion levels: 1010 -> 994 ms per frame.  Walking a whole level in one launch with per-level hit
     // buffers and chunking only the shading was measured too: 130 -> ~50 closest-hit launches per frame, 1005 ms: dropped)
@@ -806,6 +815,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     bool ok = ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) == 0;
     // every reachable level now, so that a failure shrinks the batch instead of ending the frame
     for (int l = 0; ok && l <= deepest; l++) ok = ensure_level(sc, l, cap_rays) == 0;
+    // ... and the ray sort's scratch (a failure here also halves the batch)
+    if (ok && sc->ray_sort_bits > 0 && deepest >= 1) ok = ensure_sort(sc, cap_rays) == 0;
     if (ok) break;
     (void) hipGetLastError();
     if (bt == 1) return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
@@ -983,7 +994,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         DScene St = S;
         int e = 0;
         if (sc->ray_sort_bits > 0 && level >= 1 && (long) n >= g_ray_sort_min) {
-          if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");
+          if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");   // (sized with the queues: cannot fail here)
           e = timed(st, &acc.sort_ms, [&]() {
             return launch_ray_sort(st, rays, n, sc->scene_box, sc->ray_sort_bits, sc->d_sort[0], sc->d_sort[1], sc->d_sort[2], sc->d_sort[3],
                 sc->d_sort_tmp, sc->sort_tmp_bytes);
@@ -1123,6 +1134,11 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     acc.shadow_traversed += hc.squeued;
     acc.shadow_nodes += hc.sh_nodes; acc.shadow_prims += hc.sh_prims; acc.shadow_insts += hc.sh_insts;
     acc.batches++;
+    if (sc->batch_fn) {
+      // (the stream was synchronised above: the batch's pixels are final in d_fb)
+      const std::vector<int32_t> bids(ids.begin() + (long) b0, ids.begin() + (long) b0 + nb);
+      if (sc->batch_fn(sc->batch_user, sc->device, bids.data(), nb)) { acc.interrupted = 1; break; }
+    }
   }
   (void) hipEventRecord(ev_all[1], st);
   hipError_t se = hipStreamSynchronize(st);
@@ -1199,6 +1215,8 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
           grow((void **) &sc->d_rects, &sc->d_rects_n, mine[d].size() * 4, sizeof(int32_t)))
         return bad(FJGPU_ENOMEM, "device allocation failed for a device's frame");
       fb = sc->d_frame;
+      // (tiles a batch callback keeps from being rendered are packed and sent all the same: they read 0)
+      if (sc->batch_fn && hipMemset(fb, 0, npx * 4 * sizeof(float)) != hipSuccess) return bad(FJGPU_ENODEV, "frame clear failed");
     }
     const int e = fjgpu_render_tiles(sc, r, mine[d].data(), (int) mine[d].size(), fb, nullptr, &st);
     if (e) return bad(e, fjgpu_last_error());

@@ -4,6 +4,15 @@
 #ifndef FJGPU_DEV_SHADE_H
 #define FJGPU_DEV_SHADE_H
 
+// Sample uid of the random-stream contract (the oracle computes the same): tile id * 2^20 + sample index
+// in the tile as a 64-bit number, its high word folded into the low one -- the plain 32-bit sum for frames of up to 4096
+// tiles of up to 2^20 samples, distinct streams beyond.  (The sample's TIME index travels separately: DPath.flags >> 1.)
+__device__ __forceinline__ uint32_t sample_uid(int32_t tile_id, uint32_t k)
+{
+  const unsigned long long u = ((unsigned long long) (uint32_t) tile_id << 20) + k;
+  return (uint32_t) u ^ ((uint32_t) (u >> 32) * 0x9E3779B1u);
+}
+
 // Camera::GetRay (src/fj_camera.cc:79-110): a time-sampled camera is evaluated at the
 // sample's time, a static one uses the host-built matrix.  k = index of the sample in its
 // tile (time stream, sample uid), slot = its place in the batch's sample arrays.
@@ -30,7 +39,7 @@ __device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, 
   p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
   p.group = S.target_group;
   p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
-  p.flags = 0; p.rng = 0; p.uid = ((uint32_t) tile_id << 20) + k;
+  p.flags = k << 1; p.rng = 0; p.uid = sample_uid(tile_id, k);
   *path_out = p;
 }
 
@@ -246,7 +255,7 @@ struct ChildRay {
 
 // `cxt` is uniform per call site (reflect / refract / diffuse children are
 // emitted by separate calls), so the per-context ray count is one atomic per block
-__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t key,
+__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
     DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, uint32_t *s_tmp)
 {
   const uint32_t slot = block_append(c.want, &cnt->next_count, &cnt->rays[cxt], s_tmp);
@@ -263,7 +272,7 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
   p.cxt = (uint8_t) cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
   p.group = c.group;
   p.fc[0] = c.fc[0]; p.fc[1] = c.fc[1]; p.fc[2] = c.fc[2];
-  p.flags = c.flags; p.rng = key; p.uid = uid;
+  p.flags = c.flags | tbits; p.rng = key; p.uid = uid;     // tbits: the sample's time index << 1
   next_paths[slot] = p;
 }
 
@@ -293,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   DLightRec lr;
   DLightHair lh;
   lr.kind = 0;
-  uint32_t sample = 0, rng = 0, uid = 0;
+  uint32_t sample = 0, rng = 0, uid = 0, tbits = 0;
 
   if (hit) {
     const DRay r = rays[i];
@@ -301,6 +310,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     sample = p.sample;
     rng = p.rng;
     uid = p.uid;
+    tbits = p.flags & ~1u;
     const DInstance *I = &S.instances[h.inst];
     const DPrimSet *P = &S.primsets[I->primset];
     const V3 ro = mk(r.o[0], r.o[1], r.o[2]), rd = mk(r.d[0], r.d[1], r.d[2]);
@@ -310,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     const double *IM = I->M, *IMinv = I->Minv;
     double tm[12], tmi[12];
     if (kMotion && I->xform >= 0) {
-      xform_at(&S.xforms[I->xform], sample_time(S, p.uid & 0xfffffu), tm, tmi);
+      xform_at(&S.xforms[I->xform], sample_time(S, p.flags >> 1), tm, tmi);
       IM = tm; IMinv = tmi;
     }
     const V3 oo = xpoint(IMinv, ro);
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       const FJ_GLOBAL double *cp = FJ_G(double, P->curve_cp) + sl * 12;
       V3 c0 = ld3(cp), c1 = ld3(cp + 3), c2 = ld3(cp + 6), c3 = ld3(cp + 9);
       if (kMotion && P->curve_vel) {          // time_sample (src/fj_curve.cc:392-397): cp += time * velocity
-        const double tm_ = sample_time(S, p.uid & 0xfffffu);
+        const double tm_ = sample_time(S, p.flags >> 1);
         const FJ_GLOBAL double *w = FJ_G(double, P->curve_vel) + sl * 12;
         c0 = c0 + tm_ * ld3(w); c1 = c1 + tm_ * ld3(w + 3); c2 = c2 + tm_ * ld3(w + 6); c3 = c3 + tm_ * ld3(w + 9);
       }
@@ -403,7 +413,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
             // vertices, then the instance's M as a vector transform
             V3 p0 = ld3(FJ_G(double, P->P) + 3 * (size_t) i0), p1 = ld3(FJ_G(double, P->P) + 3 * (size_t) i1), p2 = ld3(FJ_G(double, P->P) + 3 * (size_t) i2);
             if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
-              const double tm_ = sample_time(S, p.uid & 0xfffffu);
+              const double tm_ = sample_time(S, p.flags >> 1);
               p0 = p0 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i0);
               p1 = p1 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i1);
               p2 = p2 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i2);
@@ -434,7 +444,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 0;
-          lr.uid = p.uid; lr.key = p.rng;
+          lr.uid = p.uid; lr.key = p.rng; lr.kind |= (int32_t) (p.flags & ~1u);     // (kind bit 0; the time index above it)
           if (lr.W[0] == 0.f && lr.W[1] == 0.f && lr.W[2] == 0.f && !sp.count_all_shadow) want_light = false;
         }
         if (sh->do_reflect && (int) p.rdepth + 1 <= sp.max_reflect_depth) {
@@ -491,7 +501,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           lr.sample = sample;
           lr.group = I->shadow_target;
           lr.kind = 1;
-          lr.uid = p.uid; lr.key = p.rng;
+          lr.uid = p.uid; lr.key = p.rng; lr.kind |= (int32_t) (p.flags & ~1u);     // (kind bit 0; the time index above it)
         }
         Os = 1.f;
         break;
@@ -508,7 +518,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           if (has_uv) {
             V3 p0 = ld3(FJ_G(double, P->P) + 3 * (size_t) i0), p1 = ld3(FJ_G(double, P->P) + 3 * (size_t) i1), p2 = ld3(FJ_G(double, P->P) + 3 * (size_t) i2);
             if (kMotion && P->velocity) {    // the time-sampled vertices of Mesh::ray_intersect
-              const double tm_ = sample_time(S, p.uid & 0xfffffu);
+              const double tm_ = sample_time(S, p.flags >> 1);
               p0 = p0 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i0);
               p1 = p1 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i1);
               p2 = p2 + tm_ * ld3(FJ_G(double, P->velocity) + 3 * (size_t) i2);
@@ -594,13 +604,13 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   if (want_light) {
     if (lslot < sp.light_capacity) {
       lrecs[lslot] = lr;
-      if (lr.kind == 1 && S.lrec_hair) S.lrec_hair[lslot] = lh;
+      if ((lr.kind & 1) && S.lrec_hair) S.lrec_hair[lslot] = lh;
     }
     else cnt->overflow = 1;
   }
-  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
-  emit_child(c0, CXT_REFLECT_RAY, sample, uid, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
-  emit_child(c1, CXT_REFRACT_RAY, sample, uid, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
 }
 
 #endif

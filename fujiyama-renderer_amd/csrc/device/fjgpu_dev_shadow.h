@@ -78,13 +78,13 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
     double cos_limit = 0;
     if (active) {
       R = lrecs[rec];
-      if (kHair && R.kind == 1) H = S.lrec_hair[rec];
+      if (kHair && (R.kind & 1)) H = S.lrec_hair[rec];
       Ps = mk(R.P[0], R.P[1], R.P[2]);
       axis = mk(R.N[0], R.N[1], R.N[2]);
       nml_axis = normalize(axis);
       r_sample = R.sample;
       W[0] = R.W[0]; W[1] = R.W[1]; W[2] = R.W[2];
-      cos_limit = (!kHair || R.kind == 0) ? sp.cos_half_pi : sp.cos_pi;
+      cos_limit = (!kHair || (R.kind & 1) == 0) ? sp.cos_half_pi : sp.cos_pi;
       g_first = S.groups[R.group].first; g_count = S.groups[R.group].count;
       g_single = S.groups[R.group].n_instances == 1;
       g_sbounds = S.groups[R.group].sbounds;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
         const bool lit = !surely_behind && !(cosangle < cos_limit) && !(Cl[0] < .0001 && Cl[1] < .0001 && Cl[2] < .0001);
         if (lit) {
           float k[3] = {0.f, 0.f, 0.f};
-          if (!kHair || R.kind == 0) {   // plastic_shader.cc:131-137
+          if (!kHair || (R.kind & 1) == 0) {   // plastic_shader.cc:131-137
             float Kd = (float) dot(axis, Ln);
             Kd = (float) (Kd > 0 ? (double) Kd : 0.);
             k[0] = Kd * Cl[0]; k[1] = Kd * Cl[1]; k[2] = Kd * Cl[2];
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
             q.c[0] = W[0] * k[0]; q.c[1] = W[1] * k[1]; q.c[2] = W[2] * k[2];
             // (lean any-hit walk: a single-instance group's only candidate is settled here)
             // (tindex: the sample's slot in the time table for the general walk; in split mode the join slot, 0 = none)
-            q.sample = r_sample; q.group = (sp.pre_resolve && g_single) ? ~g_inst : R.group; q.tindex = (kSplit && sp.join_capacity) ? 0u : (R.uid & 0xfffffu);
+            q.sample = r_sample; q.group = (sp.pre_resolve && g_single) ? ~g_inst : R.group; q.tindex = (kSplit && sp.join_capacity) ? 0u : ((uint32_t) R.kind >> 1);
           } else if (!kSplit || !pending) {
             sum[0] += k[0]; sum[1] += k[1]; sum[2] += k[2];
           }

@@ -46,9 +46,6 @@ __device__ __forceinline__ uint32_t adaptive_grab(uint32_t grab, uint32_t n)
 // (DCounters.*_xcd_head, one per 128-byte line); the waves of XCD x start in region x -- their L2 then
 // holds the nodes that ONE stretch of the queue walks, not those of eight, and a head has an eighth of
 // the pullers -- and move on to the next region when theirs is empty.  Everything here is wave-uniform.
-#ifndef FJ_CLOSEST_QNODES
-#define FJ_CLOSEST_QNODES 1              // 0: the closest-hit walk reads the 128-byte f32 nodes in every instantiation
-#endif
 #ifndef FJ_XCD_HEADS
 #define FJ_XCD_HEADS 1                  // 0: one region
 #endif
@@ -612,7 +609,7 @@ struct ClosestPolicy {
     const DRay q = rays[i];
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = q.tmin; r->tmax = q.tmax;
-    r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].uid & 0xfffffu) : 0.;   // fjgpu_trace: time 0
+    r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].flags >> 1) : 0.;   // fjgpu_trace: time 0
     r->group = paths ? paths[i].group : default_group;
     r->anyhit = false;
     return true;

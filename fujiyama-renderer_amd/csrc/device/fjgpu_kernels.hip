@@ -107,7 +107,11 @@ __global__ void __launch_bounds__(BLOCK) k_move_tiles(float4 *fb, int xres, cons
 // ------------------------------------------------------- k_quantize_nodes
 // DNode -> DNodeQ (fjgpu_types.h): child boxes outward onto the 65536^3 grid origin + q * cell.
 // floor / ceil in f64, then checked against the decoded plane and stepped outward if a rounding
-// went the wrong way: the decoded box always contains the f32 box.
+// went the wrong way: the decoded box contains the f32 box wherever that box lies inside the
+// grid (coordinates clamp to [0, 65535]; the grid spans the primitive set's PADDED bounds, and a
+// node box is the f64 primitive bounds rounded outward by <= 2 ulp of f32, which stays inside
+// the 1e-4 padding for |coordinate| < 512 -- beyond that a clamped plane can sit inside the f32
+// box by those ulps, but never inside the f64 bounds of the geometry: still conservative).
 __global__ void __launch_bounds__(BLOCK) k_quantize_nodes(const DNode *nodes, uint32_t n, double ox, double oy, double oz,
     double cx, double cy, double cz, DNodeQ *out)
 {
@@ -266,7 +270,7 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
   // (SPLIT: rays into groups of several instances are queued once per candidate instance, DScene.shadow_join)
   const bool split = sp.join_capacity != 0 && S.shadow_join != nullptr;
   if (S.has_area) { if (split) FJ_LAUNCH_CULL(true, true, true); else FJ_LAUNCH_CULL(true, true, false); }          // general instantiation
-  else if (S.has_hair) FJ_LAUNCH_CULL(true, false, false);
+  else if (S.has_hair) { if (split) FJ_LAUNCH_CULL(true, false, true); else FJ_LAUNCH_CULL(true, false, false); }
   else { if (split) FJ_LAUNCH_CULL(false, false, true); else FJ_LAUNCH_CULL(false, false, false); }
 #undef FJ_LAUNCH_CULL
   LAUNCH_CHECK();

@@ -207,15 +207,22 @@ int TlasBuildDevice(const DInstance *d_instances, const std::vector<int> &member
     return done(-1, "upload failed");
   hipLaunchKernelGGL(k_tlas_build, dim3(G), dim3(TB), 0, 0, d_instances, d_members, d_mfirst, d_mcount, W, d_nemit);
   std::vector<int> nemit(G);
-  if (hipGetLastError() != hipSuccess || hipMemcpy(nemit.data(), d_nemit, G * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-    return done(-1, hipGetErrorString(hipGetLastError()));
+  {
+    hipError_t le = hipGetLastError();        // (reading it clears it: keep the value for the message)
+    if (le == hipSuccess) le = hipMemcpy(nemit.data(), d_nemit, G * sizeof(int), hipMemcpyDeviceToHost);
+    if (le != hipSuccess) return done(-1, hipGetErrorString(le));
+  }
   size_t total = 0;
   for (int g = 0; g < G; g++) { (*node_first)[g] = (int) total; (*node_count)[g] = member_count[g] + nemit[g]; total += (size_t) (*node_count)[g]; }
   if (hipMemcpy(d_nfirst, node_first->data(), G * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return done(-1, "upload failed");
   void *nodes = nullptr;
   if (hipMalloc(&nodes, (total ? total : 1) * sizeof(DTNode)) != hipSuccess) return done(-1, "out of device memory");
   hipLaunchKernelGGL(k_tlas_emit, dim3(G), dim3(TB), 0, 0, d_instances, d_members, d_mfirst, d_mcount, W, d_nemit, d_nfirst, (DTNode *) nodes);
-  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void) hipFree(nodes); return done(-1, hipGetErrorString(hipGetLastError())); }
+  {
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipDeviceSynchronize();
+    if (le != hipSuccess) { (void) hipFree(nodes); return done(-1, hipGetErrorString(le)); }
+  }
   *d_nodes = (DTNode *) nodes;
   return done(0, nullptr);
 }

@@ -29,6 +29,10 @@ struct DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 64, "DNodeQ must be 64 bytes");
 
+#ifndef FJ_CLOSEST_QNODES
+#define FJ_CLOSEST_QNODES 1              // 0: the closest-hit walk reads the 128-byte f32 nodes in every instantiation
+#endif
+
 #define FJ_NO_CHILD 0xffffffffu
 #define FJ_LEAF_FLAG 0x80000000u
 #ifndef FJ_MAX_LEAF_PRIMS
@@ -237,9 +241,10 @@ struct DPath {                 // 48 B per-ray path state
   uint8_t cxt, ddepth, rdepth, tdepth;   // ray context + diffuse / reflect / refract depths
   int32_t group;               // trace target group
   float fc[3];                 // pending pow(filter, t_hit) colour (glass / pathtracing refraction)
-  uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit
+  uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit; bits 1..31: index of the sample in its tile
+                               // (its time is time_tab[flags >> 1]; every ray of the sample's path tree carries it)
   uint32_t rng;                // pathtracing RNG contract: path key (child k of key p = 4 p + k)
-  uint32_t uid;                // pathtracing RNG contract: tile id * 2^20 + sample index in the tile
+  uint32_t uid;                // RNG contract: sample_uid(tile id, sample index in the tile) (fjgpu_dev_shade.h)
 };
 static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
 
@@ -254,8 +259,9 @@ struct DLightRec {             // 80 B: one shading event that gathers direct li
   float W[3];                  // throughput * diffuse * diffuse_map (plastic) or throughput (hair)
   uint32_t sample;
   int32_t group;               // shadow target of the shaded object
-  int32_t kind;                // 0 lambert (plastic), 1 kajiya-kay (hair: + DLightHair of the same slot)
-  uint32_t uid;                // DPath.uid of the shading ray (its low 20 bits index the sample's time)
+  int32_t kind;                // bit 0: 0 lambert (plastic), 1 kajiya-kay (hair: + DLightHair of the same slot); bits 1..31: the
+                               // sample's index in its tile (time of the shadow rays: DShadowRay.tindex)
+  uint32_t uid;                // DPath.uid of the shading ray
   uint32_t key;                // path key of the shading ray (area-light stream, with uid)
 };
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace fjhost {
 
@@ -530,17 +531,34 @@ static int render_scene(Scene *sc, Renderer *ren)
 
   std::vector<fjgpu_stats> st(want);
   std::memset(st.data(), 0, sizeof(fjgpu_stats) * want);
+  // sample_done: the reference reports every sample from its worker threads (CbReportSampleDone in
+  // integrate_samples, src/fj_renderer.cc:1061-1096) and an interrupt ends the pool after the tile in
+  // flight.  A host call per sample is infeasible here: the hook fires once per BATCH of
+  // tiles a device completes (fjgpu_set_batch_callback; from that device's host thread, as the reference
+  // fires it from its workers), and an interrupt stops every device after the batch it is rendering.
+  struct BatchCtx { Renderer *ren; std::mutex mu; std::vector<int32_t> done; bool cancel = false; } bctx;
+  bctx.ren = ren;
+  const fjgpu_batch_fn on_batch = [](void *user, int, const int32_t *ids, int n) -> int {
+    BatchCtx *c = static_cast<BatchCtx *>(user);
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->done.insert(c->done.end(), ids, ids + n);
+    if (c->ren->sample_done && c->ren->sample_done(c->ren->tile_data) == fj::CALLBACK_INTERRUPT) c->cancel = true;
+    return c->cancel ? 1 : 0;
+  };
+  for (fjgpu_scene *g : gs) fjgpu_set_batch_callback(g, on_batch, &bctx);
   const double t2 = now_s();
-  err = fjgpu_render_frame_multi(gs.data(), want, &sc->render, tile_ids.data(), (int) tile_ids.size(), fb->GetWritable(0, 0, 0), st.data());
+  // (a tile_start interrupt on the very first tile leaves nothing to render: the frame stays as resized)
+  if (!tile_ids.empty())
+    err = fjgpu_render_frame_multi(gs.data(), want, &sc->render, tile_ids.data(), (int) tile_ids.size(), fb->GetWritable(0, 0, 0), st.data());
   const double t3 = now_s();
   if (err) g_last_error = std::string("fjgpu_render_frame_multi: ") + fjgpu_last_error();
   destroy_all();
   if (err) return -1;
 
-  // sample_done is reported once per frame (a per-sample host call is infeasible; an interrupt
-  // from it has nothing left to stop), tile_done once per rendered tile
-  if (ren->sample_done) (void) ren->sample_done(ren->tile_data);
-  for (int32_t t : tile_ids) {
+  // tile_done once per rendered tile, in queue order, when the frame is in host memory
+  // (TileInfo.framebuffer is readable for the finished tile, src/fj_callback.h:39-59)
+  std::sort(bctx.done.begin(), bctx.done.end());
+  for (int32_t t : bctx.done) {
     const fj::TileInfo ti = tile_info(t);
     if (ren->tile_done) ren->tile_done(ren->tile_data, &ti);
   }

@@ -49,7 +49,7 @@ class GpuStats(C.Structure):           # fjgpu_stats
         ("closest_ms", C.c_double), ("light_loop_ms", C.c_double), ("shadow_walk_ms", C.c_double),
         ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64), ("shadow_insts", C.c_uint64),
         ("closest_launches", C.c_uint32), ("light_loop_launches", C.c_uint32),
-        ("shadow_walk_launches", C.c_uint32), ("pad_", C.c_uint32),
+        ("shadow_walk_launches", C.c_uint32), ("interrupted", C.c_uint32),
         ("sort_ms", C.c_double), ("rays_sorted", C.c_uint64),
     ]
 

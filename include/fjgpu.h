@@ -67,7 +67,8 @@ typedef struct fjgpu_stats {
   uint64_t shadow_nodes;       /* BLAS nodes fetched by the shadow walk alone (counting instantiation) */
   uint64_t shadow_prims;       /* triangle / curve tests of the shadow walk alone */
   uint64_t shadow_insts;       /* instance boxes tested by the shadow walk alone */
-  uint32_t closest_launches, light_loop_launches, shadow_walk_launches, pad_;
+  uint32_t closest_launches, light_loop_launches, shadow_walk_launches;
+  uint32_t interrupted;        /* 1: the batch callback asked to stop; the batches after that one were not rendered */
   double   sort_ms;            /* ray-queue sort in front of the closest-hit walk (option "ray_sort"; part of closest_ms) */
   uint64_t rays_sorted;        /* rays that went through it */
 } fjgpu_stats;
@@ -94,6 +95,19 @@ int fjgpu_tile_rect(const fj_render_desc *render, int tile_id, int32_t rect[4]);
 int fjgpu_render_tiles(fjgpu_scene *scene, const fj_render_desc *render,
     const int32_t *tile_ids, int n_tiles,
     float *d_framebuffer, void *hip_stream, fjgpu_stats *stats);
+
+/* Batch callback.  fjgpu_render_tiles cuts its tile list into BATCHES (as many tiles as the wavefront
+ * queues hold: a whole 1080p / 64 spp frame is one batch, option "batch_tiles"); `fn` is called on the
+ * calling host thread each time a batch is complete on the device -- the tiles' pixels are final in the
+ * device framebuffer -- with the ids of its tiles.  This is where the host side fires the reference's
+ * per-sample `sample_done` hook, once per batch (CbReportSampleDone in integrate_samples,
+ * src/fj_renderer.cc:1061-1096; a host call per sample is infeasible, SURVEY 8b "Threading").  A nonzero
+ * return stops the call after this batch, like the reference's worker pool after a CALLBACK_INTERRUPT
+ * (render_tile -> LoopStatus::Cancel, src/fj_renderer.cc:1098-1121): the remaining tiles are not rendered,
+ * the call returns 0 and stats->interrupted is 1.  fn = NULL removes it.  (If a call has to be repeated
+ * because split shadow rays overflowed their queue -- see "split_shadow" -- its batches are reported again.) */
+typedef int (*fjgpu_batch_fn)(void *user, int device, const int32_t *tile_ids, int n_tiles);
+int fjgpu_set_batch_callback(fjgpu_scene *scene, fjgpu_batch_fn fn, void *user);
 
 /* Convenience: all tiles, result copied to a HOST buffer (xres*yres*4 floats). */
 int fjgpu_render_frame(fjgpu_scene *scene, const fj_render_desc *render,
@@ -139,7 +153,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * whose shaders scatter (glass, pathtracing), off elsewhere.  "ray_sort_min": launches of fewer rays keep
  * queue order (default 65536).  "split_shadow" 1/0 (default 1): in scenes served by the lean any-hit walk, a shadow
  * ray into a group of several instances is queued once per instance whose box it passes (joined by a counter)
- * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).  0 or FJGPU_EINVAL. */
+ * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).
+ * "batch_tiles" n: scenes created from now on start with the per-scene option of that name set to n (0 = sized by
+ * memory; how a host that never sees the scene handle -- SiRenderScene -- cuts a frame into batches).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
 
 /* Inspection, no device needed: the instance level of `group` as the HOST builder lays it out (the device builds
@@ -154,7 +170,9 @@ int fjgpu_host_instance_level(const fj_scene_desc *desc, int group, int32_t *out
  * "node_record_bytes" (128; "anyhit_node_record_bytes" 64: the lean any-hit walk reads the quantised
  * twin of a node), "tri_record_bytes" (36 when every mesh is stored as exact f32
  * triangles, else 72), "blas_nodes", "stack_need", "lean_anyhit" (1: shadow rays are walked by
- * k_shadow_anyhit, 0: by the general k_shadow_trace).  Returns 0 or FJGPU_EINVAL. */
+ * k_shadow_anyhit, 0: by the general k_shadow_trace), "closest_kernel" (0 k_trace_closest, 1 k_trace_closest_phased,
+ * 2 its curve instantiation, 3 its motion instantiation), "closest_node_record_bytes" (64: the closest-hit walk reads the
+ * quantised nodes too; 128 in scenes with curve sets or motion), "has_curves", "has_motion".  Returns 0 or FJGPU_EINVAL. */
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);
 
 /* Diagnostics: the host-side math that feeds geometry to the device (matrices,

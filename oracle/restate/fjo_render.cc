@@ -280,7 +280,7 @@ struct Cxt {
   float opacity_threshold;
   int trace_target;       // group index
   // counter-based RNG contract of the pathtracing restatement:
-  uint32_t sample_uid;    // tile id * 2^20 + sample index inside the tile
+  uint32_t sample_uid;    // tile id * 2^20 + sample index inside the tile (64-bit, folded to 32: see render_tile)
   uint32_t path_key;      // 0 for the camera ray; child k of a ray with key p has 4 p + k
 };
 
@@ -864,7 +864,12 @@ static void render_tile(RenderState *rs, const fj_render_desc &r, const CameraSt
   cxt.opacity_threshold = .995f;
   cxt.trace_target = rs->sc->d->target_group;
   auto integrate = [&](Sample &s, uint32_t index_in_tile) {
-    cxt.sample_uid = ((uint32_t) tile.id << 20) + index_in_tile;
+    {
+      // tile id * 2^20 + sample index as a 64-bit number, the high word folded into the low one: the plain
+      // 32-bit sum for frames of up to 4096 tiles of up to 2^20 samples, distinct streams beyond
+      const unsigned long long u = ((unsigned long long) (uint32_t) tile.id << 20) + index_in_tile;
+      cxt.sample_uid = (uint32_t) u ^ ((uint32_t) (u >> 32) * 0x9E3779B1u);
+    }
     cxt.path_key = 0;
     Ray ray;
     CameraGetRay(cam, s.uv, s.time, &ray);

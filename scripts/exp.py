@@ -31,7 +31,7 @@ for spec in sys.argv[2:]:
         j = json.loads(p.stdout.strip().splitlines()[-1])
         with open(os.path.join(out, "%s.%s.json" % (name, label)), "w") as f:
             json.dump(j, f)
-        k = j["roofline"]["kernel_ms_per_frame_rank0"]
+        k = {a: b for a, b in j["roofline"]["kernel_ms_per_frame_rank0"].items() if a.startswith(("k_trace", "k_shadow"))}
         c = j["config"]["counters_counting_frame_rank0"]
         m = j["config"]["ms_last_frame_rank0"]
         line += "  ms/frame %.1f  Mray/s %.0f | %s | shade %.1f gen %.1f resolve %.1f | nodes %.3g prims %.3g shtrav %.3g" % (

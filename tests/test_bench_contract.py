@@ -28,8 +28,15 @@ def test_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_trace") and r["launches"] >= 1 and r["avg_launch_ms"] > 0
+    # a counter-measured HBM fraction (rocprofv3 child passes of the same run): <= 1 by construction
+    assert r["traffic"] is not None and r["frac"] is not None, "the rocprofv3 counter passes did not run"
+    assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["hbm_counters"]["fetch_size_factor"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
+    assert r["binding_resource"] in ("hbm", "valu")
+    # the dominant kernel by measured time, named; the SURVEY 8(d) bytes are kept apart
+    assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_trace", "k_trace_closest", "k_trace_closest_phased")
+    assert r["launches"] >= 1 and r["avg_launch_ms"] > 0 and r["algorithmic"]["bytes_per_launch"] > 0
+    assert max(r["kernel_ms_per_frame_rank0"], key=lambda k: r["kernel_ms_per_frame_rank0"][k] if k.startswith("k_trace") or k.startswith("k_shadow_a") or k.startswith("k_shadow_t") else -1) == r["kernel"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

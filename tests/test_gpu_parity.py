@@ -408,6 +408,45 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
         assert float(rel_err(frames[0][0], frames[1][0]).max()) <= 1e-5
 
 
+def test_hair_shader_declared_in_an_all_opaque_mesh_scene_with_split_shadow_rays(asset_dir):
+    """a HairShader in a scene WITHOUT curves whose shadow groups hold several instances: the light loop runs its
+    hair instantiation, and that one must queue rays per candidate instance exactly like the plain one does (the
+    lean any-hit walk reads every entry as (instance, join slot)); both with the shader merely declared and with
+    it shading a mesh -- the oracle's ray counts and pixels, split on and off"""
+    base = workloads.crowd(asset_dir, res=(64, 48), spp=(2, 2), mesh="tiny", n=12)
+    declared = base.replace("NewCamera cam1", "OpenPlugin hair_shader HairShader.so\nNewShader hair1 hair_shader\nNewCamera cam1", 1)
+    assert declared != base
+    used = declared.replace("AssignShader obj3 DEFAULT_SHADING_GROUP obj_shader1", "AssignShader obj3 DEFAULT_SHADING_GROUP hair1")
+    assert used != declared
+    for text in (declared, used):
+        for split in (1, 0):
+            gpu.global_option("split_shadow", split)
+            try:
+                fb, st, ref, rc = render_both(text)
+            finally:
+                gpu.global_option("split_shadow", 1)
+            assert st.rays.as_dict() == rc.as_dict()
+            assert rc.shadow > rc.camera
+            assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
+@pytest.mark.parametrize("builder,kw", [
+    # 80 x 60 tiles of 8 x 8 pixels = 4800 tiles (> 4096: the tile id no longer fits 12 bits of the sample uid)
+    ("motion", dict(res=(640, 480), spp=(1, 1), mesh="tiny", kind="both", extra=(("tilesize", (8, 8)),))),
+    ("arealights", dict(res=(640, 480), spp=(1, 1), mesh="tiny", kind="both", extra=(("tilesize", (8, 8)),))),
+    ("cornell", dict(res=(640, 480), spp=(1, 1), mesh="tiny", extra=(("tilesize", (8, 8)),))),
+    # one tile of (2 * 520 + 4)^2 = 1.09 M samples (> 2^20: the sample's time index no longer fits 20 bits of the uid)
+    ("motion", dict(res=(520, 520), spp=(2, 2), mesh="tiny", kind="object", extra=(("tilesize", (520, 520)),))),
+], ids=["motion_4800_tiles", "area_lights_4800_tiles", "pathtracing_4800_tiles", "motion_tile_of_1M_samples"])
+def test_frames_beyond_4096_tiles_and_tiles_beyond_2_20_samples(builder, kw, asset_dir):
+    """sample times and random streams are keyed by (tile id, sample index in the tile): the uid is the 64-bit
+    tile * 2^20 + index folded to 32 bits, the time index travels on its own (DPath.flags) -- a 1080p frame with
+    16 x 16 tiles (8160 tiles) renders like any other.  Device == oracle (same contract)."""
+    fb, st, ref, rc = render_both(workloads.BUILDERS[builder](asset_dir, **kw))
+    assert st.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
 def test_unsupported_features_fail_loudly(asset_dir):
     """features outside the device path: explicit error naming the feature, never a silent
     approximation or a CPU fallback"""
@@ -419,14 +458,6 @@ def test_unsupported_features_fail_loudly(asset_dir):
         gs.render_frame(rd)
     gs.close()
     assert "adaptive_max_subdivision" in str(e.value)
-    # sample times are keyed by a 20-bit index inside the tile
-    sp, rd = prepare(workloads.motion(asset_dir, res=(640, 640), spp=(2, 2), mesh="tiny", kind="object",
-                                      extra=(("tilesize", (640, 640)),)))
-    gs = gpu.Scene(sp)
-    with pytest.raises(gpu.GpuError) as e:
-        gs.render_frame(rd)
-    gs.close()
-    assert "2^20 samples" in str(e.value)
     with pytest.raises(Exception) as e:
         prepare(base.replace("OpenPlugin plastic_shader PlasticShader.so", "OpenPlugin plastic_shader VolumeShader.so"))
     assert "no device implementation" in str(e.value) or "VolumeShader" in str(e.value)
@@ -584,4 +615,37 @@ def test_si_callbacks_and_interrupts(asset_dir):
     rc = host.render_with_callbacks(frame_start=lambda i: host.CALLBACK_INTERRUPT,
                                     tile_start=lambda i: ev3.__setitem__("tiles", ev3["tiles"] + 1) or 0)
     assert rc == -1 and ev3["tiles"] == 0 and not host.framebuffer(0).any()
+
+    # sample_done fires once per BATCH of tiles (fjgpu_set_batch_callback); an interrupt from it ends the frame
+    # after that batch (integrate_samples -> LoopStatus::Cancel, src/fj_renderer.cc:1061-1121): tiles 0-3 of 6
+    gpu.global_option("batch_tiles", 2)
+    try:
+        host.run_scene_text(text, deferred=True)
+        ev4 = {"sample": 0, "done": []}
+        rc = host.render_with_callbacks(sample_done=lambda: ev4.__setitem__("sample", ev4["sample"] + 1) or 0,
+                                        tile_done=lambda i: ev4["done"].append(i.region_id) or 0)
+        assert rc == 0 and ev4["sample"] == 3 and ev4["done"] == list(range(6))
+        assert float(rel_err(host.framebuffer(0), full).max()) <= 1e-6
+        host.run_scene_text(text, deferred=True)
+        ev5 = {"sample": 0, "done": [], "frame_done": 0}
+
+        def stop_after_two():
+            ev5["sample"] += 1
+            return host.CALLBACK_INTERRUPT if ev5["sample"] == 2 else host.CALLBACK_CONTINUE
+        rc = host.render_with_callbacks(sample_done=stop_after_two, tile_done=lambda i: ev5["done"].append(i.region_id) or 0,
+                                        frame_done=lambda i: ev5.__setitem__("frame_done", 1) or 0)
+        part = host.framebuffer(0)
+        assert rc == 0 and ev5["sample"] == 2 and ev5["done"] == [0, 1, 2, 3] and ev5["frame_done"] == 1
+        assert float(rel_err(part[:32], full[:32]).max()) <= 1e-6 and float(rel_err(part[32:, :32], full[32:, :32]).max()) <= 1e-6
+        assert not part[32:, 32:].any()
+    finally:
+        gpu.global_option("batch_tiles", 0)
+
+    # a tile_start interrupt on the very FIRST tile: nothing is rendered, no tile_done, the frame still completes
+    host.run_scene_text(text, deferred=True)
+    ev6 = {"done": 0, "frame_done": 0}
+    rc = host.render_with_callbacks(tile_start=lambda i: host.CALLBACK_INTERRUPT,
+                                    tile_done=lambda i: ev6.__setitem__("done", ev6["done"] + 1) or 0,
+                                    frame_done=lambda i: ev6.__setitem__("frame_done", 1) or 0)
+    assert rc == 0 and ev6["done"] == 0 and ev6["frame_done"] == 1 and not host.framebuffer(0).any()
     host.close_scene()
