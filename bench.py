@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--rank-costs", type=int, default=0,
                     help="diagnostic: on ONE GPU time the tile share of EVERY rank of an N-GPU job (max over ranks = the N-GPU frame "
                          "time before the gather)")
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="self-check of the N > 1 code path on ONE GPU: re-runs this script as N torch.distributed ranks (gloo, all on "
+                         "cuda:0, rendering one after the other), gathers their tiles exactly like an N-GPU job and compares the "
+                         "assembled frame with rank 0's own full render; timings of such a run mean nothing")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (HBM traffic, VALU issue) that feed the roofline object")
     return ap.parse_args()
@@ -235,11 +239,34 @@ def cpu_model():
     return "unknown"
 
 
+def dry_ranks_parent(args):
+    """--dry-ranks N: this script again as N ranks under torch.distributed.run, all on cuda:0 over gloo"""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.dry_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.dry_ranks),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-tiles", "0", "--no-pmc", "--workload", args.workload]
+    if args.mesh:
+        cmd += ["--mesh", args.mesh]
+    if args.res:
+        cmd += ["--res"] + [str(v) for v in args.res]
+    if args.spp:
+        cmd += ["--spp"] + [str(v) for v in args.spp]
+    env = dict(os.environ, FJ_BENCH_DRY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
+    dry = os.environ.get("FJ_BENCH_DRY") == "1"
+    if args.dry_ranks > 1 and not dry:
+        dry_ranks_parent(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if dry else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
     torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
@@ -247,7 +274,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     # ---------------- untimed: assets, scene, BLAS build, upload
     kw = {}
@@ -293,7 +323,16 @@ def main():
     stream = torch.cuda.current_stream(device).cuda_stream
 
     def step():
-        st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
+        if dry:
+            # ranks share ONE device here: they render one after the other
+            st = None
+            for turn in range(world):
+                if turn == rank:
+                    st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
+                    torch.cuda.synchronize(device)
+                dist.barrier()
+        else:
+            st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
         frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world)
         if rank == 0:
             host_fb.copy_(frame, non_blocking=False)       # framebuffer resident in host memory
@@ -303,6 +342,9 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
+
+    if world > 1 and rank == 0 and os.environ.get("FJGPU_VERBOSE"):
+        sys.stderr.write("bench: %d ranks, backend %s, %d of %d tiles on rank 0\n" % (world, dist.get_backend(), len(my_tiles), n_tiles))
 
     for _ in range(args.warmup):
         step()
@@ -460,6 +502,15 @@ def main():
                                                "ray_sort": s0.sort_ms, "rays_sorted": int(s0.rays_sorted)}},
             "roofline": roof,
         }
+        if dry:
+            # the assembled frame of the N-rank job against this rank's own render of the whole frame
+            whole = torch.zeros_like(fb)
+            gs.render_tiles(render, list(range(n_tiles)), whole.data_ptr(), stream)
+            torch.cuda.synchronize(device)
+            a, b = host_fb.numpy(), whole.cpu().numpy()
+            rel = float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
+            out["dry_ranks"] = {"ranks": world, "backend": dist.get_backend(), "max_rel_err_vs_single_render": rel, "ok": bool(rel <= 1e-5),
+                                "note": "all ranks on cuda:0, rendering in turns: a code-path check, its timings mean nothing"}
         if world == 1 and args.rank_costs > 1:
             # per-rank cost of an N-GPU job, every rank's tile share timed on this one GPU
             # (tile t -> rank t % N): the slowest share bounds the N-GPU frame before the gather
@@ -476,8 +527,27 @@ def main():
                               "shade": rst.shade_ms, "gen": rst.gen_ms, "resolve": rst.resolve_ms, "device_total": rst.total_ms,
                               "launches": int(rst.trace_launches), "batches": int(rst.batches)})
             slow = max(range(len(costs)), key=lambda k: costs[k])
-            out["config"]["rank_costs_ms"] = {"ranks": args.rank_costs, "per_rank": costs, "max": max(costs),
+            # what an N-GPU frame adds to its slowest rank: packing the rank's tiles into a slab, the exchange, the
+            # scatter into the frame, the frame's D2H -- all but the exchange itself measured on this GPU (the 7 slabs
+            # of <= 4.1 MB each arrive over separate xGMI links: priced at 50 GB/s per link, a third of the link rate)
+            G = args.rank_costs
+            ids_r = fjdist.tiles_of_rank(n_tiles, 0, G)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                slab = fjdist.pack_tiles(fb, ids_r, render.tile_w, render.tile_h)
+                slabs = [slab] * G
+                frame = fjdist.unpack_tiles(slabs, [fjdist.tiles_of_rank(n_tiles, r, G) for r in range(G)], render.xres, render.yres,
+                                            render.tile_w, render.tile_h)
+                host_fb.copy_(frame, non_blocking=False)
+            torch.cuda.synchronize(device)
+            tail_ms = (time.perf_counter() - t1) / 5 * 1e3
+            xgmi_ms = slab.numel() * 4 / 50e9 * 1e3
+            out["config"]["rank_costs_ms"] = {"ranks": G, "per_rank": costs, "max": max(costs),
                                               "speedup_before_gather": out["ms_per_step"] / max(costs),
+                                              "pack_unpack_d2h_ms_measured": tail_ms, "xgmi_exchange_ms_estimated": xgmi_ms,
+                                              "projected_frame_ms": max(costs) + tail_ms + xgmi_ms,
+                                              "projected_speedup": out["ms_per_step"] / (max(costs) + tail_ms + xgmi_ms),
                                               "slowest_rank_kernels_ms": parts[slow]}
         if world == 1 and args.cpu_tiles != 0:
             # bounded CPU sample: a block of tiles in the middle of the frame, two tiles per

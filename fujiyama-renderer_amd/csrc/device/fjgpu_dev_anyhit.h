@@ -274,6 +274,21 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
         if (kCount) lc->nodes++;
         const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], e = nd[3];
+#ifdef FJ_EXP_ALU_PAD
+        // experiment (profiles/r03_anyhit_bound_experiments.txt): FJ_EXP_ALU_PAD extra VALU instructions per inner step that
+        // depend on nothing the walk needs -- if the kernel's time follows them it is bound by VALU issue, not by node latency
+        { float pad_ = tmax32;
+#pragma unroll
+          for (int k_ = 0; k_ < FJ_EXP_ALU_PAD; k_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad_));
+          asm volatile("" :: "v"(pad_)); }
+#endif
+#ifdef FJ_EXP_LOAD_PAD
+        // experiment: FJ_EXP_LOAD_PAD extra 16-byte loads of the SAME node per inner step (L1 hits: request rate, no new latency)
+        { fj_v4u lp_ = {0, 0, 0, 0};
+#pragma unroll
+          for (int k_ = 0; k_ < FJ_EXP_LOAD_PAD; k_++) { const fj_v4u x_ = __builtin_nontemporal_load(&nd[k_ & 3]); lp_ ^= x_; }
+          asm volatile("" :: "v"(lp_.x ^ lp_.y ^ lp_.z ^ lp_.w)); }
+#endif
         // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
 #if FJ_ANYHIT_SIGNED_SLABS
         const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);

@@ -53,21 +53,67 @@ def unpack_tiles(slabs, tile_id_lists, xres, yres, tile_w, tile_h):
     return padded[:yres, :xres].contiguous()
 
 
-def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world):
+def _backend_is_device_capable():
+    """RCCL ("nccl") moves device tensors; gloo gets host copies of the slabs (CPU tests, bench.py --dry-ranks)"""
+    try:
+        return dist.get_backend() == "nccl"
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None):
     """Gather every rank's finished tiles to rank 0; returns the assembled
-    framebuffer on rank 0 and None elsewhere.  One collective per frame:
-    33.2 MB total at 1080p, <= 4.1 MB per peer."""
+    framebuffer on rank 0 and None elsewhere.  One exchange per frame:
+    33.2 MB total at 1080p, <= 4.1 MB per peer.
+
+    mode (default: env FJ_GATHER or "gather"):
+      "gather"      one dist.gather of equal-size slabs to rank 0 (RCCL: grouped send / recv over xGMI)
+      "send_recv"   the same exchange spelled as point-to-point dist.send / dist.recv
+      "all_gather"  dist.all_gather of the slabs (every rank receives the frame; rank 0 uses it)
+    If the backend refuses "gather" before any data moves (RuntimeError: not supported), the
+    point-to-point form is used for this and every later frame."""
+    import os
     H, W, _ = fb.shape
     if world == 1:
         return fb
+    mode = mode or _state.get("mode") or os.environ.get("FJ_GATHER", "gather")
     per_rank = int(math.ceil(n_tiles / float(world)))
     mine = tiles_of_rank(n_tiles, rank, world)
     slab = torch.zeros((per_rank, tile_h, tile_w, fb.shape[-1]), dtype=fb.dtype, device=fb.device)
     if mine:
         slab[:len(mine)] = pack_tiles(fb, mine, tile_w, tile_h)
-    if rank == 0:
-        out = [torch.empty_like(slab) for _ in range(world)]
-        dist.gather(slab, gather_list=out, dst=0)
-        return unpack_tiles(out, [tiles_of_rank(n_tiles, r, world) for r in range(world)], W, H, tile_w, tile_h)
-    dist.gather(slab, gather_list=None, dst=0)
-    return None
+    if not _backend_is_device_capable():
+        slab = slab.cpu()
+    out = None
+    if mode == "gather":
+        try:
+            if rank == 0:
+                out = [torch.empty_like(slab) for _ in range(world)]
+                dist.gather(slab, gather_list=out, dst=0)
+            else:
+                dist.gather(slab, gather_list=None, dst=0)
+        except (RuntimeError, NotImplementedError) as e:      # raised at dispatch, on every rank alike
+            if "support" not in str(e).lower() and "implement" not in str(e).lower():
+                raise
+            mode = _state["mode"] = "send_recv"
+            out = None
+    if mode == "send_recv":
+        if rank == 0:
+            out = [slab] + [torch.empty_like(slab) for _ in range(world - 1)]
+            for r in range(1, world):
+                dist.recv(out[r], src=r)
+        else:
+            dist.send(slab, dst=0)
+    elif mode == "all_gather":
+        got = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(got, slab)
+        out = got if rank == 0 else None
+    elif mode != "gather":
+        raise ValueError("unknown gather mode %r" % (mode,))
+    if rank != 0:
+        return None
+    frame = unpack_tiles(out, [tiles_of_rank(n_tiles, r, world) for r in range(world)], W, H, tile_w, tile_h)
+    return frame.to(fb.device) if frame.device != fb.device else frame
+
+
+_state = {}

@@ -194,26 +194,31 @@ def ensure_assets(root, meshes=("teapot",), textures=True):
         if not os.path.exists(path):
             cls = MESH_CLASSES[name]
             v, q, t = bumpy_sphere(cls[0], cls[1], seed=SEED + len(name), radius=cls[2] if len(cls) > 2 else 1.0)
-            write_ply(path + ".tmp", v, faces_quads=q, faces_tris=t)
-            os.replace(path + ".tmp", path)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            write_ply(tmp, v, faces_quads=q, faces_tris=t)
+            os.replace(tmp, path)
         out[name] = path
+    # (every file appears under its name complete or not at all: several ranks may ask for the same assets)
     path = os.path.join(root, "floor.ply")
     if not os.path.exists(path):
         v, q = floor_grid()
-        write_ply(path, v, faces_quads=q)
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        write_ply(tmp, v, faces_quads=q)
+        os.replace(tmp, path)
     out["floor"] = path
     path = os.path.join(root, "dome.ply")
     if not os.path.exists(path):
         v, q, uv = dome()
-        write_ply(path, v, faces_quads=q, uv=uv)
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        write_ply(tmp, v, faces_quads=q, uv=uv)
+        os.replace(tmp, path)
     out["dome"] = path
     if textures:
-        path = os.path.join(root, "sky.mip")
-        if not os.path.exists(path):
-            write_mip(path, sky_image())
-        out["sky"] = path
-        path = os.path.join(root, "rock.mip")
-        if not os.path.exists(path):
-            write_mip(path, rock_image())
-        out["rock"] = path
+        for name, image in (("sky", sky_image), ("rock", rock_image)):
+            path = os.path.join(root, name + ".mip")
+            if not os.path.exists(path):
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                write_mip(tmp, image())
+                os.replace(tmp, path)
+            out[name] = path
     return out

@@ -30,7 +30,7 @@ def test_pack_unpack_roundtrip_with_ragged_edge_tiles():
     assert torch.equal(back, fb)
 
 
-def _worker(rank, world, port, H, W, out_path):
+def _worker(rank, world, port, H, W, out_path, mode=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, H, W, out_path):
     for t in fjdist.tiles_of_rank(n_tiles, rank, world):
         x0, y0 = (t % nx) * tw, (t // nx) * th
         fb[y0:y0 + th, x0:x0 + tw] = full[y0:y0 + th, x0:x0 + tw]
-    frame = fjdist.gather_frame(fb, n_tiles, tw, th, rank, world)
+    frame = fjdist.gather_frame(fb, n_tiles, tw, th, rank, world, mode=mode)
     if rank == 0:
         assert torch.equal(frame, full)
         np.save(out_path, frame.numpy())
@@ -54,12 +54,14 @@ def _worker(rank, world, port, H, W, out_path):
     dist.destroy_process_group()
 
 
-def test_gather_frame_gloo_world2(tmp_path):
+@pytest.mark.parametrize("mode,world", [("gather", 2), ("send_recv", 2), ("all_gather", 2), ("gather", 3)])
+def test_gather_frame_gloo(tmp_path, mode, world):
+    """every spelling of the one exchange (gather / point-to-point / all_gather), world sizes 2 and 3 (ragged deal)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, port, 54, 100, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, 54, 100, out, mode), nprocs=world, join=True)
     f = np.load(out)
     assert f.shape == (54, 100, 4) and f[53, 99, 0] == 53 * 1000.0 + 99
