@@ -67,6 +67,9 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
 #ifndef FJ_ANYHIT_SIGNED_SLABS
 #define FJ_ANYHIT_SIGNED_SLABS 1
 #endif
+#if !FJ_ANYHIT_SIGNED_SLABS && FJ_SLAB_PERM
+#error "the unsigned slab variant converts the grid coordinates itself: build it with -DFJ_SLAB_PERM=0"
+#endif
 #ifndef FJ_ANYHIT_POSTPONE
 #define FJ_ANYHIT_POSTPONE 1
 #endif

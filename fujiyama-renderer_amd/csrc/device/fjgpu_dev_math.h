@@ -123,6 +123,17 @@ __device__ __forceinline__ Slab32 slab32_setup(V3 oo, V3 inv, const double *boun
 //   t~ = fmaf((float) q, A, B),  A = (float)(cell/od),  B = (float)((g0 - oo)/od)
 // is off by at most 2^-23 (65535 |A| + |B|)(1 + 2^-18) (roundings of A, of B, of the fma; (float) q
 // is exact).  i = A, l = B - e, h = B + e with e three times that bound, as above.
+//
+// FJ_SLAB_PERM (default): the integer reaches the fma WITHOUT a conversion instruction.  A byte permute
+// (v_perm_b32) drops the 16-bit coordinate into the mantissa of 2^23: as_float(0x4B000000 | q) IS the
+// number 8388608 + q, exactly.  The fma then computes (8388608 + q) A + (c - 8388608 A) -- product and sum
+// exact, ONE rounding of the result, which has the magnitude of t again -- so all that is new is the
+// rounding of the shifted addend c' = fmaf(-8388608, A, c): at most one ulp of 8388608 |A|, i.e. |A|
+// (one grid cell of t).  l' and h' are moved outward by 2 |A| for it: the box grows by two of its 65536
+// cells at most.  Per child and axis: two permutes instead of a rotate and two SDWA conversions.
+#ifndef FJ_SLAB_PERM
+#define FJ_SLAB_PERM 1
+#endif
 __device__ __forceinline__ Slab32Axis slab32q_axis(double inv, double oo, double g0, double cell)
 {
   const float A = (float) (cell * inv), B = (float) ((g0 - oo) * inv);
@@ -130,8 +141,13 @@ __device__ __forceinline__ Slab32Axis slab32q_axis(double inv, double oo, double
   const bool ok = e < 1e30f;
   Slab32Axis a;
   a.i = ok ? A : 0.f;
+#if FJ_SLAB_PERM
+  a.l = ok ? fmaf(-8388608.f, A, B - e) - 2.f * fabsf(A) : -1e30f;
+  a.h = ok ? fmaf(-8388608.f, A, B + e) + 2.f * fabsf(A) : 1e30f;
+#else
   a.l = ok ? B - e : -1e30f;
   a.h = ok ? B + e : 1e30f;
+#endif
   return a;
 }
 __device__ __forceinline__ Slab32 slab32q_setup(V3 oo, V3 inv, const double *g0, const double *cell)
@@ -161,18 +177,34 @@ __device__ __forceinline__ bool slab32_test(fj_v2f px, fj_v2f py, fj_v2f pz, con
   return tn <= tf;
 }
 // The same test on a QUANTISED box with the direction signs of the ray used up front: wx wy wz are the
-// (min, max) words of one child; sh* = 16 where the ray runs towards smaller coordinates on that axis
-// (slab32_shift), else 0.  Rotating the word by sh puts the NEAR plane in the low half, so one packed
-// fma per axis yields (entry, exit) directly -- fma(b, i, l) is monotonic in b, hence
-// min(fma(min, i, l), fma(max, i, l)) IS fma(near, i, l) and likewise for the exit side: the same
-// numbers as slab32_test, 4 instead of 6 instructions per axis.
+// (min, max) words of one child; sh* (slab32_shift) say which half of a word is the NEAR plane on that
+// axis -- the low one unless the ray runs towards smaller coordinates.  With the near plane in the first
+// and the far plane in the second element, one packed fma per axis yields (entry, exit) directly --
+// fma(b, i, l) is monotonic in b, hence min(fma(min, i, l), fma(max, i, l)) IS fma(near, i, l) and
+// likewise for the exit side: the same numbers as slab32_test, 4 instead of 6 instructions per axis.
+//   FJ_SLAB_PERM 1: sh = the v_perm_b32 selector that builds as_float(0x4B000000 | near half) -- result bytes 3, 2 =
+//                   bytes 3, 2 of the constant (selector values 7, 6), bytes 1, 0 = the word's (1, 0) or (3, 2); the
+//                   far half's selector is sh ^ 0x0202
+//   FJ_SLAB_PERM 0: sh = 16 or 0, the word is rotated (v_alignbit_b32) and converted (2 SDWA cvt)
+#if FJ_SLAB_PERM
+__device__ __forceinline__ uint32_t slab32_shift(float i) { return 0x07060100u ^ ((__float_as_uint(i) >> 31) * 0x0202u); }
+__device__ __forceinline__ fj_v2f slab32q_planes(uint32_t w, uint32_t sh)
+{
+  fj_v2f p;
+  p.x = __uint_as_float(__builtin_amdgcn_perm(0x4B000000u, w, sh));
+  p.y = __uint_as_float(__builtin_amdgcn_perm(0x4B000000u, w, sh ^ 0x0202u));
+  return p;
+}
+#else
 __device__ __forceinline__ uint32_t slab32_shift(float i) { return (__float_as_uint(i) >> 31) << 4; }
+__device__ __forceinline__ fj_v2f slab32q_planes(uint32_t w, uint32_t sh) { return unpack_q(__builtin_amdgcn_alignbit(w, w, sh)); }
+#endif
 __device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t wz, const Slab32 s, uint32_t shx, uint32_t shy, uint32_t shz,
     float tmin32, float tmax32, float *tnear = nullptr)
 {
-  const fj_v2f px = unpack_q(__builtin_amdgcn_alignbit(wx, wx, shx));
-  const fj_v2f py = unpack_q(__builtin_amdgcn_alignbit(wy, wy, shy));
-  const fj_v2f pz = unpack_q(__builtin_amdgcn_alignbit(wz, wz, shz));
+  const fj_v2f px = slab32q_planes(wx, shx);
+  const fj_v2f py = slab32q_planes(wy, shy);
+  const fj_v2f pz = slab32q_planes(wz, shz);
   fj_v2f cx, cy, cz;
   cx.x = s.x.l; cx.y = s.x.h; cy.x = s.y.l; cy.y = s.y.h; cz.x = s.z.l; cz.y = s.z.h;
   const fj_v2f tx = __builtin_elementwise_fma(px, (fj_v2f) (s.x.i), cx);
