@@ -86,6 +86,7 @@ struct fjgpu_scene {
   size_t a_samples = 0, a_cell_bytes = 0;
   struct Level { DRay *rays; DPath *paths; size_t cap; };
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
+  bool uses_sample_uid;            // some random stream or sample time of the scene is keyed by the sample's uid / index in its tile
   int max_children;                // most child rays one shading event can emit in this scene
   bool bounce_diffuse, bounce_reflect, bounce_refract;   // bounce types some shader of the scene emits
   DHit *d_hits;
@@ -330,7 +331,29 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
       P.qnodes = q;
     }
-    e |= M.upload(dps.data(), dps.size(), &S.primsets);      // (after the loop above: DPrimSet.qnodes is set)
+    // ... and of the 8-wide twin (host builds of meshes: DNode8 -> DNodeQ8, the same grid)
+    std::vector<const DNodeQ8 *> q8(dps.size(), nullptr);
+    bool wide_all = true, any_mesh = false;
+    for (size_t i = 0; i < dps.size(); i++) {
+      const DPrimSet &P = dps[i];
+      if (P.type != FJ_PRIMSET_MESH || P.n_prims == 0) continue;
+      any_mesh = true;
+      const fjgpu::HostPrimSet &h = hs.primsets[i];
+      if (!P.qnodes || e) { wide_all = false; continue; }
+      if (h.root8 & FJ_LEAF_FLAG) continue;               // a tree that is one leaf: nothing to read
+      if (h.nodes8.size() == 0) { wide_all = false; continue; }
+      const DNode8 *src = nullptr;
+      DNodeQ8 *q = nullptr;
+      void *tmp = nullptr;
+      if (hipMalloc(&tmp, h.nodes8.size() * sizeof(DNode8)) != hipSuccess) { e = 1; continue; }
+      src = static_cast<const DNode8 *>(tmp);
+      if (hipMemcpy(tmp, h.nodes8.data(), h.nodes8.size() * sizeof(DNode8), hipMemcpyHostToDevice) != hipSuccess || M.alloc(h.nodes8.size(), &q) ||
+          launch_quantize_nodes8(nullptr, src, (uint32_t) h.nodes8.size(), &qgrid[i][0], &qgrid[i][3], q) || hipDeviceSynchronize() != hipSuccess) e = 1;
+      (void) hipFree(tmp);
+      q8[i] = q;
+    }
+    S.anyhit_wide = (wide_all && any_mesh && getenv("FJGPU_WIDE8")) ? 1 : 0;
+    e |= M.upload(dps.data(), dps.size(), &S.primsets);      // (after the loops above: DPrimSet.qnodes is set)
     {
       // the instance table, each record with a copy of its primitive set's entry data
       std::vector<DInstance> di = hs.instances;
@@ -347,15 +370,20 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     // as 32-bit offsets from the lowest of their addresses
     uintptr_t lo = UINTPTR_MAX, hi = 0;
     auto tris_of = [](const DPrimSet &P) { return (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts); };
-    for (const DPrimSet &P : dps) {
+    for (size_t i = 0; i < dps.size(); i++) {
+      const DPrimSet &P = dps[i];
       if (!P.qnodes) continue;
       const uintptr_t pn = (uintptr_t) P.qnodes, pt = tris_of(P);
       lo = std::min(lo, std::min(pn, pt)); hi = std::max(hi, std::max(pn, pt));
+      if (q8[i]) { lo = std::min(lo, (uintptr_t) q8[i]); hi = std::max(hi, (uintptr_t) q8[i]); }
     }
     // (hipMalloc returns 256-byte aligned blocks: offsets in units of 128 B span 512 GB)
     bool fits = lo != UINTPTR_MAX && lo % 128 == 0 && (hi - lo) / 128 < 0xffffffffull;
-    for (const DPrimSet &P : dps)
+    for (size_t i = 0; i < dps.size(); i++) {
+      const DPrimSet &P = dps[i];
       if (P.qnodes && (((uintptr_t) P.qnodes - lo) % 128 != 0 || (tris_of(P) - lo) % 128 != 0)) fits = false;
+      if (q8[i] && ((uintptr_t) q8[i] - lo) % 128 != 0) fits = false;
+    }
     // the lean walk reads f32 triangle records only (every PLY mesh): a mesh that needs f64
     // vertices sends the scene's shadow rays through the general walk
     for (const DPrimSet &P : dps) if (P.qnodes && !P.tri_verts32) fits = false;
@@ -377,6 +405,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         a.node_base = (uint32_t) (((uintptr_t) P.qnodes - lo) / 128);
         a.tri_base = (uint32_t) ((tris_of(P) - lo) / 128);
         a.tris_f32 = P.tri_verts32 ? 1 : 0;
+        a.root8 = hs.primsets[I.primset].root8;
+        a.node8_base = q8[I.primset] ? (uint32_t) (((uintptr_t) q8[I.primset] - lo) / 128) : 0u;
       }
     }
     e |= M.upload(ai.data(), ai.size(), &S.any_insts);
@@ -439,7 +469,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
   {
     int need = 0;
-    for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
+    for (const auto &ps : hs.primsets) need = std::max(need, std::max(ps.stack_need, S.anyhit_wide ? ps.stack_need8 : 0));
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;
     // (scenes with curve sets run the kernels that keep FJ_STACK_LDS_CURVES entries in LDS)
@@ -459,7 +489,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     }
     if (getenv("FJGPU_VERBOSE"))
       for (const auto &ps : hs.primsets)
-        fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d\n", ps.type, ps.n_prims, ps.nodes.size(), ps.max_depth, ps.stack_need);
+        fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d; 8-wide nodes %zu stack need %d\n", ps.type, ps.n_prims,
+            ps.nodes.size(), ps.max_depth, ps.stack_need, ps.nodes8.size(), ps.stack_need8);
   }
   S.has_curves = 0;
   S.all_opaque = 1;
@@ -474,9 +505,11 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   sc->cam_fov = hs.cam_fov;
   sc->n_light_samples = S.n_light_samples;
   sc->max_children = 0;
+  sc->uses_sample_uid = S.has_motion || S.cam_xform != nullptr || S.has_area;
   sc->bounce_diffuse = sc->bounce_reflect = sc->bounce_refract = false;
   for (int i = 0; i < desc->n_shaders; i++) {
     const fj_shader_desc &sh = desc->shaders[i];
+    if (sh.type == FJ_SHADER_PATHTRACING) sc->uses_sample_uid = true;
     auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
     int k = 0;
     if (sh.type == FJ_SHADER_PLASTIC) { k = sh.do_reflect ? 1 : 0; if (k) sc->bounce_reflect = true; }
@@ -491,8 +524,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   }
   S.incoherent_rays = (sc->max_children >= 2 || sc->bounce_diffuse) ? 1 : 0;
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
-  S.pad_inc_ = 0;
   S.ray_perm = nullptr;
+  S.cam_uv = nullptr; S.cam_slot0 = 0;
   S.shadow_join = nullptr;
   sc->split_shadow = S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base && g_split_shadow;
   if (const char *e = getenv("FJGPU_SPLIT_SHADOW"))
@@ -593,7 +626,8 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (!scene || !name || !value) return fail(FJGPU_EINVAL, "bad query call");
   const std::string n(name);
   if (n == "node_record_bytes") { *value = (double) sizeof(DNode); return 0; }
-  if (n == "anyhit_node_record_bytes") { *value = (double) sizeof(DNodeQ); return 0; }
+  if (n == "anyhit_node_record_bytes") { *value = (double) (scene->S.anyhit_wide ? sizeof(DNodeQ8) : sizeof(DNodeQ)); return 0; }
+  if (n == "anyhit_wide") { *value = scene->S.anyhit_wide; return 0; }
   if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
@@ -945,9 +979,12 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     (void) hipMemsetAsync(sc->d_accum, 0, sizeof(float) * 4 * (size_t) n_samples, st);
     (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
 
+    // implicit camera rays (fjgpu_dev_shade.h): level 0 is rebuilt from the (u, v) table where it is needed
+    const bool implicit_cam = !adaptive && S.cam_xform == nullptr && !sc->uses_sample_uid && !getenv("FJGPU_EXPLICIT_CAMERA_RAYS");
     if (!adaptive) {
       rc = timed(st, &acc.gen_ms, [&]() {
-        return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv, sc->levels[0].rays, sc->levels[0].paths);
+        return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv,
+            implicit_cam ? nullptr : sc->levels[0].rays, implicit_cam ? nullptr : sc->levels[0].paths);
       });
       if (rc) break;
       acc.rays.camera += n_samples;
@@ -987,11 +1024,13 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
       const uint32_t chunk_max = kids <= 1 ? count : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
       for (uint32_t off = 0; off < count; off += chunk_max) {
         const uint32_t n = std::min(chunk_max, count - off);
-        const DRay *rays = sc->levels[level].rays + off;
-        const DPath *paths = sc->levels[level].paths + off;
+        const bool implicit = implicit_cam && level == 0;
+        const DRay *rays = implicit ? nullptr : sc->levels[level].rays + off;
+        const DPath *paths = implicit ? nullptr : sc->levels[level].paths + off;
         (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
         // secondary rays leave the shading kernel in emission order: walk them in (octant, cell) order
         DScene St = S;
+        if (implicit) { St.cam_uv = sc->d_suv + 2 * (size_t) off; St.cam_slot0 = off; }
         int e = 0;
         if (sc->ray_sort_bits > 0 && level >= 1 && (long) n >= g_ray_sort_min) {
           if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");   // (sized with the queues: cannot fail here)
@@ -1012,6 +1051,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
         shadow_pending[lb] = false;
         DScene Sl = S;
+        if (implicit) { Sl.cam_uv = St.cam_uv; Sl.cam_slot0 = off; }
         Sl.lrec_hair = sc->d_lhair[lb];
         e = timed(st, &acc.shade_ms, [&]() {
           return launch_shade(st, Sl, shp, rays, paths, sc->d_hits, n, sc->d_accum,

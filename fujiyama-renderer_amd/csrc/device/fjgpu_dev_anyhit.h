@@ -85,7 +85,11 @@ __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 
 // kMulti = false: every shadow group that can receive shadow rays has one instance, so every queue
 // entry names its instance (the instance-BVH walk and its registers are compiled out).
-template <bool kCount, bool kMulti>
+// kWide: the walk reads the 8-wide twin of the tree (DNodeQ8, DScene.anyhit_wide): eight box tests per dependent node
+// fetch instead of four -- about half as many round trips per ray (the walk is bound by their latency x occupancy,
+// profiles/r03_anyhit_bound_experiments.txt) and half as many step overheads; every hit child goes onto the stack, the
+// largest (stored first) on top, and the next node is popped.
+template <bool kCount, bool kMulti, bool kWide>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
     uint32_t n, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
 {
@@ -252,8 +256,8 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           vinst = inst;
 #endif
           tmax32 = f32_above(tmax);
-          node_base = A->node_base; tri_base = A->tri_base;
-          cur = A->root; sp = 0;
+          node_base = kWide ? A->node8_base : A->node_base; tri_base = A->tri_base;
+          cur = kWide ? A->root8 : A->root; sp = 0;
           break;
         }
       }
@@ -271,8 +275,58 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         PH(3, 1); PH(4, n_now);
       } else { PH(3, 1); PH(4, n_inner); }
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
-      const bool deep = __ballot(in_now && sp + 3 > FJ_STACK_LDS_ANYHIT) != 0ull;
-      if (in_now) {
+      const bool deep = __ballot(in_now && sp + (kWide ? 8 : 3) > FJ_STACK_LDS_ANYHIT) != 0ull;
+      if (kWide && in_now) {
+        // 128-byte quantised 8-wide node: eight 16-byte loads (24 words of (min, max) pairs + 8 child refs)
+        const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 7));
+        if (kCount) lc->nodes++;
+        const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3], w4 = nd[4], w5 = nd[5], e0 = nd[6], e1 = nd[7];
+        const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
+        const bool h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32);
+        FJ_SCHED_FENCE();
+        const bool h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32);
+        FJ_SCHED_FENCE();
+        const bool h2 = slab32q_test(w1.z, w1.w, w2.x, s32, shx, shy, shz, tmin32, tmax32) && e0.z != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32) && e0.w != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h4 = slab32q_test(w3.x, w3.y, w3.z, s32, shx, shy, shz, tmin32, tmax32) && e1.x != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h5 = slab32q_test(w3.w, w4.x, w4.y, s32, shx, shy, shz, tmin32, tmax32) && e1.y != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h6 = slab32q_test(w4.z, w4.w, w5.x, s32, shx, shy, shz, tmin32, tmax32) && e1.z != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        const bool h7 = slab32q_test(w5.y, w5.z, w5.w, s32, shx, shy, shz, tmin32, tmax32) && e1.w != FJ_NO_CHILD;
+        FJ_SCHED_FENCE();
+        if (!deep) {
+          // every hit child onto the stack, the first (largest) last: an unconditional store per child
+          // (whatever lies above the new top is dead) and a conditional step of the top
+          int s_ = sp;
+          AH_LDS(s_) = e1.w; s_ += (int) h7;
+          AH_LDS(s_) = e1.z; s_ += (int) h6;
+          AH_LDS(s_) = e1.y; s_ += (int) h5;
+          AH_LDS(s_) = e1.x; s_ += (int) h4;
+          AH_LDS(s_) = e0.w; s_ += (int) h3;
+          AH_LDS(s_) = e0.z; s_ += (int) h2;
+          AH_LDS(s_) = e0.y; s_ += (int) h1;
+          AH_LDS(s_) = e0.x; s_ += (int) h0;
+          sp = s_;
+        } else {
+          if (h7) push(sp, e1.w);
+          if (h6) push(sp, e1.z);
+          if (h5) push(sp, e1.y);
+          if (h4) push(sp, e1.x);
+          if (h3) push(sp, e0.w);
+          if (h2) push(sp, e0.z);
+          if (h1) push(sp, e0.y);
+          if (h0) push(sp, e0.x);
+        }
+        cur = (sp == 0) ? TRAV_DONE : pop(sp);
+#if FJ_ANYHIT_POSTPONE
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+#endif
+      }
+      if (!kWide && in_now) {
         // 64-byte quantised node: four 16-byte loads (12 words of (min, max) pairs + 4 child refs)
         const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
         if (kCount) lc->nodes++;
@@ -413,14 +467,14 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #ifndef FJ_ANYHIT_MINB_MULTI
 #define FJ_ANYHIT_MINB_MULTI 4
 #endif
-template <bool kCount, bool kMulti>
+template <bool kCount, bool kMulti, bool kWide>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
+  traverse_anyhit<kCount, kMulti, kWide>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

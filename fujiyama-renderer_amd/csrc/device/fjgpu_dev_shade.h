@@ -16,31 +16,63 @@ __device__ __forceinline__ uint32_t sample_uid(int32_t tile_id, uint32_t k)
 // Camera::GetRay (src/fj_camera.cc:79-110): a time-sampled camera is evaluated at the
 // sample's time, a static one uses the host-built matrix.  k = index of the sample in its
 // tile (time stream, sample uid), slot = its place in the batch's sample arrays.
-template <bool kMovingCamera>
-__device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, int32_t tile_id, uint32_t k, uint32_t slot,
-    DRay *ray_out, DPath *path_out)
+// (static camera: the ray of sample coordinates (u, v), from the host-built matrix)
+__device__ __forceinline__ DRay static_camera_ray(const DScene &S, double u, double v)
 {
   const double *cam = S.cam_M;
-  double cm[12], cmi[12];
-  if (kMovingCamera) { xform_at(S.cam_xform, sample_time(S, k), cm, cmi); cam = cm; }
   const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
   const V3 tw = xpoint(cam, target);
   const V3 eye = mk(cam[3], cam[7], cam[11]);
   const V3 dir = normalize(tw - eye);
-
   DRay r;
   r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
   r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
   r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
-  *ray_out = r;
+  return r;
+}
+__device__ __forceinline__ DPath camera_path(const DScene &S, uint32_t slot, uint32_t k, uint32_t uid)
+{
   DPath p;
   p.sample = slot;
   p.T[0] = p.T[1] = p.T[2] = 1.f;
   p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
   p.group = S.target_group;
   p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
-  p.flags = k << 1; p.rng = 0; p.uid = sample_uid(tile_id, k);
-  *path_out = p;
+  p.flags = k << 1; p.rng = 0; p.uid = uid;
+  return p;
+}
+// IMPLICIT camera rays (DScene.cam_uv): with a static camera, and no random stream or sample time keyed by the
+// sample's uid anywhere in the scene, a camera ray is a function of its sample's (u, v) alone, and its path state is a
+// constant but for the sample slot.  k_gen_camera then writes only the (u, v) table the pixel filter needs anyway, and
+// the closest-hit walk and the shading kernel rebuild ray i of level 0 from cam_uv[i] -- ~50 instructions -- instead of
+// reading the 64 + 48 bytes per sample that k_gen_camera would have written (C3: 141 M samples, 15.8 GB less written
+// and 25 GB less read per frame).  The same arithmetic in the same order as camera_ray: the same rays bit for bit.
+__device__ __forceinline__ DRay implicit_camera_ray(const DScene &S, uint32_t i)
+{
+  const double2 uv = reinterpret_cast<const double2 *>(S.cam_uv)[i];
+  return static_camera_ray(S, uv.x, uv.y);
+}
+
+template <bool kMovingCamera>
+__device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, int32_t tile_id, uint32_t k, uint32_t slot,
+    DRay *ray_out, DPath *path_out)
+{
+  if (!kMovingCamera) *ray_out = static_camera_ray(S, u, v);
+  else {
+    double cm[12], cmi[12];
+    xform_at(S.cam_xform, sample_time(S, k), cm, cmi);
+    const double *cam = cm;
+    const V3 target = mk((u - .5) * S.cam_uv_size[0], (v - .5) * S.cam_uv_size[1], -1);
+    const V3 tw = xpoint(cam, target);
+    const V3 eye = mk(cam[3], cam[7], cam[11]);
+    const V3 dir = normalize(tw - eye);
+    DRay r;
+    r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
+    r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
+    r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
+    *ray_out = r;
+  }
+  *path_out = camera_path(S, slot, k, sample_uid(tile_id, k));
 }
 
 // --------------------------------------------------------------- k_gen_camera
@@ -73,6 +105,7 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   s_uv[2 * (size_t) slot + 1] = v;
   (void) time_tab;   // (the same table as S.time_tab)
 
+  if (!kMovingCamera && rays == nullptr) return;      // implicit camera rays: the (u, v) table is all that is needed
   camera_ray<kMovingCamera>(S, u, v, T.id, k, slot, rays + slot, paths + slot);
 }
 
@@ -284,6 +317,9 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
 #ifndef FJ_SHADE_MINB
 #define FJ_SHADE_MINB 3           // resident blocks per CU the register budget is cut for (169 VGPRs as written = 2 waves; 164 = 3: C3 15.8 -> 14.8 ms, C4 269 -> 258)
 #endif
+// (Round 3 tried a lean instantiation without the glass / hair / pathtracing paths for scenes of ConstantShader /
+// PlasticShader only: 138 VGPRs instead of 168, or 128 with 12 spills for a fourth wave -- C3 14.5 ms either way.  The
+// kernel is bound by the attribute gathers themselves, not by occupancy.)
 template <bool kMotion>
 __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeParams sp, const DRay *rays, const DPath *paths,
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths,
@@ -305,8 +341,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   uint32_t sample = 0, rng = 0, uid = 0, tbits = 0;
 
   if (hit) {
-    const DRay r = rays[i];
-    DPath p = paths[i];
+    // (level 0 with implicit camera rays: nothing was written, ray and path state follow from the sample slot)
+    const DRay r = rays ? rays[i] : implicit_camera_ray(S, i);
+    DPath p = rays ? paths[i] : camera_path(S, S.cam_slot0 + i, 0u, 0u);
     sample = p.sample;
     rng = p.rng;
     uid = p.uid;

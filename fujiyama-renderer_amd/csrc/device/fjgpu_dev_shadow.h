@@ -97,6 +97,11 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
     // entered it at t <= 0 < distance, which is all BoxRayIntersect asks for (src/fj_box.cc:73-138).
     const bool deep_inside = active && g_single &&
         Ps.x > sb[0] + 2e-4 && Ps.x < sb[3] - 2e-4 && Ps.y > sb[1] + 2e-4 && Ps.y < sb[4] - 2e-4 && Ps.z > sb[2] + 2e-4 && Ps.z < sb[5] - 2e-4;
+    // (Tried in round 3 and dropped: per-lane LISTS of the lights that are not surely behind the surface -- a cheap first
+    // pass with the light index wave-uniform, then every lane walks its own list, so that the expensive part runs
+    // max-list-length times instead of once per light.  Only 36 % of C3's pairs are lit, yet the loop got slower, 22.8 ->
+    // 27.0 ms (C6 56.7 -> 59.2): per-lane light records are vector loads, the lists of a wave's lanes differ enough that the
+    // longest is ~3/4 of all lights, and both loops in one kernel cost 4 spilled registers.)
     // the light index is wave-uniform: the sample's 72 bytes come through the scalar cache into
     // SGPRs instead of 64 identical vector loads
     for (uint32_t l = 0; l < nl; l++) {

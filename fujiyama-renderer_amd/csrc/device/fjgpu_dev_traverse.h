@@ -85,6 +85,8 @@ struct QueueClaim {
   }
 };
 
+__device__ __forceinline__ DRay implicit_camera_ray(const DScene &S, uint32_t i);      // fjgpu_dev_shade.h
+
 struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
@@ -606,7 +608,7 @@ struct ClosestPolicy {
   __device__ bool fetch(uint32_t k, RayIn *r) const
   {
     const uint32_t i = slot(k);
-    const DRay q = rays[i];
+    const DRay q = rays ? rays[i] : implicit_camera_ray(*S, i);     // (DScene.cam_uv: level 0 of a static camera)
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
     r->tmin = q.tmin; r->tmax = q.tmax;
     r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].flags >> 1) : 0.;   // fjgpu_trace: time 0

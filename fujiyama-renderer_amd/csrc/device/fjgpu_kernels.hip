@@ -138,6 +138,34 @@ __global__ void __launch_bounds__(BLOCK) k_quantize_nodes(const DNode *nodes, ui
   out[i] = q;
 }
 
+// the same for the 8-wide twin (DNode8 -> DNodeQ8); empty slots come out as an inverted box (min 65535, max 0)
+__global__ void __launch_bounds__(BLOCK) k_quantize_nodes8(const DNode8 *nodes, uint32_t n, double ox, double oy, double oz,
+    double cx, double cy, double cz, DNodeQ8 *out)
+{
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const DNode8 *nd = &nodes[i];
+  DNodeQ8 q;
+  const double o[3] = {ox, oy, oz}, c[3] = {cx, cy, cz};
+  for (int k = 0; k < 8; k++) {
+    q.child[k] = nd->child[k];
+    for (int a = 0; a < 3; a++) {
+      const double lo = (double) nd->box[k][2 * a], hi = (double) nd->box[k][2 * a + 1];
+      if (nd->child[k] == FJ_NO_CHILD) { q.q[k][2 * a] = 65535; q.q[k][2 * a + 1] = 0; continue; }
+      double ql = floor((lo - o[a]) / c[a]), qh = ceil((hi - o[a]) / c[a]);
+      if (!(ql >= 0)) ql = 0;
+      if (!(qh <= 65535)) qh = 65535;
+      if (!(qh >= 0)) qh = 0;
+      if (!(ql <= 65535)) ql = 65535;
+      if (o[a] + ql * c[a] > lo && ql > 0) ql -= 1;
+      if (o[a] + qh * c[a] < hi && qh < 65535) qh += 1;
+      q.q[k][2 * a] = (uint16_t) ql;
+      q.q[k][2 * a + 1] = (uint16_t) qh;
+    }
+  }
+  out[i] = q;
+}
+
 // ----------------------------------------------------------- host launchers
 // persistent launches: at most PERSIST_BLOCKS_PER_CU resident blocks per CU
 #define PERSIST_BLOCKS_PER_CU 4
@@ -233,12 +261,10 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
     const DHit *hits, uint32_t n, float *s_accum, DRay *next_rays, DPath *next_paths, DLightRec *lrecs, DCounters *cnt)
 {
   if (n == 0) return 0;
-  if (S.has_motion)
-    hipLaunchKernelGGL(k_shade<true>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
-        s_accum, next_rays, next_paths, lrecs, cnt);
-  else
-    hipLaunchKernelGGL(k_shade<false>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n,
-        s_accum, next_rays, next_paths, lrecs, cnt);
+#define FJ_LAUNCH_SHADE(MOTION) hipLaunchKernelGGL((k_shade<MOTION>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, S, sp, rays, paths, hits, n, \
+    s_accum, next_rays, next_paths, lrecs, cnt)
+  if (S.has_motion) FJ_LAUNCH_SHADE(true); else FJ_LAUNCH_SHADE(false);
+#undef FJ_LAUNCH_SHADE
   LAUNCH_CHECK();
   return 0;
 }
@@ -280,10 +306,12 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
-#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
+#define FJ_LAUNCH_ANYHIT2(COUNT, MULTI, WIDE) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI, WIDE>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
+#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) do { if (S.anyhit_wide) FJ_LAUNCH_ANYHIT2(COUNT, MULTI, true); else FJ_LAUNCH_ANYHIT2(COUNT, MULTI, false); } while (0)
     // (with DScene.shadow_join every queue entry names its instance: the instantiation without the instance-level walk)
     if (S.multi_shadow_groups && !S.shadow_join) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
     else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
+#undef FJ_LAUNCH_ANYHIT2
 #undef FJ_LAUNCH_ANYHIT
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
@@ -300,6 +328,15 @@ int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const 
 {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_quantize_nodes, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, n, origin[0], origin[1], origin[2],
+      cell[0], cell[1], cell[2], out);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_quantize_nodes8(hipStream_t st, const DNode8 *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ8 *out)
+{
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_quantize_nodes8, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, n, origin[0], origin[1], origin[2],
       cell[0], cell[1], cell[2], out);
   LAUNCH_CHECK();
   return 0;

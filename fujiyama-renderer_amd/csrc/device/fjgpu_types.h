@@ -29,6 +29,25 @@ struct DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 64, "DNodeQ must be 64 bytes");
 
+// ---- 8-wide twin of the tree for the lean any-hit walk (host SAH builds; EXPERIMENT, built and used only with the
+// environment variable FJGPU_WIDE8): the same binary tree collapsed to eight children per node, so that a ray makes fewer
+// DEPENDENT node fetches (the walk is bound by the latency of those, profiles/r03_anyhit_bound_experiments.txt).  Measured
+// (profiles/r03_anyhit_wide8_and_perm.txt): 29 % fewer node visits, not the 45 % hoped for, 15 % MORE VALU instructions (eight
+// box tests + eight stack stores per step), C3 walk 64.4 -> 72.7 ms, C2 54.2 -> 60.2, C6 297 -> 333: the 4-wide tree stays.  DNode8 is the builder's f32 form, DNodeQ8 what the walk reads:
+// 128 B = eight 16-byte loads, child k's (min, max) grid words of x, y, z at q[k], same grid as DNodeQ.  Any hit ends
+// a shadow ray, so the children need no distance order: they are stored by decreasing surface area.
+struct DNode8 {
+  float box[8][6];             // child k: (min, max) pairs of x, y, z; empty slots: (FLT_MAX, -FLT_MAX)
+  uint32_t child[8];           // same child refs as DNode (node refs index the DNode8 / DNodeQ8 array)
+  uint32_t pad[8];
+};
+static_assert(sizeof(DNode8) == 256, "DNode8 must be 256 bytes");
+struct DNodeQ8 {
+  uint16_t q[8][6];
+  uint32_t child[8];
+};
+static_assert(sizeof(DNodeQ8) == 128, "DNodeQ8 must be 128 bytes");
+
 #ifndef FJ_CLOSEST_QNODES
 #define FJ_CLOSEST_QNODES 1              // 0: the closest-hit walk reads the 128-byte f32 nodes in every instantiation
 #endif
@@ -128,7 +147,9 @@ struct DAnyInst {
   uint32_t root;
   uint32_t tris_f32;           // 1: f32 records
   int32_t n_prims;
-  uint32_t pad[3];
+  uint32_t node8_base;         // DNodeQ8 array (the 8-wide twin; DScene.anyhit_wide) ...
+  uint32_t root8;              // ... and its root ref
+  uint32_t pad;
 };
 static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 
@@ -190,7 +211,7 @@ struct DScene {
   const DLightSample *light_samples;
   DLightHair *lrec_hair;       // work buffer (set per render call) or null
   uint32_t shadow_queue_cap;   // entries of the shadow-ray queue (a walk never reads past it, whatever the slot counter says)
-  uint32_t pad_sq_;
+  uint32_t cam_slot0;          // implicit camera rays: sample slot of ray 0 of the launch (a level walked in chunks)
   uint32_t *shadow_join;       // work buffer or null.  Lean any-hit walk with shadow groups of several instances: a ray
                                // whose world-space test passes k >= 2 instance boxes is queued k times, once per
                                // instance, and all k entries name one slot here (DShadowRay.tindex = slot + 1; 0 = a
@@ -209,9 +230,11 @@ struct DScene {
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
+  int32_t anyhit_wide;         // every mesh has the 8-wide twin of its tree (DAnyInst.node8_base): the lean any-hit walk reads it
   int32_t incoherent_rays;     // some shader emits two children per hit or diffuse bounces (glass, pathtracing): the
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
-  int32_t pad_inc_;
+  const double *cam_uv;        // implicit camera rays: the (u, v) table of the batch's samples (sample slot = ray index of
+                               // level 0; fjgpu_dev_shade.h) while level 0 is walked and shaded, else null
   const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
                                // (hits are written to the ray's own slot); null = queue order
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
