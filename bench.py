@@ -159,7 +159,12 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
             "cpu_model": cpu_model(), "kind": "port", "sample": desc, "seconds": seconds, "rays": int(rc.total())}
 
 
-PMC_SETS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+# read side: the L2's fabric read requests.  On gfx950 a request carries 64 or 128 bytes and no counter tells them apart
+# (rocprofv3's FETCH_SIZE = 64 B x RDREQ; TCC_BUBBLE, the 128-byte count of gfx942, reads 0) -- calibrated on known byte
+# counts (profiles/r03_fetch_size_calibration.json): random 64-byte record gathers, the node fetch of the walks, move 64 B per
+# request; coalesced streaming reads 128 B.  So 64 x RDREQ is a LOWER bound of the bytes read, 128 x RDREQ an upper one,
+# and the estimate adds, to the lower bound, half of the bytes the kernel reads as coalesced streams (its queue records).
+PMC_SETS = (("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"), ("WRITE_SIZE",),
             ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
 
@@ -390,10 +395,12 @@ def main():
             shadow_name: {"ms": float(sum(s.shadow_walk_ms for s in stats)), "launches": float(sum(s.shadow_walk_launches for s in stats)),
                           "alg": float(counted.shadow_nodes * s_node_walk + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +
                                        counted.shadow_traversed * S_SHADOW) * nf,
-                          "rays": float(counted.shadow_traversed) * nf},
+                          "rays": float(counted.shadow_traversed) * nf,
+                          "streamed_bytes": float(counted.shadow_traversed) * S_SHADOW * nf},
             closest_name: {"ms": float(sum(s.closest_ms - s.sort_ms for s in stats)), "launches": float(sum(s.closest_launches for s in stats)),
                            "alg": float(closest_algorithmic_bytes(counted, s_node_closest, s_prim)) * nf,
-                           "rays": float(counted.rays_traced - counted.rays.shadow) * nf},
+                           "rays": float(counted.rays_traced - counted.rays.shadow) * nf,
+                           "streamed_bytes": float(counted.rays_traced - counted.rays.shadow) * S_RAY_IN * nf},
         }
         kname = max(cand, key=lambda k: cand[k]["ms"])
         K = cand[kname]
@@ -415,15 +422,29 @@ def main():
             pmc = pmc_passes(args, kname)
         launches_per_frame = walk_nl / nf if nf else 1.0
         avg_ms = walk_ms / walk_nl if walk_nl else None
-        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and launches_per_frame and avg_ms:
+        if pmc and "TCC_EA0_RDREQ_sum" in pmc and "WRITE_SIZE" in pmc and launches_per_frame and avg_ms:
+            rd, rd32 = pmc["TCC_EA0_RDREQ_sum"], pmc.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+            read_low = 64.0 * (rd - rd32) + 32.0 * rd32            # every request a 64-byte one (= FETCH_SIZE)
+            read_high = 128.0 * (rd - rd32) + 32.0 * rd32          # every request a 128-byte one
+            # coalesced record streams of this kernel per frame (128-byte requests, tallied at 64 B in the lower bound)
+            streamed = K["streamed_bytes"] / nf
+            read_bytes = read_low + min(0.5 * streamed, read_low)
+            how = ("64 B x TCC_EA0_RDREQ (lower bound: right for the 64-byte node gathers, calibrated) + half of the %.1f GB per frame "
+                   "the kernel reads as coalesced streams (128-byte requests)" % (streamed / 1e9))
             # (per frame in the child -> per launch of this run)
-            traffic = (cal["factor"] * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / launches_per_frame
+            traffic = (read_bytes + pmc["WRITE_SIZE"] * 1024.0) / launches_per_frame
             gbps = traffic / (avg_ms * 1e-3) / 1e9
             hbm = {"GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS, "traffic_bytes_per_launch": traffic,
-                   "FETCH_SIZE_KB_per_frame": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_per_frame": pmc["WRITE_SIZE"],
-                   "fetch_size_factor": cal["factor"], "fetch_size_factor_source": cal["source"], "calibration_pattern": cal["pattern"],
+                   "read_bytes_per_frame": read_bytes, "read_bytes_from": how,
+                   "read_bytes_bounds_per_frame": [read_low, read_high],
+                   "frac_of_peak_bounds": [(read_low + pmc["WRITE_SIZE"] * 1024.0) / launches_per_frame / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                           min(1.0, (read_high + pmc["WRITE_SIZE"] * 1024.0) / launches_per_frame / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)],
+                   "read_requests_per_frame": {"all": rd, "32B": rd32},
+                   "FETCH_SIZE_KB_per_frame_as_rocprofv3_reports_it": rd * 64.0 / 1024.0, "WRITE_SIZE_KB_per_frame": pmc["WRITE_SIZE"],
+                   "calibration": cal,
                    "traffic_over_algorithmic": traffic / (walk_alg / walk_nl) if walk_alg else None,
-                   "note": "bytes the L2s requested from the fabric (Infinity Cache hits are in it: an upper bound of DRAM traffic)"}
+                   "note": "bytes the L2s requested from the fabric (Infinity Cache hits are in it: an upper bound of DRAM traffic); "
+                           "WRITE_SIZE as reported (uncalibrated; 3 % of this kernel's traffic)"}
         if pmc and pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES") and pmc.get("SQ_ACTIVE_INST_VALU"):
             props = torch.cuda.get_device_properties(device)
             simds = props.multi_processor_count * 4

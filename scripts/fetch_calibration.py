@@ -28,7 +28,7 @@ os.makedirs(out, exist_ok=True)
 tool = os.path.join(root, "fujiyama-renderer_amd", "bin", "hbm_gather_calib")
 env = dict(os.environ, TMPDIR="/tmp")
 plain = json.loads(subprocess.run([tool], stdout=subprocess.PIPE, check=True, text=True, cwd="/tmp", env=env).stdout.strip().splitlines()[-1])
-sets = (("FETCH_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_HIT_sum", "TCC_MISS_sum"))
+sets = (("FETCH_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_BUBBLE_sum"), ("TCC_HIT_sum", "TCC_MISS_sum"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(int)
 rows = []
@@ -59,8 +59,16 @@ for name, c in sorted(agg.items()):
         "factor_needed_over_FETCH_SIZE": need / fetch_b if fetch_b else None,
         "TCC_EA0_RDREQ_per_launch": rd, "TCC_EA0_RDREQ_32B_per_launch": c.get("TCC_EA0_RDREQ_32B_sum", 0.0) / nl1,
         "bytes_needed_per_RDREQ": need / rd if rd else None,
+        "TCC_BUBBLE_per_launch": c.get("TCC_BUBBLE_sum", 0.0) / nl1,
+        # a request carries 32, 64 or 128 bytes; TCC_BUBBLE counts the 128-byte ones
+        "bytes_from_request_counters": (128.0 * c.get("TCC_BUBBLE_sum", 0.0) + 64.0 * (c.get("TCC_EA0_RDREQ_sum", 0.0) - c.get("TCC_BUBBLE_sum", 0.0) -
+                                        c.get("TCC_EA0_RDREQ_32B_sum", 0.0)) + 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0.0)) / nl1,
         "L2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)),
+        "needed_over_bytes_from_request_counters": None,
         "ms": plain["kernels"][name]["ms"], "GBps_needed": plain["kernels"][name]["GBps_needed"]}
+for v in res["kernels"].values():
+    if v["bytes_from_request_counters"]:
+        v["needed_over_bytes_from_request_counters"] = v["bytes_needed_per_launch"] / v["bytes_from_request_counters"]
 with open(os.path.join(out, tag + "_fetch_size_calibration.json"), "w") as f:
     json.dump(res, f, indent=1)
 with open(os.path.join(out, tag + "_fetch_size_calibration.csv"), "w") as f:

@@ -31,7 +31,7 @@ def test_bench_line_has_the_contract_fields():
     # a counter-measured HBM fraction (rocprofv3 child passes of the same run): <= 1 by construction
     assert r["traffic"] is not None and r["frac"] is not None, "the rocprofv3 counter passes did not run"
     assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["hbm_counters"]["fetch_size_factor"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
+    assert r["hbm_counters"]["read_bytes_per_frame"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
     assert r["binding_resource"] in ("hbm", "valu")
     # the dominant kernel by measured time, named; the SURVEY 8(d) bytes are kept apart
     assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_trace", "k_trace_closest", "k_trace_closest_phased")
