@@ -374,15 +374,24 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         const unsigned long long busym = __ballot(have && !deep && cur != TRAV_DONE);
         if ((unsigned) __popcll(pendm) >= tune.leaf_wait || busym == 0ull) {
           if (lane == (unsigned) __ffsll((long long) pendm) - 1u) { FJ_CURVE_STAT(2, 1); FJ_CURVE_STAT(3, __popcll(pendm)); }   // second-stage execs / lanes
+          double t = 0, u = 0;
+          bool hitc = false;
+#if FJ_CURVE_COOP
+          // (every lane of the wave: the lanes share the leaf walks of the carried curves, curve_ray_coop)
+          hitc = curve_ray_coop<kMotion>(carrying, P, pend, rtime, oo, od,
+              (CoopWave *) ((char *) (stk.rayspace - threadIdx.x) + (threadIdx.x >> 6) * (14 * 64 * 8)), &t, &u);
+#endif
                 if (carrying) {
             bool stop = false;
             const size_t sl = pend;
             pend = 0xffffffffu;
             const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
-            double t, u = 0;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
-            if (curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
-                          (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace, oo, od}, &t, &u) &&
+#if !FJ_CURVE_COOP
+            hitc = curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
+                          (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace, oo, od}, &t, &u);
+#endif
+            if (hitc &&
                 (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {

@@ -505,19 +505,37 @@ def test_full_size_headline_properties(asset_dir):
         assert float(rel_err(c[yy0:y1, x0:x1], ref[yy0:y1, x0:x1]).max()) <= REL_TOL
 
 
-@pytest.mark.parametrize("builder,expect,tiles", [
-    ("buddhas", (1280, 720, 4, 4), (9 * 40 + 12, 12 * 40 + 20)),          # C2: glass + plastic, 1.09 M triangles x 3
-    ("cornell", (1920, 1080, 16, 16), (16 * 60 + 22, 20 * 60 + 30)),      # C4: pathtracing, 256 spp
-    ("furry", (1920, 1080, 8, 8), (14 * 60 + 28, 17 * 60 + 33)),          # C5: fur curves + hair shader
-    ("ibl", (1920, 1080, 8, 8), (15 * 60 + 25, 18 * 60 + 31)),            # C6: dome light, 256 samples
-], ids=["c2_buddhas", "c4_pathtracing", "c5_furry", "c6_ibl"])
-def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, tiles, asset_dir):
-    """the other BASELINE.json configurations at their FULL size: two whole tiles each against
-    the oracle (reference accelerators, reference recursion) -- same rays per context, same pixels"""
+def _round_number():
+    """the build round (VERDICT.md of the previous round is in the tree from round 2 on): seeds the tile draw below, so
+    that every round's GPU run checks OTHER full-size tiles than the last one did"""
+    import re
+    try:
+        m = re.search(r"VERDICT\s+\S+\s+round\s+(\d+)", open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "VERDICT.md")).read())
+        return int(m.group(1)) + 1 if m else 1
+    except OSError:
+        return 1
+
+
+def _drawn_tiles(builder, n_tiles, count):
+    rng = np.random.RandomState(1000 * _round_number() + sum(ord(c) for c in builder))
+    return sorted(int(t) for t in rng.choice(n_tiles, size=count, replace=False))
+
+
+@pytest.mark.parametrize("builder,expect,count", [
+    ("dragon", (1920, 1080, 8, 8), 12),            # C3 (headline): 7.22 M triangles
+    ("buddhas", (1280, 720, 4, 4), 12),            # C2: glass + plastic, 1.09 M triangles x 16 instances
+    ("cornell", (1920, 1080, 16, 16), 12),         # C4: pathtracing, 256 spp
+    ("furry", (1920, 1080, 8, 8), 8),              # C5: fur curves + hair shader (the oracle's slowest: 8 tiles)
+    ("ibl", (1920, 1080, 8, 8), 12),               # C6: dome light, 256 samples
+], ids=["c3_dragon", "c2_buddhas", "c4_pathtracing", "c5_furry", "c6_ibl"])
+def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, count, asset_dir):
+    """every BASELINE.json configuration at its FULL size: whole tiles, drawn afresh every round from a seeded generator
+    (tile ids in the assertion message), against the oracle (reference accelerators, reference recursion) -- same rays
+    per context, same pixels"""
     import torch
     sp, rd = prepare(workloads.BUILDERS[builder](asset_dir))
     assert (rd.xres, rd.yres, rd.rate_x, rd.rate_y) == expect
-    pick = list(tiles)
+    pick = _drawn_tiles(builder, gpu.tile_count(rd), count)
     gs = gpu.Scene(sp)
     fb = torch.zeros((rd.yres, rd.xres, 4), dtype=torch.float32, device="cuda")
     st = gs.render_tiles(rd, pick, fb.data_ptr())
@@ -526,12 +544,27 @@ def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, tiles, a
     osc = oracle_ffi.OracleScene(sp)
     ref, rc = osc.render(rd, tile_ids=pick)
     osc.close()
-    assert st.rays.as_dict() == rc.as_dict()
-    assert rc.total() > 20 * rc.camera or builder == "cornell"
+    assert st.rays.as_dict() == rc.as_dict(), (pick, st.rays.as_dict(), rc.as_dict())
+    assert rc.total() > 10 * rc.camera or builder == "cornell"
     for t in pick:
         x0, y0, x1, y1 = gpu.tile_rect(rd, t)
-        assert out[y0:y1, x0:x1].any()
-        assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL
+        assert out[y0:y1, x0:x1].any(), (builder, t)
+        assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL, (builder, t, pick)
+
+
+@pytest.mark.skipif(os.environ.get("FJ_SKIP_WHOLE_FRAME") == "1", reason="opted out (FJ_SKIP_WHOLE_FRAME=1)")
+def test_whole_frame_c2_matches_oracle(asset_dir):
+    """C2 (happy_buddhas-class, 1280x720, 16 spp) as a WHOLE frame against the oracle on the host threads (~40 s of CPU):
+    every one of the 920 tiles, ray counts per context equal, every pixel within tolerance"""
+    sp, rd = prepare(workloads.buddhas(asset_dir))
+    gs = gpu.Scene(sp)
+    fb, st = gs.render_frame(rd)
+    gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    assert st.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
 
 
 def test_multi_device_frame_equals_single_device_frame(asset_dir):
