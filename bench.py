@@ -323,6 +323,7 @@ def main():
     my_tiles = fjdist.tiles_of_rank(n_tiles, rank, world)
     if args.as_rank_of > 1 and world == 1:
         my_tiles = fjdist.tiles_of_rank(n_tiles, 0, args.as_rank_of)
+    tile_rects = [gpu.tile_rect(render, t) for t in range(n_tiles)]
     fb = torch.zeros((render.yres, render.xres, 4), dtype=torch.float32, device=device)
     host_fb = torch.empty((render.yres, render.xres, 4), dtype=torch.float32).pin_memory()
     stream = torch.cuda.current_stream(device).cuda_stream
@@ -338,7 +339,7 @@ def main():
                 dist.barrier()
         else:
             st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
-        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world)
+        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world, rects=tile_rects)
         if rank == 0:
             host_fb.copy_(frame, non_blocking=False)       # framebuffer resident in host memory
         return st
@@ -552,17 +553,16 @@ def main():
             # scatter into the frame, the frame's D2H -- all but the exchange itself measured on this GPU (the 7 slabs
             # of <= 4.1 MB each arrive over separate xGMI links: priced at 50 GB/s per link, a third of the link rate)
             G = args.rank_costs
-            ids_r = fjdist.tiles_of_rank(n_tiles, 0, G)
+            slabs = fjdist._DeviceSlabs(fb, tile_rects, n_tiles, render.tile_w, render.tile_h, 0, G)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
             for _ in range(5):
-                slab = fjdist.pack_tiles(fb, ids_r, render.tile_w, render.tile_h)
-                slabs = [slab] * G
-                frame = fjdist.unpack_tiles(slabs, [fjdist.tiles_of_rank(n_tiles, r, G) for r in range(G)], render.xres, render.yres,
-                                            render.tile_w, render.tile_h)
-                host_fb.copy_(frame, non_blocking=False)
+                gpu.pack_tiles(fb.data_ptr(), render.xres, slabs.mine.data_ptr(), slabs.per_rank, slabs.tile_px, slabs.slab.data_ptr(), stream)
+                gpu.unpack_tiles(fb.data_ptr(), render.xres, slabs.all.data_ptr(), G * slabs.per_rank, slabs.tile_px, slabs.recv.data_ptr(), stream)
+                host_fb.copy_(fb, non_blocking=False)
             torch.cuda.synchronize(device)
             tail_ms = (time.perf_counter() - t1) / 5 * 1e3
+            slab = slabs.slab
             xgmi_ms = slab.numel() * 4 / 50e9 * 1e3
             out["config"]["rank_costs_ms"] = {"ranks": G, "per_rank": costs, "max": max(costs),
                                               "speedup_before_gather": out["ms_per_step"] / max(costs),

@@ -84,7 +84,7 @@ struct fjgpu_scene {
   uint8_t *d_apstate = nullptr, *d_acells = nullptr;
   const void *a_owner = nullptr;
   size_t a_samples = 0, a_cell_bytes = 0;
-  struct Level { DRay *rays; DPath *paths; size_t cap; };
+  struct Level { DRay *rays; DPath *paths; size_t cap; uint32_t *keys; };     // keys: sort keys of the level's rays (written by the shading kernel that emits them) or null
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   bool uses_sample_uid;            // some random stream or sample time of the scene is keyed by the sample's uid / index in its tile
   int max_children;                // most child rays one shading event can emit in this scene
@@ -683,7 +683,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     int e = 0;
     e |= W.alloc(samples * 2, &sc->d_suv);
     e |= W.alloc(samples * 4, &sc->d_accum);
-    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
+    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
     e |= W.alloc(rays, &sc->d_hits);
     for (int k = 0; k < 2; k++) {
       e |= W.alloc(rays, &sc->d_lrecs[k]);
@@ -733,6 +733,8 @@ int ensure_level(fjgpu_scene *sc, int level, size_t cap)
   if (L.cap >= cap) return 0;
   DeviceBuffers &W = *sc->work;
   if (W.alloc(cap, &L.rays) || W.alloc(cap, &L.paths)) return -1;   // older, smaller buffers stay owned by `work`
+  L.keys = nullptr;
+  if (sc->ray_sort_bits > 0 && level >= 1 && W.alloc(cap, &L.keys)) return -1;
   L.cap = cap;
   return 0;
 }
@@ -747,6 +749,7 @@ int ensure_sort(fjgpu_scene *sc, size_t cap)
   char *tmp = nullptr;
   if (W.alloc(sc->sort_tmp_bytes, &tmp)) return -1;
   sc->d_sort_tmp = tmp;
+  if (ray_sort_fill_iota(nullptr, sc->d_sort[2], (uint32_t) cap) || hipDeviceSynchronize() != hipSuccess) return -1;   // the sort's values: 0 .. n-1
   sc->sort_cap = cap;
   return 0;
 }
@@ -820,7 +823,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // bounce type only occurs if some shader of the scene emits it
   const int deepest = (sc->bounce_diffuse ? std::max(0, r->max_diffuse_depth) : 0) +
       (sc->bounce_reflect ? std::max(0, r->max_reflect_depth) : 0) + (sc->bounce_refract ? std::max(0, r->max_refract_depth) : 0);
-  if (sc->levels.size() < (size_t) deepest + 1) sc->levels.resize((size_t) deepest + 1, fjgpu_scene::Level{nullptr, nullptr, 0});
+  if (sc->levels.size() < (size_t) deepest + 1) sc->levels.resize((size_t) deepest + 1, fjgpu_scene::Level{nullptr, nullptr, 0, nullptr});
   long bt = sc->batch_tiles;
   if (bt <= 0) {
     const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
@@ -856,7 +859,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     if (bt == 1) return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
     // another process holds part of the HBM: half the batch (the old arena is released first)
     sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0;
-    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; }
+    for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
     sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
     sc->sort_cap = 0;
     bt = std::max<long>(1, bt / 2);
@@ -887,6 +890,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   shp.max_diffuse_depth = r->max_diffuse_depth; shp.max_reflect_depth = r->max_reflect_depth; shp.max_refract_depth = r->max_refract_depth;
   shp.count_all_shadow = (int) sc->count_all_shadow;
   shp.ray_capacity = (uint32_t) cap_rays; shp.light_capacity = (uint32_t) cap_rays;
+  shp.next_keys = nullptr; shp.sort_bits = std::max(1, std::min(9, sc->ray_sort_bits)); shp.pad_ = 0;
+  ray_sort_grid(sc->scene_box, shp.sort_bits, shp.sort_lo, shp.sort_scale);
   ShadowParams swp;
   swp.cos_half_pi = std::cos(3.14159265358979323846 / 2.);
   swp.cos_pi = std::cos(3.14159265358979323846);
@@ -1034,8 +1039,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         int e = 0;
         if (sc->ray_sort_bits > 0 && level >= 1 && (long) n >= g_ray_sort_min) {
           if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");   // (sized with the queues: cannot fail here)
+          // (the keys were written by the shading kernel that emitted these rays: ShadeParams.next_keys)
           e = timed(st, &acc.sort_ms, [&]() {
-            return launch_ray_sort(st, rays, n, sc->scene_box, sc->ray_sort_bits, sc->d_sort[0], sc->d_sort[1], sc->d_sort[2], sc->d_sort[3],
+            return launch_ray_sort_keyed(st, sc->levels[level].keys + off, n, sc->ray_sort_bits, sc->d_sort[1], sc->d_sort[2], sc->d_sort[3],
                 sc->d_sort_tmp, sc->sort_tmp_bytes);
           });
           if (e) return e;
@@ -1053,8 +1059,10 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         DScene Sl = S;
         if (implicit) { Sl.cam_uv = St.cam_uv; Sl.cam_slot0 = off; }
         Sl.lrec_hair = sc->d_lhair[lb];
+        ShadeParams shl = shp;
+        shl.next_keys = (can_emit && sc->ray_sort_bits > 0) ? sc->levels[level + 1].keys : nullptr;
         e = timed(st, &acc.shade_ms, [&]() {
-          return launch_shade(st, Sl, shp, rays, paths, sc->d_hits, n, sc->d_accum,
+          return launch_shade(st, Sl, shl, rays, paths, sc->d_hits, n, sc->d_accum,
               can_emit ? sc->levels[level + 1].rays : nullptr, can_emit ? sc->levels[level + 1].paths : nullptr, sc->d_lrecs[lb], sc->d_cnt);
         });
         if (e) return e;
@@ -1296,6 +1304,22 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
   }
   HIP_TRY(hipMemcpy(h_fb, first->d_frame, npx * 4 * sizeof(float), hipMemcpyDeviceToHost));
   if (stats) for (int d = 0; d < G; d++) stats[d] = sts[d];
+  return 0;
+}
+
+int fjgpu_pack_tiles(const float *d_fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *d_slab, void *hip_stream)
+{
+  if (!d_fb || !d_rects || !d_slab || xres <= 0 || tile_px <= 0 || n_tiles < 0) return fail(FJGPU_EINVAL, "bad tile slab arguments");
+  if (launch_move_tiles(static_cast<hipStream_t>(hip_stream), false, const_cast<float *>(d_fb), xres, d_rects, n_tiles, tile_px, d_slab))
+    return fail(FJGPU_ENODEV, "tile pack launch failed");
+  return 0;
+}
+
+int fjgpu_unpack_tiles(float *d_fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, const float *d_slab, void *hip_stream)
+{
+  if (!d_fb || !d_rects || !d_slab || xres <= 0 || tile_px <= 0 || n_tiles < 0) return fail(FJGPU_EINVAL, "bad tile slab arguments");
+  if (launch_move_tiles(static_cast<hipStream_t>(hip_stream), true, d_fb, xres, d_rects, n_tiles, tile_px, const_cast<float *>(d_slab)))
+    return fail(FJGPU_ENODEV, "tile unpack launch failed");
   return 0;
 }
 

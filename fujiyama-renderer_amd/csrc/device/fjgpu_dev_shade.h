@@ -275,6 +275,30 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t *counter, u
   return want ? slot : 0xffffffffu;
 }
 
+// key of the ray-queue sort: direction octant (3 bits) over the Morton code of the origin's cell in a 2^bits grid per axis
+// over the scene box (fjgpu_raysort.hip sorts (key, index) pairs over exactly these 3 + 3 bits bits)
+__device__ __forceinline__ uint32_t sort_spread3(uint32_t v)      // 10 bits -> every third bit
+{
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__device__ __forceinline__ uint32_t ray_sort_key(V3 o, V3 d, const double *lo, const double *scale, int bits)
+{
+  const double cells = (double) (1u << bits);
+  const double p[3] = {o.x, o.y, o.z};
+  uint32_t c[3];
+  for (int a = 0; a < 3; a++) {
+    double x = (p[a] - lo[a]) * scale[a];
+    x = x < 0. ? 0. : (x > cells - 1. ? cells - 1. : x);        // (NaN compares false twice: cell 0 below)
+    c[a] = x == x ? (uint32_t) x : 0u;
+  }
+  const uint32_t oct = (d.x < 0. ? 1u : 0u) | (d.y < 0. ? 2u : 0u) | (d.z < 0. ? 4u : 0u);
+  return (oct << (3 * bits)) | sort_spread3(c[0]) | (sort_spread3(c[1]) << 1) | (sort_spread3(c[2]) << 2);
+}
+
 struct ChildRay {
   bool want;
   V3 o, d;
@@ -289,7 +313,7 @@ struct ChildRay {
 // `cxt` is uniform per call site (reflect / refract / diffuse children are
 // emitted by separate calls), so the per-context ray count is one atomic per block
 __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
-    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, uint32_t *s_tmp)
+    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, uint32_t *s_tmp, const ShadeParams &sp)
 {
   const uint32_t slot = block_append(c.want, &cnt->next_count, &cnt->rays[cxt], s_tmp);
   if (!c.want) return;
@@ -299,6 +323,7 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t 
   r.d[0] = c.d.x; r.d[1] = c.d.y; r.d[2] = c.d.z;
   r.tmin = c.tmin; r.tmax = c.tmax;
   next_rays[slot] = r;
+  if (sp.next_keys) sp.next_keys[slot] = ray_sort_key(c.o, c.d, sp.sort_lo, sp.sort_scale, sp.sort_bits);
   DPath p;
   p.sample = sample;
   p.T[0] = c.T[0]; p.T[1] = c.T[1]; p.T[2] = c.T[2];
@@ -645,9 +670,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     }
     else cnt->overflow = 1;
   }
-  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
-  emit_child(c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
-  emit_child(c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp);
+  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
+  emit_child(c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
+  emit_child(c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
 }
 
 #endif

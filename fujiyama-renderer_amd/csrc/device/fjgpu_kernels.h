@@ -33,6 +33,11 @@ struct ShadeParams {
   int32_t max_diffuse_depth, max_reflect_depth, max_refract_depth;
   int32_t count_all_shadow;    // 1: trace zero-weight light records too (reference ray counts)
   uint32_t ray_capacity, light_capacity;
+  // ray-queue sort (fjgpu_raysort.hip): the key of a child ray is computed where the ray is emitted -- origin and direction
+  // are in registers there -- instead of by a pass of its own over the queue (C4: 1.6 G rays x 48 B less read per frame)
+  uint32_t *next_keys;         // key of the child in slot k of the next queue, or null (no sort in this scene / for this level)
+  double sort_lo[3], sort_scale[3];
+  int32_t sort_bits, pad_;
 };
 
 struct ShadowParams {

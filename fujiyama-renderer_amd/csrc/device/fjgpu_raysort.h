@@ -21,4 +21,11 @@ size_t ray_sort_temp_bytes(uint32_t n, int bits);
 int launch_ray_sort(hipStream_t st, const DRay *rays, uint32_t n, const double box[6], int bits,
     uint32_t *keys, uint32_t *keys_alt, uint32_t *slots, uint32_t *perm, void *temp, size_t temp_bytes);
 
+// the same with the keys already in place (written by the shading kernel where the rays were emitted, ShadeParams.next_keys);
+// iota: the numbers 0 .. n-1 (ray_sort_fill_iota)
+int launch_ray_sort_keyed(hipStream_t st, const uint32_t *keys, uint32_t n, int bits, uint32_t *keys_alt, const uint32_t *iota, uint32_t *perm,
+    void *temp, size_t temp_bytes);
+int ray_sort_fill_iota(hipStream_t st, uint32_t *iota, uint32_t n);
+void ray_sort_grid(const double box[6], int bits, double lo[3], double scale[3]);
+
 #endif

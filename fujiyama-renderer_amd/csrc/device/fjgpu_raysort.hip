@@ -48,7 +48,39 @@ __global__ void __launch_bounds__(RS_BLOCK) k_ray_sort_keys(const DRay *rays, ui
   slots[i] = i;
 }
 
+__global__ void __launch_bounds__(RS_BLOCK) k_iota(uint32_t *out, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * RS_BLOCK + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
 }  // namespace
+
+void ray_sort_grid(const double box[6], int bits, double lo[3], double scale[3])
+{
+  for (int a = 0; a < 3; a++) {
+    const double w = box[3 + a] - box[a];
+    lo[a] = box[a];
+    scale[a] = w > 0. ? (double) (1u << bits) / w : 0.;
+  }
+}
+
+int ray_sort_fill_iota(hipStream_t st, uint32_t *iota, uint32_t n)
+{
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_iota, dim3((n + RS_BLOCK - 1) / RS_BLOCK), dim3(RS_BLOCK), 0, st, iota, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ray_sort_keyed(hipStream_t st, const uint32_t *keys, uint32_t n, int bits, uint32_t *keys_alt, const uint32_t *iota, uint32_t *perm,
+    void *temp, size_t temp_bytes)
+{
+  if (n == 0) return 0;
+  if (bits < 1) bits = 1;
+  if (bits > 9) bits = 9;
+  if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_alt, iota, perm, (int) n, 0, 3 + 3 * bits, st) != hipSuccess) return -1;
+  return 0;
+}
 
 size_t ray_sort_temp_bytes(uint32_t n, int bits)
 {

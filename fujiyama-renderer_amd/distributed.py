@@ -61,7 +61,29 @@ def _backend_is_device_capable():
         return False
 
 
-def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None):
+class _DeviceSlabs(object):
+    """per-process cache of the device-side plumbing of gather_frame: the tile rectangles of this rank and -- on rank 0 --
+    of every rank in gather order (padding entries have zero area), the send slab and the receive buffer.  Packing and
+    scattering are ONE launch each of the core's k_move_tiles (fjgpu_pack_tiles / fjgpu_unpack_tiles); nothing is
+    allocated per frame."""
+
+    def __init__(self, fb, rects, n_tiles, tile_w, tile_h, rank, world):
+        dev = fb.device
+        self.per_rank = int(math.ceil(n_tiles / float(world)))
+        self.tile_px = tile_w * tile_h
+
+        def table(ids):
+            rows = [list(rects[t]) for t in ids] + [[0, 0, 0, 0]] * (self.per_rank - len(ids))
+            return torch.tensor(rows, dtype=torch.int32, device=dev).contiguous()
+        self.mine = table(tiles_of_rank(n_tiles, rank, world))
+        self.slab = torch.zeros((self.per_rank, tile_h, tile_w, 4), dtype=torch.float32, device=dev)
+        self.all = self.recv = None
+        if rank == 0:
+            self.all = torch.cat([table(tiles_of_rank(n_tiles, r, world)) for r in range(world)], dim=0).contiguous()
+            self.recv = torch.zeros((world, self.per_rank, tile_h, tile_w, 4), dtype=torch.float32, device=dev)
+
+
+def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None, rects=None):
     """Gather every rank's finished tiles to rank 0; returns the assembled
     framebuffer on rank 0 and None elsewhere.  One exchange per frame:
     33.2 MB total at 1080p, <= 4.1 MB per peer.
@@ -79,16 +101,30 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None):
     mode = mode or _state.get("mode") or os.environ.get("FJ_GATHER", "gather")
     per_rank = int(math.ceil(n_tiles / float(world)))
     mine = tiles_of_rank(n_tiles, rank, world)
-    slab = torch.zeros((per_rank, tile_h, tile_w, fb.shape[-1]), dtype=fb.dtype, device=fb.device)
-    if mine:
-        slab[:len(mine)] = pack_tiles(fb, mine, tile_w, tile_h)
-    if not _backend_is_device_capable():
+    dev_path = fb.is_cuda and rects is not None          # (device framebuffer: the core's own pack / scatter kernels)
+    ds = None
+    if dev_path:
+        from . import gpu
+        key = (fb.data_ptr(), n_tiles, tile_w, tile_h, rank, world)
+        if _state.get("slabs_key") != key:
+            _state["slabs"], _state["slabs_key"] = _DeviceSlabs(fb, rects, n_tiles, tile_w, tile_h, rank, world), key
+        ds = _state["slabs"]
+        stream = torch.cuda.current_stream(fb.device).cuda_stream
+        gpu.pack_tiles(fb.data_ptr(), W, ds.mine.data_ptr(), per_rank, ds.tile_px, ds.slab.data_ptr(), stream)
+        slab = ds.slab
+    else:
+        slab = torch.zeros((per_rank, tile_h, tile_w, fb.shape[-1]), dtype=fb.dtype, device=fb.device)
+        if mine:
+            slab[:len(mine)] = pack_tiles(fb, mine, tile_w, tile_h)
+    on_device = _backend_is_device_capable()
+    if not on_device:
         slab = slab.cpu()
     out = None
+    recv = list(ds.recv.unbind(0)) if (ds is not None and rank == 0 and on_device) else None      # views of ONE buffer
     if mode == "gather":
         try:
             if rank == 0:
-                out = [torch.empty_like(slab) for _ in range(world)]
+                out = recv if recv is not None else [torch.empty_like(slab) for _ in range(world)]
                 dist.gather(slab, gather_list=out, dst=0)
             else:
                 dist.gather(slab, gather_list=None, dst=0)
@@ -99,19 +135,32 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None):
             out = None
     if mode == "send_recv":
         if rank == 0:
-            out = [slab] + [torch.empty_like(slab) for _ in range(world - 1)]
+            if recv is not None:
+                recv[0].copy_(slab)
+                out = recv
+            else:
+                out = [slab] + [torch.empty_like(slab) for _ in range(world - 1)]
             for r in range(1, world):
                 dist.recv(out[r], src=r)
         else:
             dist.send(slab, dst=0)
     elif mode == "all_gather":
-        got = [torch.empty_like(slab) for _ in range(world)]
+        got = recv if recv is not None else [torch.empty_like(slab) for _ in range(world)]
         dist.all_gather(got, slab)
         out = got if rank == 0 else None
     elif mode != "gather":
         raise ValueError("unknown gather mode %r" % (mode,))
     if rank != 0:
         return None
+    if ds is not None:
+        # scatter into rank 0's own framebuffer (its own tiles are already there): one launch over all ranks' tiles
+        from . import gpu
+        if recv is None or out is not recv:              # (host-side exchange, gloo: bring the slabs back to the device)
+            for r in range(world):
+                ds.recv[r].copy_(out[r])
+        gpu.unpack_tiles(fb.data_ptr(), W, ds.all.data_ptr(), world * per_rank, ds.tile_px, ds.recv.data_ptr(),
+                         torch.cuda.current_stream(fb.device).cuda_stream)
+        return fb
     frame = unpack_tiles(out, [tiles_of_rank(n_tiles, r, world) for r in range(world)], W, H, tile_w, tile_h)
     return frame.to(fb.device) if frame.device != fb.device else frame
 

@@ -31,6 +31,8 @@ def lib():
         L.fjgpu_scene_create_multi.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         L.fjgpu_render_frame_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ffi.RenderDesc), C.c_void_p, C.c_int,
                                                C.c_void_p, C.POINTER(ffi.GpuStats)]
+        L.fjgpu_pack_tiles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fjgpu_unpack_tiles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.fjgpu_global_option.argtypes = [C.c_char_p, C.c_long]
         L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
@@ -171,3 +173,12 @@ def tile_rect(render, tile_id):
     r = (C.c_int32 * 4)()
     _check(lib().fjgpu_tile_rect(C.byref(render), tile_id, r))
     return tuple(r)
+
+
+def pack_tiles(fb_ptr, xres, rects_ptr, n_tiles, tile_px, slab_ptr, stream=None):
+    """device framebuffer -> tile slab (include/fjgpu.h: fjgpu_pack_tiles); raw device pointers"""
+    _check(lib().fjgpu_pack_tiles(fb_ptr, xres, rects_ptr, n_tiles, tile_px, slab_ptr, stream))
+
+
+def unpack_tiles(fb_ptr, xres, rects_ptr, n_tiles, tile_px, slab_ptr, stream=None):
+    _check(lib().fjgpu_unpack_tiles(fb_ptr, xres, rects_ptr, n_tiles, tile_px, slab_ptr, stream))

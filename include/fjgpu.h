@@ -128,6 +128,14 @@ int fjgpu_scene_create_multi(const fj_scene_desc *desc, const int *devices, int 
 int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_render_desc *render,
     const int32_t *tile_ids, int n_tiles, float *h_framebuffer, fjgpu_stats *stats);
 
+/* Tile slabs of the multi-process split (one process per GPU, bench.py / distributed.py: tile t belongs to rank t % N and
+ * the finished tiles travel to rank 0 in ONE exchange): pack copies the rectangles rects[k] = (xmin, ymin, xmax, ymax)
+ * (DEVICE array, n_tiles x 4 int32) of the DEVICE framebuffer d_fb (xres pixels per row, RGBA f32) into d_slab, tile k at
+ * pixel k * tile_px, rows of the rectangle's own width; unpack is the inverse (a rectangle of zero area is skipped: padding
+ * entries of the shorter ranks).  One kernel launch each on `hip_stream`; no synchronisation. */
+int fjgpu_pack_tiles(const float *d_fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *d_slab, void *hip_stream);
+int fjgpu_unpack_tiles(float *d_fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, const float *d_slab, void *hip_stream);
+
 /* Closest hit of n rays against group `group` (HOST arrays; copied in/out).
  * rays [n][8] = orig xyz, dir xyz, tmin, tmax.  out_t [n] (DBL_MAX on miss),
  * out_ids [n][2] = instance, primitive (-1 on miss), out_uv [n][2] = barycentric

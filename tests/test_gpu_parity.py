@@ -548,8 +548,9 @@ def test_full_size_configs_match_oracle_on_whole_tiles(builder, expect, count, a
     assert rc.total() > 10 * rc.camera or builder == "cornell"
     for t in pick:
         x0, y0, x1, y1 = gpu.tile_rect(rd, t)
-        assert out[y0:y1, x0:x1].any(), (builder, t)
+        # (a tile may be legitimately empty: camera rays that leave between the floor and the dome's rim hit nothing)
         assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL, (builder, t, pick)
+    assert out.any() and ref.any()
 
 
 @pytest.mark.skipif(os.environ.get("FJ_SKIP_WHOLE_FRAME") == "1", reason="opted out (FJ_SKIP_WHOLE_FRAME=1)")
