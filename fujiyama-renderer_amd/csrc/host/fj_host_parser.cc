@@ -187,10 +187,10 @@ struct Parser {
       if (new_id == SI_BADID) { error = g_last_error.empty() ? "command failed" : g_last_error; return -1; }
       names[tok[1]] = new_id;
     } else if (st == SI_FAIL) {
-      // The reference only aborts when status AND id are both bad
-      // (tools/scene_parser/command.cc:731-734), which lets failed property sets
-      // through silently; a silently ignored setting would break parity, so
-      // every failed command is an error here.
+      // CommandResult::IsFail (tools/scene_parser/command.cc:731-734): status SI_FAIL and entry id SI_BADID -- and a
+      // command that makes no entry never sets the id (CommandResult's constructor leaves SI_BADID, :687-690), so a
+      // failed SetProperty* / Assign* aborts the reference's `scene` too (checked against the compiled reference:
+      // tests/test_host_boundary.py::test_failed_commands_abort_like_the_reference).
       error = g_last_error.empty() ? "command failed" : g_last_error;
       return -1;
     }

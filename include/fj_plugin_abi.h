@@ -19,6 +19,16 @@
  * evaluate() is never called: there is no host shading path.  The Sl* functions a DSO
  * imports for evaluate() therefore exist only so that the DSO links; called, they report
  * the error and abort -- a shader without a device twin is refused at SiOpenPlugin.
+ *
+ * Stated limit (SURVEY 8b "How parameters reach the GPU" asks that ANY shader DSO still load and run on a host path
+ * whose Sl* exports are the CPU restatement): this build has NO host shading path by design -- the product must fail
+ * loudly where the HIP path cannot serve, and the CPU restatement is test infrastructure (oracle/) that nothing under
+ * fujiyama-renderer_amd/ may link.  So a foreign shader DSO (the reference tree's own examples: MaterialShader,
+ * SSSShader, VolumeShader -- all SURVEY section 2 out of scope) passes the whole loading protocol -- dlopen, Initialize,
+ * PluginInfo validation with the reference's PlgErrorNo -> SiErrorNo mapping -- and is then refused by SiOpenPlugin with
+ * SI_ERR_FAILLOAD and a message naming the plugin, instead of rendering on the CPU.  A maintainer who wants such a
+ * shader on the device adds its evaluate() to fjgpu_dev_shade.h's switch and its name to kKnownPlugins
+ * (csrc/host/fj_host_scene.cc); tests/test_host_boundary.py pins both behaviours.
  */
 #ifndef FJ_PLUGIN_ABI_H
 #define FJ_PLUGIN_ABI_H
