@@ -452,7 +452,8 @@ def main():
             # persistent waves live for the whole launch: wave cycles / waves per launch = the time (in the
             # counter's own unit) the kernel's launches of one frame were resident, summed over the launches
             elapsed_q = pmc["SQ_WAVE_CYCLES"] * max(pmc.get("_launches", 1.0), 1.0) / pmc["SQ_WAVES"]
-            busy = pmc["SQ_ACTIVE_INST_VALU"] / (simds * elapsed_q)
+            # (waves that leave a launch early make elapsed_q an underestimate: the share is capped at 1)
+            busy = min(1.0, pmc["SQ_ACTIVE_INST_VALU"] / (simds * elapsed_q))
             lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
             issue = {"valu_busy": busy, "lane_efficiency": lane, "useful_valu_issue": busy * lane,
                      "waves_waiting_on_memory": pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],

@@ -79,6 +79,30 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
 #else
 #define PH(i, v) do { } while (0)
 #endif
+// Cache-warming touches (experiment switch FJ_ANYHIT_PREFETCH, bit 0: the first triangle of a leaf when it is set aside,
+// bit 1: the node that goes on top of the stack): one dword of the record is loaded into a register nobody reads, so that
+// the line is on its way (L2 / Infinity Cache) when the walk comes back for it.  The register is the same for the whole
+// kernel and is never reused, so the hardware may write it whenever the data arrives; the compiler's own wait counts only
+// become stricter through an older load it does not know of (loads return in order).
+#ifndef FJ_ANYHIT_PREFETCH
+#define FJ_ANYHIT_PREFETCH 0
+#endif
+#ifndef FJ_ANYHIT_RAY_LDS
+#define FJ_ANYHIT_RAY_LDS 0
+#endif
+#if FJ_ANYHIT_RAY_LDS
+#define AH_RAYV(k) AH_RAY(k)
+#else
+#define AH_RAYV(k) ((k) == 0 ? oo.x : (k) == 1 ? oo.y : (k) == 2 ? oo.z : (k) == 3 ? od.x : (k) == 4 ? od.y : od.z)
+#endif
+#if FJ_ANYHIT_PREFETCH
+#define AH_TOUCH(addr) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_) : "v"(addr))
+#else
+#define AH_TOUCH(addr) do { } while (0)
+#endif
+#define AH_TOUCH_TRI(leaf) AH_TOUCH((const FJ_GLOBAL char *) (S.blas_base + ((size_t) tri_base << 7) + (size_t) (((leaf) & 0x7fffffffu) >> 3) * 36u))
+#define AH_TOUCH_NODE(ref) AH_TOUCH((const FJ_GLOBAL char *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) (ref) << 6)))
+
 #ifdef FJ_EXP_SLAB_VALIDATE
 __device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
 #endif
@@ -113,10 +137,17 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   qc.init(xheads, n, tune.grab);
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
-  V3 oo = mk(0, 0, 0), od = oo;            // object-space ray (f64: the triangle test's operands)
+  // object-space ray (f64: the triangle test's operands).  FJ_ANYHIT_RAY_LDS: it lives in LDS ([k][thread]) instead of in
+  // 12 registers -- only the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
+#if FJ_ANYHIT_RAY_LDS
+  double *s_ray = reinterpret_cast<double *>(s_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
+#define AH_RAY(k) s_ray[(k) * BLOCK + AH_TID()]
+#else
+  V3 oo = mk(0, 0, 0), od = oo;
+#endif
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #ifdef FJ_EXP_SLAB_VALIDATE
-  V3 inv_keep = oo;
+  V3 inv_keep = mk(0, 0, 0);
   int vinst = 0;
 #endif
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
@@ -132,6 +163,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   uint32_t pleaf = TRAV_DONE;
 #endif
   int sp = 0;
+#if FJ_ANYHIT_PREFETCH
+  uint32_t pf_ = 0;
+#endif
   const double tmin = .0001;
 #ifdef FJ_PHASE_STATS
   unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -140,7 +174,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   for (;;) {
     PH(0, 1);
 #if FJ_ANYHIT_POSTPONE
-    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
     const bool fin = cur == TRAV_DONE && pleaf == TRAV_DONE;
     const bool at_inner = cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG);
     const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
@@ -241,7 +275,11 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (A->n_prims == 0) continue;
           const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
           if (has_negative_zero(od_)) continue;
+#if FJ_ANYHIT_RAY_LDS
+          AH_RAY(0) = oo_.x; AH_RAY(1) = oo_.y; AH_RAY(2) = oo_.z; AH_RAY(3) = od_.x; AH_RAY(4) = od_.y; AH_RAY(5) = od_.z;
+#else
           oo = oo_; od = od_;
+#endif
           const V3 inv = mk(filter_rcp(od_.x), filter_rcp(od_.y), filter_rcp(od_.z));
           // the primitive set's own box: only where several instances are tried (a ray that misses
           // it finds no child box at the root either; in the single-instance walk the 12 registers
@@ -323,7 +361,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         }
         cur = (sp == 0) ? TRAV_DONE : pop(sp);
 #if FJ_ANYHIT_POSTPONE
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
 #endif
       }
       if (!kWide && in_now) {
@@ -379,7 +417,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (ee[k] == FJ_NO_CHILD) continue;
             double mn[3], mx[3], td;
             for (int a = 0; a < 3; a++) { const auto pr = dec(ww[3 * k + a], a); mn[a] = pr.first; mx[a] = pr.second; }
-            const bool g = slab(mn, mx, oo, inv_keep, tmin, squeue[idx].tmax, &td);
+            const bool g = slab(mn, mx, mk(AH_RAYV(0), AH_RAYV(1), AH_RAYV(2)), inv_keep, tmin, squeue[idx].tmax, &td);
             if (g && !hh[k]) atomicAdd(&g_slab_lost, 1ull);
             if (hh[k] && !g) atomicAdd(&g_slab_extra, 1ull);
             atomicAdd(&g_slab_tests, 1ull);
@@ -401,6 +439,10 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             // three predicated ones
             uint32_t *top = &AH_LDS(sp);
             top[0] = r1; top[BLOCK] = r2; top[2 * BLOCK] = r3;
+            if ((FJ_ANYHIT_PREFETCH & 2) && nh > 1) {      // the node (or leaf) that is now on top of the stack
+              const uint32_t tp = nh == 2 ? r1 : (nh == 3 ? r2 : r3);
+              if (tp & FJ_LEAF_FLAG) AH_TOUCH_TRI(tp); else AH_TOUCH_NODE(tp);
+            }
             sp += nh - 1;
           } else {
             if (nh > 1) push(sp, r1);
@@ -409,7 +451,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           }
         }
 #if FJ_ANYHIT_POSTPONE
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
 #endif
       }
       }
@@ -431,7 +473,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         V3 v0, v1, v2;
         load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
         FJ_SCHED_FENCE();
-        if (tri_ray_fenced(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+        if (tri_ray_fenced(v0, v1, v2, mk(AH_RAYV(0), AH_RAYV(1), AH_RAYV(2)), mk(AH_RAYV(3), AH_RAYV(4), AH_RAYV(5)), &t, &u, &v) && tmin <= t && t <= tmax) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
 #if FJ_ANYHIT_POSTPONE
           pleaf = TRAV_DONE;
@@ -446,9 +488,13 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       }
     }
   }
+#if FJ_ANYHIT_PREFETCH
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf_));
+#endif
 #undef AH_LDS
 #undef AH_OVF
 #undef AH_TID
+#undef AH_RAY
 #ifdef FJ_PHASE_STATS
   // 0-6 are wave-uniform tallies (lane 0 speaks for the wave); 10 was counted by single lanes
   for (int i = 0; i < 16; i++) {
@@ -471,7 +517,7 @@ template <bool kCount, bool kMulti, bool kWide>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK];
+  __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + (FJ_ANYHIT_RAY_LDS ? 12 * BLOCK : 0)];     // (+ the rays: 6 doubles per thread)
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
   traverse_anyhit<kCount, kMulti, kWide>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
