@@ -88,7 +88,7 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
 #define FJ_ANYHIT_PREFETCH 0
 #endif
 #ifndef FJ_ANYHIT_RAY_LDS
-#define FJ_ANYHIT_RAY_LDS 0
+#define FJ_ANYHIT_RAY_LDS 1
 #endif
 #if FJ_ANYHIT_RAY_LDS
 #define AH_RAYV(k) AH_RAY(k)
@@ -505,10 +505,15 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 }
 
 // blocks per CU (= waves per SIMD): what the registers allow WITHOUT a spill (any spill in the loop
-// doubled the frame time): the instantiation without the instance-BVH walk fits 96 VGPRs = 5 waves,
-// the general one needs 128 = 4 waves.
+// doubled the frame time).  The walk is bound by node-fetch latency x occupancy (profiles/r03_anyhit_bound_experiments.txt:
+// 3 / 4 / 5 waves 85 / 71 / 63.5 ms), so round 3 bought a SIXTH wave: the object-space ray -- 12 registers that only the
+// leaf phase reads -- lives in LDS (FJ_ANYHIT_RAY_LDS) next to a stack of 12 instead of 24 entries (deeper ones in the global
+// overflow area), which brings the instantiation without the instance-BVH walk to 80 VGPRs, no spill: C3 63.3 -> 60.4 ms, C6
+// 294.5 -> 281.9, C2 53.8 -> 52.0 (profiles/r03_exp13_six_waves.txt).  A seventh wave (72 VGPRs: 10 spills, 8 stack entries)
+// loses again: 67.4 ms.  The general instantiation needs 98 = 4 waves.  Cache-warming touches of the node / triangle a lane
+// will come back to (FJ_ANYHIT_PREFETCH) cost more in L1 requests than they save: 63.3 -> 68.3 / 70.1 / 75.6 ms.
 #ifndef FJ_ANYHIT_MINB
-#define FJ_ANYHIT_MINB 5
+#define FJ_ANYHIT_MINB 6
 #endif
 #ifndef FJ_ANYHIT_MINB_MULTI
 #define FJ_ANYHIT_MINB_MULTI 4

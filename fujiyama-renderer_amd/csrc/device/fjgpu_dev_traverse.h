@@ -87,13 +87,6 @@ struct QueueClaim {
 
 __device__ __forceinline__ DRay implicit_camera_ray(const DScene &S, uint32_t i);      // fjgpu_dev_shade.h
 
-#ifndef FJ_PHASED_RAY_LDS
-#define FJ_PHASED_RAY_LDS 0
-#endif
-#ifndef FJ_STACK_LDS_PHASED
-#define FJ_STACK_LDS_PHASED FJ_STACK_LDS
-#endif
-
 struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
@@ -442,15 +435,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
   qc.init(head, n, tune.grab);
   bool have = false;
   uint32_t idx = 0;
-  // FJ_PHASED_RAY_LDS: the object-space ray and the best hit's barycentrics live in LDS ([k][thread]; only the leaf phase
-  // touches them), and the world-space ray is read again from the queue when a lane moves on to its next instance, instead
-  // of 28 registers carried through the walk: 96 VGPRs = a fifth wave per SIMD
-#if FJ_PHASED_RAY_LDS
-  double *s_ray = reinterpret_cast<double *>(stk.lds - threadIdx.x + FJ_STACK_LDS_PHASED * BLOCK) + threadIdx.x;
-#define PH_RAY(k) s_ray[(k) * BLOCK]
-#else
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o;
-#endif
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double tmin = 0, tmax = 0, rtime = 0;
   Best best;
@@ -484,10 +469,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
           have = pol.fetch(my, &r);
           idx = my;
-#if !FJ_PHASED_RAY_LDS
-          o = r.o; d = r.d;
-#endif
-          tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           if (kMotion) rtime = r.time;
           group = r.group;
           ti = S.groups[group].first; tend = ti + S.groups[group].count;
@@ -500,10 +482,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       if (fin && have) {
         bool found = false;
         uint32_t root = TRAV_DONE;
-#if FJ_PHASED_RAY_LDS
-        V3 o, d, oo = mk(0, 0, 0), od = oo;
-        { RayIn r2; r2.o = r2.d = mk(0, 0, 1); r2.tmin = r2.tmax = r2.time = 0; r2.group = 0; r2.anyhit = false; pol.fetch(idx, &r2); o = r2.o; d = r2.d; }
-#endif
         const bool dead_ray = has_negative_zero(d);   // every box test of the reference fails (BoxRayIntersect's -0.0 quirk)
         const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
         const bool plain = plain_dir(d);
@@ -545,10 +523,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           found = true;
           break;
         }
-#if FJ_PHASED_RAY_LDS
-        if (found) { PH_RAY(0) = oo.x; PH_RAY(1) = oo.y; PH_RAY(2) = oo.z; PH_RAY(3) = od.x; PH_RAY(4) = od.y; PH_RAY(5) = od.z; }
-        else if (best.inst >= 0) { best.u = PH_RAY(6); best.v = PH_RAY(7); }
-#endif
         if (found) { cur = root; sp = 0; }
         else { pol.finish(idx, best); have = false; }
       }
@@ -616,24 +590,13 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           const FJ_GLOBAL double *w = FJ_G(double, P->tri_vel) + (size_t) first * 9;
           v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
         }
-#if FJ_PHASED_RAY_LDS
-        const V3 oo = mk(PH_RAY(0), PH_RAY(1), PH_RAY(2)), od = mk(PH_RAY(3), PH_RAY(4), PH_RAY(5));
-#endif
         if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
           const int pid = (int) FJ_G(uint32_t, P->prim_ids)[first];
           if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
-            best.t = t; best.inst = ii; best.prim = pid;
-#if FJ_PHASED_RAY_LDS
-            PH_RAY(6) = u; PH_RAY(7) = v;
-#else
-            best.u = u; best.v = v;
-#endif
+            best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
             stop = anyhit;
           }
         }
-#if FJ_PHASED_RAY_LDS
-        if (stop) { best.u = PH_RAY(6); best.v = PH_RAY(7); }
-#endif
         if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
@@ -710,11 +673,11 @@ template <bool kCount>
 __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS_PHASED * BLOCK + (FJ_PHASED_RAY_LDS ? 16 * BLOCK : 0)];      // (+ 8 doubles per thread)
+  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS_PHASED), &lc);
+  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

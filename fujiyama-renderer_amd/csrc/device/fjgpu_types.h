@@ -67,12 +67,13 @@ static_assert(sizeof(DNodeQ8) == 128, "DNodeQ8 must be 128 bytes");
 #ifndef FJ_STACK_LDS_CURVES
 #define FJ_STACK_LDS_CURVES 24
 #endif
-// the lean any-hit walk runs more blocks per CU: 24 entries x 1 KB per block
+// the lean any-hit walk runs SIX blocks per CU: 12 entries x 1 KB per block + 12 KB for the object-space rays
+// (FJ_ANYHIT_RAY_LDS, fjgpu_dev_anyhit.h) = 24 KB per block; 14 entries: the same time
 #ifndef FJ_STACK_LDS_ANYHIT
-#define FJ_STACK_LDS_ANYHIT 24
+#define FJ_STACK_LDS_ANYHIT 12
 #endif
 #ifndef FJ_STACK_LDS_MIN
-#define FJ_STACK_LDS_MIN 24          // smallest of the three (sizes the global overflow area)
+#define FJ_STACK_LDS_MIN 12          // smallest of the three (sizes the global overflow area)
 #endif
 
 // ---- primitive set (one mesh or one curve set): its BLAS + attribute arrays
