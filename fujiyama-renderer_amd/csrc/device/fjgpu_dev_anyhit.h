@@ -516,7 +516,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #define FJ_ANYHIT_MINB 6
 #endif
 #ifndef FJ_ANYHIT_MINB_MULTI
-#define FJ_ANYHIT_MINB_MULTI 4
+#define FJ_ANYHIT_MINB_MULTI 5          // (96 VGPRs, no spill: C2 without the split 134.5 -> 124.1 ms; with the split 117.9)
 #endif
 template <bool kCount, bool kMulti, bool kWide>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,

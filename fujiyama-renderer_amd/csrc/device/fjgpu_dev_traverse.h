@@ -158,6 +158,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   int sp = 0;
 #ifdef FJ_PHASE_STATS
   unsigned long long it_all = 0, it_tail = 0;   // wave iterations; ... after the queue ran dry for this wave
+  // wave-level clock ticks per phase (s_memtime): refill+entry, inner steps, leaf phase, second stage of the ribbon test
+  unsigned long long cyc[4] = {0, 0, 0, 0}, c_prev = __builtin_readcyclecounter();
+#define FJ_CYC(k) do { const unsigned long long c_now = __builtin_readcyclecounter(); cyc[k] += c_now - c_prev; c_prev = c_now; } while (0)
+#else
+#define FJ_CYC(k) do { } while (0)
 #endif
 
   for (;;) {
@@ -198,7 +203,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       if (__ballot(have) == 0ull) {
         if (next >= range_end && !head_live) {
 #ifdef FJ_PHASE_STATS
-          if (lane == 0) { atomicMax(&g_phase[12], it_tail); atomicAdd(&g_phase[13], it_tail); atomicAdd(&g_phase[14], it_all); atomicAdd(&g_phase[15], 1ull); }
+          if (lane == 0) { atomicMax(&g_phase[12], it_tail); atomicAdd(&g_phase[13], it_tail); atomicAdd(&g_phase[14], it_all); atomicAdd(&g_phase[15], 1ull);
+            atomicAdd(&g_phase[1], cyc[0]); atomicAdd(&g_phase[3], cyc[1]); atomicAdd(&g_phase[5], cyc[2]); atomicAdd(&g_phase[7], cyc[3]); }
 #endif
           break;
         }
@@ -206,6 +212,10 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       }
     }
 
+    // (Round 3 measured the phases of this walk on C5 in clock ticks -- debug build: instance entry 24 %, inner steps 38 % with 24
+    // of 64 lanes, leaf phase 18 %, second stage of the ribbon test 20 % -- and tried GATING them like the lean any-hit walk does,
+    // a block running only with at least 8..64 lanes in it or when it is the fullest: 1733 -> 1755 .. 1864 ms, monotonically worse
+    // with the thresholds.  Here lanes waiting for "their" phase cost more than running every phase with whoever is there.)
     // ---- lanes between instances: enter the next instance or retire the ray
     if (have && cur == TRAV_DONE && (!kCurves || pend == 0xffffffffu)) {
       bool found = false;
@@ -267,6 +277,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       else { pol.finish(idx, best); have = false; }
     }
 
+    FJ_CYC(0);
     // ---- inner nodes: a few steps for every lane that holds one
     for (int step = 0; step < TRAV_STEPS; step++) {
       const bool inner = have && !(cur & FJ_LEAF_FLAG);
@@ -316,6 +327,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       }
     }
 
+    FJ_CYC(1);
     // ---- leaves: FP64 Moller-Trumbore on the pre-gathered triangles; curve leaves (always a
     // single curve, fjgpu_curve_build.cc) only take the first stage of the ribbon test here --
     // does the curve's ray-space box reach the ray? -- and wait for the second stage below
@@ -363,6 +375,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
       else if (!deep) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
     }
 
+    FJ_CYC(2);
     // ---- second stage of the ribbon test (the recursive subdivision, long and divergent:
     // PMC on C5 showed 8.8 of 64 lanes active per VALU instruction when every lane ran it as
     // soon as it reached a curve): it waits until enough lanes need it, or nobody can walk on
@@ -413,6 +426,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         }
       }
     }
+    FJ_CYC(3);
   }
 }
 

@@ -372,9 +372,11 @@ void debug_phase_stats()
   }
   unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
-  static const char *names[16] = {"iters", "entry_execs", "entry_lanes", "inner_execs", "inner_lanes", "leaf_execs", "leaf_lanes",
-      "tri_execs", "tri_lanes", "", "hits", "refills", "tail_iters_max", "tail_iters_sum", "walk_iters_sum", "walk_waves"};
-  for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-12s %llu\n", names[i], h[i]);
+  // (the general walk, traverse_persistent, reports clock ticks per phase in slots 1 / 3 / 5 / 7: refill + instance entry, inner steps,
+  //  leaf phase, second stage of the ribbon test; the lean any-hit walk reports executions / lanes there)
+  static const char *names[16] = {"iters", "entry_execs|entry_ticks", "entry_lanes", "inner_execs|inner_ticks", "inner_lanes", "leaf_execs|leaf_ticks", "leaf_lanes",
+      "tri_execs|stage2_ticks", "tri_lanes", "", "hits", "refills", "tail_iters_max", "tail_iters_sum", "walk_iters_sum", "walk_waves"};
+  for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-24s %llu\n", names[i], h[i]);
   unsigned long long z[16] = {0};
   (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
 #endif
