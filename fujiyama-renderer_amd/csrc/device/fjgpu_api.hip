@@ -234,6 +234,11 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (device < 0 || device >= ndev) return fail(FJGPU_EINVAL, "device index out of range");
   HIP_TRY(hipSetDevice(device));
 
+  const auto t_up0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (getenv("FJGPU_VERBOSE")) { (void) hipDeviceSynchronize(); fprintf(stderr, "fjgpu: upload: %-28s at %.3f s\n", what,
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up0).count()); }
+  };
   std::unique_ptr<fjgpu_scene> sc(new fjgpu_scene());
   sc->device = device;
   sc->batch_tiles = g_batch_tiles;
@@ -303,6 +308,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       e |= M.upload(h.curve_vel.data(), h.curve_vel.size(), &d.curve_vel);
     }
   }
+  lap("primitive sets");
   std::vector<DTexture> dtex(desc->n_textures);
   for (int i = 0; i < desc->n_textures; i++) {
     const fj_texture_desc &t = desc->textures[i];
@@ -353,6 +359,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       q8[i] = q;
     }
     S.anyhit_wide = (wide_all && any_mesh && getenv("FJGPU_WIDE8")) ? 1 : 0;
+    lap("quantised nodes");
     e |= M.upload(dps.data(), dps.size(), &S.primsets);      // (after the loops above: DPrimSet.qnodes is set)
     {
       // the instance table, each record with a copy of its primitive set's entry data
@@ -544,6 +551,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   sc->ray_sort_bits = g_ray_sort >= 0 ? (int) g_ray_sort : (S.incoherent_rays && !S.has_curves && !S.has_motion ? FJ_RAY_SORT_BITS : 0);
   if (const char *e = getenv("FJGPU_RAY_SORT")) sc->ray_sort_bits = std::max(0, std::min(9, atoi(e)));
   HIP_TRY(hipDeviceSynchronize());
+  lap("done");
   *out = sc.release();
   return 0;
 }

@@ -408,6 +408,53 @@ struct Collapse8 {
 
 }  // namespace
 
+int BuildTopTree(const float *boxes6, int K, std::vector<TopNode> *out, int32_t *root)
+{
+  out->clear();
+  if (K < 1) return -1;
+  if (K == 1) { *root = ~0; return 0; }
+  Builder b;
+  b.prims.resize((size_t) K);
+  for (int i = 0; i < K; i++) {
+    PrimRef &r = b.prims[i];
+    for (int c = 0; c < 3; c++) { r.bmin[c] = boxes6[6 * i + c]; r.bmax[c] = boxes6[6 * i + 3 + c]; r.c[c] = .5f * (r.bmin[c] + r.bmax[c]); }
+    r.id = (uint32_t) i;
+  }
+  b.nodes.reset(new Node2[(size_t) K + 2048]);
+  b.next_node = 0;
+  b.max_depth = 0;
+  b.max_leaf = 1;                      // one cluster per leaf
+  b.trav_cost = 1.2f;
+  float mn[3], mx[3];
+  ChunkAlloc alloc(&b.next_node);
+  const uint32_t r2 = b.build(0, K, 0, 0, mn, mx, alloc);
+  // Node2 tree -> TopNode list (children first is not needed: indices are assigned on the way down)
+  struct Walk {
+    const Builder &b; std::vector<TopNode> &out;
+    int32_t go(uint32_t ref, float *bmn, float *bmx)
+    {
+      if (ref & FJ_LEAF_FLAG) {
+        const uint32_t begin = (ref & 0x7fffffffu) >> 3;       // (count - 1 == 0)
+        const PrimRef &p = b.prims[begin];
+        for (int c = 0; c < 3; c++) { bmn[c] = p.bmin[c]; bmx[c] = p.bmax[c]; }
+        return ~(int32_t) p.id;
+      }
+      const Node2 &n = b.nodes[ref];
+      const int32_t me = (int32_t) out.size();
+      out.push_back(TopNode());
+      float a[3], c[3], e[3], f[3];
+      const int32_t l = go(n.lc, a, c), r = go(n.rc, e, f);
+      TopNode &t = out[(size_t) me];
+      t.left = l; t.right = r;
+      for (int k = 0; k < 3; k++) { bmn[k] = std::min(a[k], e[k]); bmx[k] = std::max(c[k], f[k]); t.box[k] = bmn[k]; t.box[3 + k] = bmx[k]; }
+      return me;
+    }
+  } w{b, *out};
+  float bmn[3], bmx[3];
+  *root = w.go(r2, bmn, bmx);
+  return 0;
+}
+
 float RoundDown2(double v) { return down2(v); }
 float RoundUp2(double v) { return up2(v); }
 

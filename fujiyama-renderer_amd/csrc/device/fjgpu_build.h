@@ -79,6 +79,10 @@ struct HostScene {
 // BLAS build over arbitrary primitive boxes (meshes and curve sets share it)
 struct PrimRef { float bmin[3], bmax[3], c[3]; uint32_t id; };
 void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float trav_cost);
+// Binned-SAH binary tree over K boxes with ONE box per leaf: the top of a device-built BLAS over the clusters its
+// agglomeration has formed so far (fjgpu_lbvh.hip).  nodes[i].left / right >= 0: index of another TopNode; < 0: ~(box index).
+struct TopNode { int32_t left, right; float box[6]; };
+int BuildTopTree(const float *boxes6, int K, std::vector<TopNode> *nodes, int32_t *root);
 float RoundDown2(double v);   // f64 -> f32 toward -inf, one more ulp outward
 float RoundUp2(double v);
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "fjgpu_lbvh.h"
+#include "fjgpu_build.h"
 
 namespace {
 
@@ -214,6 +215,16 @@ __global__ void __launch_bounds__(LB) k_ploc_mark(const uint32_t *NN, int c, uns
   unsigned long long m = 0;
   if ((int) NN[j] == i) m = i < j ? (1ull << 32) : 1ull;
   marks[i] = m;
+}
+
+// boxes and leaf counts of the current clusters, packed (the host builds the top of the tree over them)
+__global__ void __launch_bounds__(LB) k_cluster_boxes(const uint32_t *C, int c, BTree T, float *boxes6, uint32_t *counts)
+{
+  const int i = blockIdx.x * LB + threadIdx.x;
+  if (i >= c) return;
+  const Box6 b = T.box[C[i]];
+  for (int k = 0; k < 3; k++) { boxes6[6 * i + k] = b.mn[k]; boxes6[6 * i + 3 + k] = b.mx[k]; }
+  counts[i] = T.count[C[i]];
 }
 
 __global__ void __launch_bounds__(LB) k_ploc_apply(const uint32_t *C, int c, const uint32_t *NN, const unsigned long long *marks,
@@ -429,7 +440,13 @@ int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, 
     int c = n;
     uint32_t next_node = (uint32_t) n;
     int rounds = 0;
-    while (c > 1) {
+    // HYBRID TOP: agglomeration is at its best near the leaves (small clusters, neighbours in the Morton window) and at its
+    // worst near the root, where every ray passes.  So the clustering stops once at most `top` clusters are left, and the tree
+    // ABOVE them is a binned-SAH build over the clusters' boxes on the host (BuildTopTree: microseconds for 10^4 boxes).
+    int top = 65536;                   // C3: 0 / 1 k / 8 k / 64 k / 512 k / 2 M clusters: 137.6 / 138.3 / 135.5 / 133.8 / 134.2 / 131.7 ms per frame (host tree: 129.4),
+                                       // prepare 0.49 / . / 0.48 / 0.48 / 0.74 / 1.45 s (host build: 1.0 - 2.5 s)
+    if (const char *e = getenv("FJGPU_PLOC_TOP")) top = atoi(e);
+    while (c > 1 && c > top) {
       const unsigned g = (unsigned) ((c + LB - 1) / LB);
       hipLaunchKernelGGL(k_ploc_nearest, dim3(g), dim3(LB), 0, 0, c0, c, radius, T.box, nn);
       hipLaunchKernelGGL(k_ploc_mark, dim3(g), dim3(LB), 0, 0, nn, c, marks);
@@ -445,6 +462,38 @@ int LbvhBuildMesh(const double *d_P, const double *d_vel, const int32_t *d_idx, 
       std::swap(c0, c1);
       rounds++;
     }
+    if (c > 1) {
+      // the top of the tree over the c remaining clusters
+      float *d_b6 = nullptr; uint32_t *d_cnt = nullptr;
+      LB_TRY(dalloc(&d_b6, (size_t) 6 * c)); LB_TRY(dalloc(&d_cnt, (size_t) c));
+      hipLaunchKernelGGL(k_cluster_boxes, dim3((unsigned) ((c + LB - 1) / LB)), dim3(LB), 0, 0, c0, c, T, d_b6, d_cnt);
+      std::vector<float> b6((size_t) 6 * c);
+      std::vector<uint32_t> cnt((size_t) c), cid((size_t) c);
+      LB_TRY(hipMemcpy(b6.data(), d_b6, sizeof(float) * b6.size(), hipMemcpyDeviceToHost));
+      LB_TRY(hipMemcpy(cnt.data(), d_cnt, sizeof(uint32_t) * cnt.size(), hipMemcpyDeviceToHost));
+      LB_TRY(hipMemcpy(cid.data(), c0, sizeof(uint32_t) * cid.size(), hipMemcpyDeviceToHost));
+      (void) hipFree(d_b6); (void) hipFree(d_cnt);
+      std::vector<fjgpu::TopNode> tn;
+      int32_t troot = 0;
+      if (fjgpu::BuildTopTree(b6.data(), c, &tn, &troot) || tn.size() != (size_t) c - 1) { *err = "device BLAS build: top tree failed"; goto fail; }
+      const size_t m = tn.size();
+      std::vector<uint32_t> hl(m), hr(m), hc(m, 0u);
+      std::vector<Box6> hb(m);
+      auto id_of = [&](int32_t ch) { return ch >= 0 ? next_node + (uint32_t) ch : cid[(size_t) ~ch]; };
+      // counts bottom-up: children of a TopNode have larger indices (pre-order numbering)
+      for (size_t i = m; i-- > 0;) {
+        const fjgpu::TopNode &t = tn[i];
+        hl[i] = id_of(t.left); hr[i] = id_of(t.right);
+        hc[i] = (t.left >= 0 ? hc[(size_t) t.left] : cnt[(size_t) ~t.left]) + (t.right >= 0 ? hc[(size_t) t.right] : cnt[(size_t) ~t.right]);
+        for (int k = 0; k < 3; k++) { hb[i].mn[k] = t.box[k]; hb[i].mx[k] = t.box[3 + k]; }
+      }
+      LB_TRY(hipMemcpy(T.left + next_node, hl.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice));
+      LB_TRY(hipMemcpy(T.right + next_node, hr.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice));
+      LB_TRY(hipMemcpy(T.count + next_node, hc.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice));
+      LB_TRY(hipMemcpy(T.box + next_node, hb.data(), sizeof(Box6) * m, hipMemcpyHostToDevice));
+      root2 = id_of(troot);
+      if (getenv("FJGPU_VERBOSE") && n > 100000) fprintf(stderr, "fjgpu: clustering build: top of the tree over %d clusters by binned SAH\n", c);
+    } else
     LB_TRY(hipMemcpy(&root2, c0, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (getenv("FJGPU_VERBOSE") && n > 100000) fprintf(stderr, "fjgpu: clustering build: %d rounds, window radius %d\n", rounds, radius);
   }
