@@ -372,6 +372,16 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         for (int k = 0; k < 3; k++) { I.qorigin[k] = qgrid[I.primset][k]; I.qcell[k] = qgrid[I.primset][3 + k]; }
       }
       e |= M.upload(di.data(), di.size(), &S.instances);
+      std::vector<DInstEntry> ie(di.size());
+      for (size_t k = 0; k < di.size(); k++) {
+        const DInstance &I = di[k];
+        DInstEntry &E = ie[k];
+        std::memcpy(E.Minv, I.Minv, sizeof(E.Minv));
+        std::memcpy(E.pbounds, I.pbounds, sizeof(E.pbounds));
+        for (int a = 0; a < 3; a++) { E.qorigin[a] = I.qorigin[a]; E.qcell[a] = I.qcell[a]; }
+        E.pqnodes = I.pqnodes; E.pnodes = I.pnodes; E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
+      }
+      e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
     }
     // flat per-instance records of that walk (static mesh instances): node and triangle arrays
     // as 32-bit offsets from the lowest of their addresses
@@ -441,10 +451,13 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     for (size_t g = 0; g < groups.size(); g++) { groups[g].first = nfirst[g]; groups[g].count = ncount[g]; }
     e |= M.upload(groups.data(), groups.size(), &S.groups);
     S.group_nodes = d_nodes;
+    S.n_group_nodes = (int32_t) total;
   } else {
     e |= M.upload(hs.groups.data(), hs.groups.size(), &S.groups);
     e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
+    S.n_group_nodes = (int32_t) hs.group_nodes.size();
   }
+  S.inst_lds = (S.n_group_nodes <= FJ_INST_LDS_NODES && (int) hs.instances.size() <= FJ_INST_LDS_INSTS && !getenv("FJGPU_NO_INST_LDS")) ? 1 : 0;
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
   S.cam_xform = nullptr;

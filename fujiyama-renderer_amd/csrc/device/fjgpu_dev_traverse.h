@@ -438,9 +438,13 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 // else can run -- instead of every phase in turn with whoever happens to be there.  The leaf phase
 // tests one triangle per lane and execution.  Same tests, same order per ray (instances in the
 // group's order, children near to far, the leaf's triangles in slot order), same tie rules.
-template <bool kCount, bool kMotion, class Policy>
-__device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
+// kInstLds: the scene's instance level (DTNodes, then one DInstEntry per instance) sits in LDS at s_inst (DScene.inst_lds;
+// filled by the kernel); otherwise the same records are read from DScene.group_nodes / inst_entries.
+template <bool kCount, bool kMotion, bool kInstLds, class Policy>
+__device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
+  const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
+  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + FJ_INST_LDS_NODES * 7) : S.inst_entries;
   const unsigned lane = __lane_id();
   bool head_live = true;
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
@@ -461,6 +465,13 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
   const DNode *nodes = nullptr;
   uint32_t cur = TRAV_DONE;
   int sp = 0;
+#ifdef FJ_PHASE_STATS
+  // wave-level clock ticks, executions and lanes per phase; the instance loop's trips summed over lanes / as the wave's maximum
+  unsigned long long pcyc[3] = {0, 0, 0}, pex[3] = {0, 0, 0}, pln[3] = {0, 0, 0}, trips_lane = 0, trips_wave = 0, pc_prev = __builtin_readcyclecounter();
+#define FJ_PCYC(k, mask) do { const unsigned long long c_now = __builtin_readcyclecounter(); pcyc[k] += c_now - pc_prev; pc_prev = c_now; pex[k]++; pln[k] += __popcll(mask); } while (0)
+#else
+#define FJ_PCYC(k, mask) do { } while (0)
+#endif
 
   for (;;) {
     const bool fin = cur == TRAV_DONE;
@@ -471,7 +482,15 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
 
     if ((unsigned) __popcll(m_turn) >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
-      if (m_turn == 0ull) break;
+      if (m_turn == 0ull) {
+#ifdef FJ_PHASE_STATS
+        if (lane == 0) {
+          for (int k = 0; k < 3; k++) { atomicAdd(&g_phase[1 + 2 * k], pcyc[k]); atomicAdd(&g_phase[2 + 2 * k], pln[k]); atomicAdd(&g_phase[7 + k], pex[k]); }
+          atomicAdd(&g_phase[10], trips_lane); atomicAdd(&g_phase[11], trips_wave);
+        }
+#endif
+        break;
+      }
       // ---- turnover: fetch, enter the next instance, or retire
       if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
       const bool fetch = fin && !have;
@@ -493,6 +512,9 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       }
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
+#ifdef FJ_PHASE_STATS
+      unsigned my_trips = 0;
+#endif
       if (fin && have) {
         bool found = false;
         uint32_t root = TRAV_DONE;
@@ -502,7 +524,10 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         const bool single = S.groups[group].n_instances == 1;
         const double *gsb = S.groups[group].sbounds;
         while (!dead_ray && ti < tend) {
-          const DTNode *tn_ = &S.group_nodes[ti];
+#ifdef FJ_PHASE_STATS
+          my_trips++;
+#endif
+          const DTNode *tn_ = &gnodes[ti];
           if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
             double tq;
             ti = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? ti + 1 : tn_->skip;
@@ -510,12 +535,17 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           }
           ii = tn_->inst;
           ti++;
-          const DInstance *I = &S.instances[ii];
+          const DInstEntry *I = &gents[ii];
           if (kCount) lc->insts++;
           double tn;
           const double tfar = anyhit ? tmax : fmin(tmax, best.t);
           // the reference's own (possibly non-enclosing) instance box, full ray range
-          if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
+          if (kInstLds) {                  // (values, not a pointer: the two sources sit in different address spaces)
+            double ibox[6];
+            if (single) { for (int k = 0; k < 6; k++) ibox[k] = gsb[k]; }
+            else { for (int k = 0; k < 6; k++) ibox[k] = tn_->box[k]; }
+            if (!box_ray_ref_fast(ibox, o, d, winv, plain, tmin, tmax)) continue;
+          } else if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
           if (kMotion && I->xform >= 0) {
             double tm[12], tmi[12];
             xform_at(&S.xforms[I->xform], rtime, tm, tmi);
@@ -540,6 +570,19 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         if (found) { cur = root; sp = 0; }
         else { pol.finish(idx, best); have = false; }
       }
+#ifdef FJ_PHASE_STATS
+      {
+        unsigned mx = my_trips, sum = my_trips;     // what the loop cost the wave (its slowest lane) / what the lanes needed
+        for (int off = 32; off; off >>= 1) {
+          const unsigned other = (unsigned) __shfl_xor((int) mx, off);
+          mx = other > mx ? other : mx;
+          sum += (unsigned) __shfl_xor((int) sum, off);
+        }
+        trips_wave += mx;
+        trips_lane += sum;
+      }
+#endif
+      FJ_PCYC(0, m_turn);
       continue;
     }
 
@@ -589,6 +632,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
             if (nh > 1) stk.push(sp, r1);
           }
         }
+        FJ_PCYC(1, __ballot(in_now));
       }
     } else {
       // ---- leaves: ONE triangle per lane (FP64 Moller-Trumbore on the pre-gathered vertices)
@@ -615,6 +659,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
       }
+      FJ_PCYC(2, __ballot(at_leaf));
     }
   }
 }
@@ -683,15 +728,23 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
 #ifndef FJ_PHASED_MINB
 #define FJ_PHASED_MINB 4
 #endif
-template <bool kCount>
+template <bool kCount, bool kInstLds>
 __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ double s_inst[kInstLds ? FJ_INST_LDS_BYTES / 8 : 1];
+  if (kInstLds) {               // the scene's instance level, verbatim: DTNodes (7 words each), then DInstEntry records (28 words)
+    const unsigned long long *src_n = (const unsigned long long *) S.group_nodes, *src_e = (const unsigned long long *) S.inst_entries;
+    unsigned long long *dst = (unsigned long long *) s_inst;
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_group_nodes * 7u; w += BLOCK) dst[w] = src_n[w];
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * 28u; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + w] = src_e[w];
+    __syncthreads();
+  }
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_phased<kCount, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc);
+  traverse_phased<kCount, false, kInstLds>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

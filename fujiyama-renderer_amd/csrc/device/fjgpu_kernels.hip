@@ -248,8 +248,13 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     if (count_events) FJ_LAUNCH_CLOSEST(true, true, true); else FJ_LAUNCH_CLOSEST(true, false, true);
   } else if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false); }
   else if (S.incoherent_rays) {   // glass / pathtracing scenes: the phase-scheduled walk (see k_trace_closest_phased)
-    if (count_events) hipLaunchKernelGGL(k_trace_closest_phased<true>, grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
-    else hipLaunchKernelGGL(k_trace_closest_phased<false>, grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+    if (S.inst_lds) {           // the whole instance level fits the blocks' LDS
+      if (count_events) hipLaunchKernelGGL((k_trace_closest_phased<true, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+      else hipLaunchKernelGGL((k_trace_closest_phased<false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+    } else {
+      if (count_events) hipLaunchKernelGGL((k_trace_closest_phased<true, false>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+      else hipLaunchKernelGGL((k_trace_closest_phased<false, false>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+    }
   }
   else { if (count_events) FJ_LAUNCH_CLOSEST(false, true, false); else FJ_LAUNCH_CLOSEST(false, false, false); }
 #undef FJ_LAUNCH_CLOSEST
@@ -377,6 +382,11 @@ void debug_phase_stats()
   static const char *names[16] = {"iters", "entry_execs|entry_ticks", "entry_lanes", "inner_execs|inner_ticks", "inner_lanes", "leaf_execs|leaf_ticks", "leaf_lanes",
       "tri_execs|stage2_ticks", "tri_lanes", "", "hits", "refills", "tail_iters_max", "tail_iters_sum", "walk_iters_sum", "walk_waves"};
   for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-24s %llu\n", names[i], h[i]);
+  // (the phase-scheduled closest-hit walk, traverse_phased: ticks / lanes of turnover, inner, leaf in 1..6, their executions in 7..9,
+  //  trips of the instance loop summed over lanes in 10 and as the wave's maximum per turnover in 11)
+  if (h[7] && h[11]) fprintf(stderr, "fjgpu phase phased-walk: turnover %llu execs %.1f lanes %.0f ticks | inner %llu execs %.1f lanes %.0f ticks | leaf %llu execs %.1f lanes %.0f ticks | "
+      "instance loop %.2f trips per turnover lane, %.2f wave trips per turnover\n", h[7], (double) h[2] / h[7], (double) h[1] / h[7], h[8], (double) h[4] / (h[8] ? h[8] : 1), (double) h[3] / (h[8] ? h[8] : 1),
+      h[9], (double) h[6] / (h[9] ? h[9] : 1), (double) h[5] / (h[9] ? h[9] : 1), (double) h[10] / (h[2] ? h[2] : 1), (double) h[11] / h[7]);
   unsigned long long z[16] = {0};
   (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
 #endif

@@ -135,6 +135,24 @@ struct DInstance {
   double qorigin[3], qcell[3]; // the closest-hit walk of scenes without curve sets reads these 64-byte nodes too
 };
 
+// What the phase-scheduled closest-hit walk reads when a ray enters an instance, packed: a scene whose whole instance level
+// (every DTNode and one of these per instance) fits FJ_INST_LDS_BYTES is copied to LDS by each block of that walk, so the
+// dependent loads of the instance loop (node -> instance -> root) cost LDS instead of L1 / L2 round trips.
+struct DInstEntry {
+  double Minv[12];             // world -> object (time 0; DInstance.xform >= 0: evaluated per ray instead)
+  double pbounds[6];
+  double qorigin[3], qcell[3];
+  const DNodeQ *pqnodes;
+  const DNode *pnodes;
+  uint32_t proot;
+  int32_t pn_prims;
+  int32_t primset;
+  int32_t xform;
+};
+#define FJ_INST_LDS_NODES 39            // DTNodes (56 B) ...
+#define FJ_INST_LDS_INSTS 20            // ... and DInstEntry records (224 B) a block keeps in LDS: 6 664 bytes
+#define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 224)
+
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
 // load after the queue entry instead of instance -> primitive set -> pointers)
 struct DAnyInst {
@@ -207,6 +225,9 @@ struct DScene {
   const DInstance *instances;
   const DGroup *groups;
   const DTNode *group_nodes;
+  const DInstEntry *inst_entries;  // [n_instances]
+  int32_t n_group_nodes;
+  int32_t inst_lds;            // the instance level fits FJ_INST_LDS_NODES / FJ_INST_LDS_INSTS (k_trace_closest_phased keeps it in LDS)
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;
