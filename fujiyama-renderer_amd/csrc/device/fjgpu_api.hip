@@ -380,6 +380,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         std::memcpy(E.pbounds, I.pbounds, sizeof(E.pbounds));
         for (int a = 0; a < 3; a++) { E.qorigin[a] = I.qorigin[a]; E.qcell[a] = I.qcell[a]; }
         E.pqnodes = I.pqnodes; E.pnodes = I.pnodes; E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
+        const DPrimSet &P = dps[I.primset];
+        E.tri_verts = P.tri_verts; E.tri_verts32 = P.tri_verts32; E.tri_vel = P.tri_vel; E.prim_ids = P.prim_ids;
       }
       e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
     }
@@ -457,7 +459,9 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     e |= M.upload(hs.group_nodes.data(), hs.group_nodes.size(), &S.group_nodes);
     S.n_group_nodes = (int32_t) hs.group_nodes.size();
   }
-  S.inst_lds = (S.n_group_nodes <= FJ_INST_LDS_NODES && (int) hs.instances.size() <= FJ_INST_LDS_INSTS && !getenv("FJGPU_NO_INST_LDS")) ? 1 : 0;
+  static_assert(sizeof(DInstEntry) == 8 * FJ_INST_LDS_ENTRY_WORDS && sizeof(DTNode) == 56 && sizeof(DGroup) == 64, "LDS copy of the instance level");
+  S.inst_lds = (S.n_group_nodes <= FJ_INST_LDS_NODES && (int) hs.instances.size() <= FJ_INST_LDS_INSTS && (int) hs.groups.size() <= FJ_INST_LDS_GROUPS &&
+                !getenv("FJGPU_NO_INST_LDS")) ? 1 : 0;
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
   S.cam_xform = nullptr;

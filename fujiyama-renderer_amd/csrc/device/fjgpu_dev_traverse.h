@@ -445,6 +445,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
   const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + FJ_INST_LDS_NODES * 7) : S.inst_entries;
+  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + FJ_INST_LDS_NODES * 7 + FJ_INST_LDS_INSTS * FJ_INST_LDS_ENTRY_WORDS) : S.groups;
   const unsigned lane = __lane_id();
   bool head_live = true;
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
@@ -461,7 +462,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
   int ti = 0, tend = 0, ii = -1;           // cursor in the group's threaded instance BVH
   int group = 0;
   bool anyhit = false;
-  const DPrimSet *P = nullptr;
   const DNode *nodes = nullptr;
   uint32_t cur = TRAV_DONE;
   int sp = 0;
@@ -505,7 +505,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           if (kMotion) rtime = r.time;
           group = r.group;
-          ti = S.groups[group].first; tend = ti + S.groups[group].count;
+          ti = ggroups[group].first; tend = ti + ggroups[group].count;
           best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
           sp = 0;
         }
@@ -521,31 +521,32 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         const bool dead_ray = has_negative_zero(d);   // every box test of the reference fails (BoxRayIntersect's -0.0 quirk)
         const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
         const bool plain = plain_dir(d);
-        const bool single = S.groups[group].n_instances == 1;
-        const double *gsb = S.groups[group].sbounds;
+        const bool single = ggroups[group].n_instances == 1;
+        const double *gsb = ggroups[group].sbounds;
         while (!dead_ray && ti < tend) {
 #ifdef FJ_PHASE_STATS
           my_trips++;
 #endif
+          // inner nodes of the instance BVH (conservative box, skip link) are passed in a loop of their own: a trip of the
+          // outer loop is one INSTANCE for every lane
           const DTNode *tn_ = &gnodes[ti];
-          if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
+          int inst_ = tn_->inst;
+          while (inst_ < 0) {
             double tq;
             ti = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? ti + 1 : tn_->skip;
-            continue;
+            if (ti >= tend) break;
+            tn_ = &gnodes[ti];
+            inst_ = tn_->inst;
           }
-          ii = tn_->inst;
+          if (inst_ < 0) break;            // (the list ended on a missed inner node)
+          ii = inst_;
           ti++;
           const DInstEntry *I = &gents[ii];
           if (kCount) lc->insts++;
           double tn;
           const double tfar = anyhit ? tmax : fmin(tmax, best.t);
           // the reference's own (possibly non-enclosing) instance box, full ray range
-          if (kInstLds) {                  // (values, not a pointer: the two sources sit in different address spaces)
-            double ibox[6];
-            if (single) { for (int k = 0; k < 6; k++) ibox[k] = gsb[k]; }
-            else { for (int k = 0; k < 6; k++) ibox[k] = tn_->box[k]; }
-            if (!box_ray_ref_fast(ibox, o, d, winv, plain, tmin, tmax)) continue;
-          } else if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
+          if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
           if (kMotion && I->xform >= 0) {
             double tm[12], tmi[12];
             xform_at(&S.xforms[I->xform], rtime, tm, tmi);
@@ -557,7 +558,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           }
           if (has_negative_zero(od)) continue;
           const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
-          P = &S.primsets[I->primset];
           nodes = I->pnodes;
           if (I->pn_prims == 0) continue;
           if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
@@ -643,13 +643,14 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         double t, u = 0, v = 0;
         if (kCount) lc->prims++;
         V3 v0, v1, v2;
-        load_tri(P->tri_verts, P->tri_verts32, first, &v0, &v1, &v2);
-        if (kMotion && P->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
-          const FJ_GLOBAL double *w = FJ_G(double, P->tri_vel) + (size_t) first * 9;
+        const DInstEntry *E = &gents[ii];      // (the instance this lane is in)
+        load_tri(E->tri_verts, E->tri_verts32, first, &v0, &v1, &v2);
+        if (kMotion && E->tri_vel) {       // Mesh::ray_intersect: P + time * velocity (src/fj_mesh.cc:252-259)
+          const FJ_GLOBAL double *w = FJ_G(double, E->tri_vel) + (size_t) first * 9;
           v0 = v0 + rtime * ld3(w); v1 = v1 + rtime * ld3(w + 3); v2 = v2 + rtime * ld3(w + 6);
         }
         if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
-          const int pid = (int) FJ_G(uint32_t, P->prim_ids)[first];
+          const int pid = (int) FJ_G(uint32_t, E->prim_ids)[first];
           if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
             best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
             stop = anyhit;
@@ -734,11 +735,13 @@ __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   __shared__ double s_inst[kInstLds ? FJ_INST_LDS_BYTES / 8 : 1];
-  if (kInstLds) {               // the scene's instance level, verbatim: DTNodes (7 words each), then DInstEntry records (28 words)
+  if (kInstLds) {               // the scene's instance level, verbatim: DTNodes (7 words each), DInstEntry records, DGroups (8 words)
     const unsigned long long *src_n = (const unsigned long long *) S.group_nodes, *src_e = (const unsigned long long *) S.inst_entries;
     unsigned long long *dst = (unsigned long long *) s_inst;
     for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_group_nodes * 7u; w += BLOCK) dst[w] = src_n[w];
-    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * 28u; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + w] = src_e[w];
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * FJ_INST_LDS_ENTRY_WORDS; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + w] = src_e[w];
+    const unsigned long long *src_g = (const unsigned long long *) S.groups;
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_groups * 8u; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + FJ_INST_LDS_INSTS * FJ_INST_LDS_ENTRY_WORDS + w] = src_g[w];
     __syncthreads();
   }
   ClosestPolicy pol;

@@ -144,14 +144,20 @@ struct DInstEntry {
   double qorigin[3], qcell[3];
   const DNodeQ *pqnodes;
   const DNode *pnodes;
+  const double *tri_verts;     // the primitive set's leaf-order arrays (DPrimSet): the leaf phase reads them through this record
+  const float *tri_verts32;
+  const double *tri_vel;
+  const uint32_t *prim_ids;
   uint32_t proot;
   int32_t pn_prims;
   int32_t primset;
   int32_t xform;
 };
-#define FJ_INST_LDS_NODES 39            // DTNodes (56 B) ...
-#define FJ_INST_LDS_INSTS 20            // ... and DInstEntry records (224 B) a block keeps in LDS: 6 664 bytes
-#define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 224)
+#define FJ_INST_LDS_NODES 39            // DTNodes (56 B), ...
+#define FJ_INST_LDS_INSTS 20            // ... DInstEntry records (256 B) ...
+#define FJ_INST_LDS_GROUPS 12           // ... and DGroups (64 B) a block keeps in LDS: 8 072 bytes (with the 32 KB of stacks: 4 blocks per CU)
+#define FJ_INST_LDS_ENTRY_WORDS 32      // sizeof(DInstEntry) / 8
+#define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
 // load after the queue entry instead of instance -> primitive set -> pointers)
@@ -227,7 +233,7 @@ struct DScene {
   const DTNode *group_nodes;
   const DInstEntry *inst_entries;  // [n_instances]
   int32_t n_group_nodes;
-  int32_t inst_lds;            // the instance level fits FJ_INST_LDS_NODES / FJ_INST_LDS_INSTS (k_trace_closest_phased keeps it in LDS)
+  int32_t inst_lds;            // the instance level fits FJ_INST_LDS_NODES / _INSTS / _GROUPS (k_trace_closest_phased keeps it in LDS)
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;
