@@ -248,31 +248,52 @@ __device__ V3 bump_mapping(const DTexture &bump, V3 dPdu, V3 dPdv, float tu, flo
   return normalize(nb);
 }
 
-// block-aggregated append: slots by ballot prefix count inside the wave, wave offsets through
-// LDS, ONE global atomic per block and queue.  (Every wave of a frame adding to the same
-// counters -- which share one cache line -- serialises in L2: 10 M same-line atomics per C3
-// frame were most of the shading kernel's time.)  Every thread of the block must call it.
-// `tally` (optional) receives the number of appended entries, also once per block.
-__device__ __forceinline__ uint32_t block_append(bool want, uint32_t *counter, unsigned long long *tally, uint32_t *s_tmp)
+// Block-aggregated append of the shading kernel's four outputs -- the light record and the diffuse / reflect / refract
+// children, the three children into ONE queue -- in a single pass: slots by ballot prefix count inside the wave, wave
+// offsets through LDS, ONE global atomic per block and queue, the two issued side by side by two lanes of the same wave
+// instruction.  (Every wave of a frame adding to the same counters -- which share one cache line -- serialises in L2:
+// 10 M same-line atomics per C3 frame were most of the shading kernel's time.  Four appends one after the other -- each two
+// barriers and a returning atomic the whole block waits for -- were a third of a block's life on C4.)
+// Every thread of the block must call it.  A block's children sit in the queue as [diffuse | reflect | refract].
+struct AppendSlots { uint32_t light, c2, c0, c1; };
+__device__ __forceinline__ AppendSlots block_append4(bool want_light, bool want2, bool want0, bool want1, DCounters *cnt, uint32_t *s_tmp)
 {
-  const unsigned long long mask = __ballot(want);
+  constexpr int W = BLOCK / 64;
+  const unsigned long long mL = __ballot(want_light), m2 = __ballot(want2), m0 = __ballot(want0), m1 = __ballot(want1);
   const unsigned lane = __lane_id(), w = threadIdx.x >> 6;
-  if (lane == 0) s_tmp[w] = (uint32_t) __popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (int k = 0; k < BLOCK / 64; k++) { const uint32_t c = s_tmp[k]; s_tmp[k] = total; total += c; }
-    uint32_t base = 0;
-    if (total) {
-      base = atomicAdd(counter, total);
-      if (tally) atomicAdd(tally, (unsigned long long) total);
-    }
-    s_tmp[BLOCK / 64] = base;
+  if (lane == 0) {
+    s_tmp[w] = (uint32_t) __popcll(mL); s_tmp[W + w] = (uint32_t) __popcll(m2);
+    s_tmp[2 * W + w] = (uint32_t) __popcll(m0); s_tmp[3 * W + w] = (uint32_t) __popcll(m1);
   }
   __syncthreads();
-  const uint32_t slot = s_tmp[BLOCK / 64] + s_tmp[w] + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-  __syncthreads();          // s_tmp is reused by the next call
-  return want ? slot : 0xffffffffu;
+  uint32_t tot[4], before[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    uint32_t t = 0, bf = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) { const uint32_t c = s_tmp[q * W + k]; bf += (unsigned) k < w ? c : 0u; t += c; }
+    tot[q] = t; before[q] = bf;
+  }
+  if (threadIdx.x < 2) {       // lane 0: the light queue; lane 1: the ray queue
+    const uint32_t total = threadIdx.x == 0 ? tot[0] : tot[1] + tot[2] + tot[3];
+    uint32_t base = 0;
+    if (total) base = atomicAdd(threadIdx.x == 0 ? &cnt->light_count : &cnt->next_count, total);
+    s_tmp[4 * W + threadIdx.x] = base;
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 67) {     // (another wave: the per-context ray counts; nobody waits for these)
+    const int q = (int) threadIdx.x - 63;
+    static_assert(CXT_DIFFUSE_RAY == 2 && CXT_REFLECT_RAY == 3 && CXT_REFRACT_RAY == 4, "contexts of the three children");
+    if (tot[q]) atomicAdd(&cnt->rays[q + 1], (unsigned long long) tot[q]);
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint32_t baseL = s_tmp[4 * W], baseR = s_tmp[4 * W + 1];
+  AppendSlots a;
+  a.light = want_light ? baseL + before[0] + (uint32_t) __popcll(mL & lt) : 0xffffffffu;
+  a.c2 = want2 ? baseR + before[1] + (uint32_t) __popcll(m2 & lt) : 0xffffffffu;
+  a.c0 = want0 ? baseR + tot[1] + before[2] + (uint32_t) __popcll(m0 & lt) : 0xffffffffu;
+  a.c1 = want1 ? baseR + tot[1] + tot[2] + before[3] + (uint32_t) __popcll(m1 & lt) : 0xffffffffu;
+  return a;
 }
 
 // key of the ray-queue sort: direction octant (3 bits) over the Morton code of the origin's cell in a 2^bits grid per axis
@@ -310,12 +331,10 @@ struct ChildRay {
   uint32_t flags;
 };
 
-// `cxt` is uniform per call site (reflect / refract / diffuse children are
-// emitted by separate calls), so the per-context ray count is one atomic per block
-__device__ __forceinline__ void emit_child(const ChildRay &c, int cxt, uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
-    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, uint32_t *s_tmp, const ShadeParams &sp)
+// writes child `c` to its slot of the next level's queue (block_append4)
+__device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t slot, int cxt, uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
+    DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, const ShadeParams &sp)
 {
-  const uint32_t slot = block_append(c.want, &cnt->next_count, &cnt->rays[cxt], s_tmp);
   if (!c.want) return;
   if (slot >= capacity) { cnt->overflow = 1; return; }
   DRay r;
@@ -661,8 +680,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   }
 
   // ---- compaction: ballot + prefix count, one atomic per block and queue
-  __shared__ uint32_t s_tmp[BLOCK / 64 + 1];
-  const uint32_t lslot = block_append(want_light, &cnt->light_count, nullptr, s_tmp);
+  __shared__ uint32_t s_tmp[4 * (BLOCK / 64) + 2];
+  const AppendSlots slots = block_append4(want_light, c2.want, c0.want, c1.want, cnt, s_tmp);
+  const uint32_t lslot = slots.light;
   if (want_light) {
     if (lslot < sp.light_capacity) {
       lrecs[lslot] = lr;
@@ -670,9 +690,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     }
     else cnt->overflow = 1;
   }
-  emit_child(c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
-  emit_child(c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
-  emit_child(c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, s_tmp, sp);
+  emit_child(c2, slots.c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, sp);
+  emit_child(c0, slots.c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, sp);
+  emit_child(c1, slots.c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, sp);
 }
 
 #endif
