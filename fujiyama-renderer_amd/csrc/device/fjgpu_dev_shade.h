@@ -320,35 +320,40 @@ __device__ __forceinline__ uint32_t ray_sort_key(V3 o, V3 d, const double *lo, c
   return (oct << (3 * bits)) | sort_spread3(c[0]) | (sort_spread3(c[1]) << 1) | (sort_spread3(c[2]) << 2);
 }
 
+// A child ray as the shaders leave it: what differs between the three children of a hit.  Their origin is the hit point,
+// tmax is 1000 (src/shaders/*: SlTrace's TraceContext), the depth counters follow from the context, and only a refraction child
+// carries a filter colour -- kept out of the record so that three of them do not hold 72 registers to the end of the kernel.
 struct ChildRay {
   bool want;
-  V3 o, d;
-  double tmin, tmax;
+  V3 d;
   float T[3];
-  uint8_t dd, rd, td;
+  float tmin;                  // .001f or .0001f (widened to the same double the reference's literal gives: see emit_child)
   int group;
-  float fc[3];
   uint32_t flags;
 };
 
 // writes child `c` to its slot of the next level's queue (block_append4)
-__device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t slot, int cxt, uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
+__device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t slot, int cxt, V3 o, const DPath &parent, const float *fc,
+    uint32_t sample, uint32_t uid, uint32_t tbits, uint32_t key,
     DRay *next_rays, DPath *next_paths, DCounters *cnt, uint32_t capacity, const ShadeParams &sp)
 {
   if (!c.want) return;
   if (slot >= capacity) { cnt->overflow = 1; return; }
   DRay r;
-  r.o[0] = c.o.x; r.o[1] = c.o.y; r.o[2] = c.o.z;
+  r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
   r.d[0] = c.d.x; r.d[1] = c.d.y; r.d[2] = c.d.z;
-  r.tmin = c.tmin; r.tmax = c.tmax;
+  r.tmin = c.tmin < .0005f ? .0001 : .001; r.tmax = 1000;
   next_rays[slot] = r;
-  if (sp.next_keys) sp.next_keys[slot] = ray_sort_key(c.o, c.d, sp.sort_lo, sp.sort_scale, sp.sort_bits);
+  if (sp.next_keys) sp.next_keys[slot] = ray_sort_key(o, c.d, sp.sort_lo, sp.sort_scale, sp.sort_bits);
   DPath p;
   p.sample = sample;
   p.T[0] = c.T[0]; p.T[1] = c.T[1]; p.T[2] = c.T[2];
-  p.cxt = (uint8_t) cxt; p.ddepth = c.dd; p.rdepth = c.rd; p.tdepth = c.td;
+  p.cxt = (uint8_t) cxt;
+  p.ddepth = parent.ddepth + (cxt == CXT_DIFFUSE_RAY ? 1 : 0);
+  p.rdepth = parent.rdepth + (cxt == CXT_REFLECT_RAY ? 1 : 0);
+  p.tdepth = parent.tdepth + (cxt == CXT_REFRACT_RAY ? 1 : 0);
   p.group = c.group;
-  p.fc[0] = c.fc[0]; p.fc[1] = c.fc[1]; p.fc[2] = c.fc[2];
+  p.fc[0] = fc ? fc[0] : 1.f; p.fc[1] = fc ? fc[1] : 1.f; p.fc[2] = fc ? fc[2] : 1.f;
   p.flags = c.flags | tbits; p.rng = key; p.uid = uid;     // tbits: the sample's time index << 1
   next_paths[slot] = p;
 }
@@ -378,6 +383,10 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
 
   ChildRay c0, c1, c2;   // reflect, refract, diffuse children (glass: c0 + c1, plastic: c0, pathtracing: any)
   c0.want = c1.want = c2.want = false;
+  V3 Pw = mk(0, 0, 0);   // the hit point: origin of every child
+  float fc1[3] = {1.f, 1.f, 1.f};      // filter colour a refraction child carries to its hit
+  DPath p;
+  p.ddepth = p.rdepth = p.tdepth = 0;
   bool want_light = false;
   DLightRec lr;
   DLightHair lh;
@@ -387,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   if (hit) {
     // (level 0 with implicit camera rays: nothing was written, ray and path state follow from the sample slot)
     const DRay r = rays ? rays[i] : implicit_camera_ray(S, i);
-    DPath p = rays ? paths[i] : camera_path(S, S.cam_slot0 + i, 0u, 0u);
+    p = rays ? paths[i] : camera_path(S, S.cam_slot0 + i, 0u, 0u);
     sample = p.sample;
     rng = p.rng;
     uid = p.uid;
@@ -452,7 +461,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       }
       sg = P->face_group ? FJ_G(int32_t, P->face_group)[h.prim] : 0;
     }
-    V3 Pw = oo + h.t * od;                                        // RayPointAt in object space
+    Pw = oo + h.t * od;                                        // RayPointAt in object space
     // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)
     Pw = xpoint(IM, Pw);
     N = normalize(xvector(IM, N));
@@ -532,13 +541,12 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           const V3 R = normalize(reflect(Iw, Nf));
           const double Kr = fresnel(Iw, Nf, (double) (1.f / sh->ior));
           c0.want = true;
-          c0.o = Pw; c0.d = R; c0.tmin = .001; c0.tmax = 1000;
+          c0.d = R; c0.tmin = .001f;
           c0.T[0] = (float) (Kr * sh->reflect[0]) * p.T[0];
           c0.T[1] = (float) (Kr * sh->reflect[1]) * p.T[1];
           c0.T[2] = (float) (Kr * sh->reflect[2]) * p.T[2];
-          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
           c0.group = I->reflect_target;
-          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+          c0.flags = 0;
         }
         Os = sh->opacity;
         break;
@@ -549,20 +557,18 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
         const double Kt = 1 - Kr;
         if ((int) p.rdepth + 1 <= sp.max_reflect_depth) {
           c0.want = true;
-          c0.o = Pw; c0.d = normalize(reflect(Iw, N)); c0.tmin = .0001; c0.tmax = 1000;
+          c0.d = normalize(reflect(Iw, N)); c0.tmin = .0001f;
           c0.T[0] = (float) Kr * p.T[0]; c0.T[1] = (float) Kr * p.T[1]; c0.T[2] = (float) Kr * p.T[2];
-          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
           c0.group = I->reflect_target;
-          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+          c0.flags = 0;
         }
         if ((int) p.tdepth + 1 <= sp.max_refract_depth) {
           c1.want = true;
-          c1.o = Pw; c1.d = normalize(refract(Iw, N, (double) (1.f / sh->ior))); c1.tmin = .0001; c1.tmax = 1000;
+          c1.d = normalize(refract(Iw, N, (double) (1.f / sh->ior))); c1.tmin = .0001f;
           c1.T[0] = (float) Kt * p.T[0]; c1.T[1] = (float) Kt * p.T[1]; c1.T[2] = (float) Kt * p.T[2];
-          c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
           c1.group = I->refract_target;
           const bool filt = sh->do_color_filter && dot(Iw, N) < 0;
-          c1.fc[0] = sh->filter_color[0]; c1.fc[1] = sh->filter_color[1]; c1.fc[2] = sh->filter_color[2];
+          fc1[0] = sh->filter_color[0]; fc1[1] = sh->filter_color[1]; fc1[2] = sh->filter_color[2];
           c1.flags = filt ? 1u : 0u;
         }
         Os = 1.f;
@@ -631,33 +637,30 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           const V3 D = normalize(u * cos(r1) * r2sqrt + v * sin(r1) * r2sqrt + w * sqrt(1. - r2));
           const float kd = (float) dot(Np, D);
           c2.want = true;
-          c2.o = Pw; c2.d = D; c2.tmin = .001; c2.tmax = 1000;
+          c2.d = D; c2.tmin = .001f;
           c2.T[0] = p.T[0] * (Cdm[0] * kd * sh->diffuse[0]);
           c2.T[1] = p.T[1] * (Cdm[1] * kd * sh->diffuse[1]);
           c2.T[2] = p.T[2] * (Cdm[2] * kd * sh->diffuse[2]);
-          c2.dd = p.ddepth + 1; c2.rd = p.rdepth; c2.td = p.tdepth;
           c2.group = I->reflect_target;                              // SlDiffuseContext uses the REFLECT target
-          c2.fc[0] = c2.fc[1] = c2.fc[2] = 1.f; c2.flags = 0;
+          c2.flags = 0;
         }
         if (luminance3(sh->reflect) > 0.f && (int) p.rdepth + 1 <= sp.max_reflect_depth) {   // integrate_reflect
           const float kr = (float) fresnel(Iw, Np, 1. / (double) sh->ior);
           c0.want = true;
-          c0.o = Pw; c0.d = normalize(reflect(Iw, Np)); c0.tmin = .001; c0.tmax = 1000;
+          c0.d = normalize(reflect(Iw, Np)); c0.tmin = .001f;
           c0.T[0] = p.T[0] * (kr * sh->reflect[0]); c0.T[1] = p.T[1] * (kr * sh->reflect[1]); c0.T[2] = p.T[2] * (kr * sh->reflect[2]);
-          c0.dd = p.ddepth; c0.rd = p.rdepth + 1; c0.td = p.tdepth;
           c0.group = I->reflect_target;
-          c0.fc[0] = c0.fc[1] = c0.fc[2] = 1.f; c0.flags = 0;
+          c0.flags = 0;
         }
         if (luminance3(sh->refract) > 0.f && (int) p.tdepth + 1 <= sp.max_refract_depth) {   // integrate_refract
           const double Kr = fresnel(Iw, Np, (double) (1 / sh->ior));      // 1/ior in f32, as in the plugin
           const float kt = (float) (1 - Kr);
           c1.want = true;
-          c1.o = Pw; c1.d = normalize(refract(Iw, Np, 1. / (double) sh->ior)); c1.tmin = .0001; c1.tmax = 1000;
+          c1.d = normalize(refract(Iw, Np, 1. / (double) sh->ior)); c1.tmin = .0001f;
           c1.T[0] = p.T[0] * (kt * sh->refract[0]); c1.T[1] = p.T[1] * (kt * sh->refract[1]); c1.T[2] = p.T[2] * (kt * sh->refract[2]);
-          c1.dd = p.ddepth; c1.rd = p.rdepth; c1.td = p.tdepth + 1;
           c1.group = I->refract_target;
           const bool filt = sh->do_color_filter && dot(Iw, Np) < 0;
-          c1.fc[0] = sh->filter_color[0]; c1.fc[1] = sh->filter_color[1]; c1.fc[2] = sh->filter_color[2];
+          fc1[0] = sh->filter_color[0]; fc1[1] = sh->filter_color[1]; fc1[2] = sh->filter_color[2];
           c1.flags = filt ? 1u : 0u;
         }
         Os = 1.f;
@@ -690,9 +693,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     }
     else cnt->overflow = 1;
   }
-  emit_child(c2, slots.c2, CXT_DIFFUSE_RAY, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, sp);
-  emit_child(c0, slots.c0, CXT_REFLECT_RAY, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, sp);
-  emit_child(c1, slots.c1, CXT_REFRACT_RAY, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, sp);
+  emit_child(c2, slots.c2, CXT_DIFFUSE_RAY, Pw, p, nullptr, sample, uid, tbits, 4 * rng + 1, next_rays, next_paths, cnt, sp.ray_capacity, sp);
+  emit_child(c0, slots.c0, CXT_REFLECT_RAY, Pw, p, nullptr, sample, uid, tbits, 4 * rng + 2, next_rays, next_paths, cnt, sp.ray_capacity, sp);
+  emit_child(c1, slots.c1, CXT_REFRACT_RAY, Pw, p, fc1, sample, uid, tbits, 4 * rng + 3, next_rays, next_paths, cnt, sp.ray_capacity, sp);
 }
 
 #endif
