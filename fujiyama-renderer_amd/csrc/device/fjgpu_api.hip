@@ -373,14 +373,22 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       }
       e |= M.upload(di.data(), di.size(), &S.instances);
       std::vector<DInstEntry> ie(di.size());
+      bool any_curves = false, any_motion = !hs.xforms.empty();       // (DScene.has_curves / has_motion, set below)
+      for (const auto &ps : hs.primsets) {
+        if (ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) any_curves = true;
+        if (!ps.tri_vel.empty() || !ps.curve_vel.empty()) any_motion = true;
+      }
       for (size_t k = 0; k < di.size(); k++) {
         const DInstance &I = di[k];
         DInstEntry &E = ie[k];
         std::memcpy(E.Minv, I.Minv, sizeof(E.Minv));
         std::memcpy(E.pbounds, I.pbounds, sizeof(E.pbounds));
         for (int a = 0; a < 3; a++) { E.qorigin[a] = I.qorigin[a]; E.qcell[a] = I.qcell[a]; }
-        E.pqnodes = I.pqnodes; E.pnodes = I.pnodes; E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
         const DPrimSet &P = dps[I.primset];
+        const bool quantised = FJ_CLOSEST_QNODES && !any_curves && !any_motion;     // (the instantiations launch_trace_closest picks)
+        E.nodes = quantised ? (const void *) I.pqnodes : (const void *) I.pnodes;
+        E.ptype = P.type; E.pad = 0;
+        E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
         E.tri_verts = P.tri_verts; E.tri_verts32 = P.tri_verts32; E.tri_vel = P.tri_vel; E.prim_ids = P.prim_ids;
       }
       e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
@@ -460,8 +468,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     S.n_group_nodes = (int32_t) hs.group_nodes.size();
   }
   static_assert(sizeof(DInstEntry) == 8 * FJ_INST_LDS_ENTRY_WORDS && sizeof(DTNode) == 56 && sizeof(DGroup) == 64, "LDS copy of the instance level");
-  S.inst_lds = (S.n_group_nodes <= FJ_INST_LDS_NODES && (int) hs.instances.size() <= FJ_INST_LDS_INSTS && (int) hs.groups.size() <= FJ_INST_LDS_GROUPS &&
-                !getenv("FJGPU_NO_INST_LDS")) ? 1 : 0;
+  S.inst_lds = getenv("FJGPU_NO_INST_LDS") ? 0 : 1;         // (each kernel checks the scene against its own budget: inst_lds_fits)
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);
   S.cam_xform = nullptr;

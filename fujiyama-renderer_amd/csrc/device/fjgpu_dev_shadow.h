@@ -367,17 +367,19 @@ struct ShadowPolicy {
   }
 };
 
-template <bool kCurves, bool kCount, bool kMotion>
+template <bool kCurves, bool kCount, bool kMotion, bool kInstLds = false>
 __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? FJ_CURVE_MINB : FJ_SHADOW_MINB)) k_shadow_trace(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
+  __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
+  if (kInstLds) InstLds::fill(S, s_inst);
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->shadow_xcd_head[0][0], make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc);
+  traverse_persistent<kCurves, kCount, kMotion, kInstLds>(S, pol, tune, n, &cnt->shadow_xcd_head[0][0], make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

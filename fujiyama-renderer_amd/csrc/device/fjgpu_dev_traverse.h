@@ -121,9 +121,37 @@ __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf
   return st;
 }
 
-template <bool kCurves, bool kCount, bool kMotion, class Policy>
-__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc)
+// ---- the instance level in LDS (DInstEntry, fjgpu_types.h): [NODES DTNodes][INSTS DInstEntry][GROUPS DGroup], verbatim copies
+struct InstLds {
+  static constexpr int NODES = FJ_INST_LDS_NODES, INSTS = FJ_INST_LDS_INSTS, GROUPS = FJ_INST_LDS_GROUPS;
+  static constexpr int ENTRIES_AT = NODES * 7, GROUPS_AT = ENTRIES_AT + INSTS * FJ_INST_LDS_ENTRY_WORDS;      // in 8-byte words
+  static constexpr int WORDS = GROUPS_AT + GROUPS * 8;
+  static bool fits(const DScene &S)        // (host: the launchers pick the kInstLds instantiations by this)
+  {
+    return S.inst_lds && S.n_group_nodes <= NODES && S.n_instances <= INSTS && S.n_groups <= GROUPS;
+  }
+  static __device__ __forceinline__ void fill(const DScene &S, double *s_inst)      // every thread of the block
+  {
+    const unsigned long long *src_n = (const unsigned long long *) S.group_nodes, *src_e = (const unsigned long long *) S.inst_entries;
+    const unsigned long long *src_g = (const unsigned long long *) S.groups;
+    unsigned long long *dst = (unsigned long long *) s_inst;
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_group_nodes * 7u; w += BLOCK) dst[w] = src_n[w];
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * FJ_INST_LDS_ENTRY_WORDS; w += BLOCK) dst[ENTRIES_AT + w] = src_e[w];
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_groups * 8u; w += BLOCK) dst[GROUPS_AT + w] = src_g[w];
+    __syncthreads();
+  }
+};
+
+// kInstLds: the scene's instance level sits in LDS at s_inst (filled by the kernel: InstLds); otherwise the same records are read
+// from DScene.group_nodes / inst_entries / groups.  (A run-time choice through generic pointers was measured: the flat loads
+// cost the fallback 8 % -- C2's closest-hit walk 20.1 -> 21.9 ms.)
+template <bool kCurves, bool kCount, bool kMotion, bool kInstLds, class Policy>
+__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc,
+    const double *s_inst)
 {
+  const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
+  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT) : S.inst_entries;
+  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + InstLds::GROUPS_AT) : S.groups;
   const unsigned lane = __lane_id();
   bool head_live = true;                   // wave-uniform: the global head still has entries
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -185,14 +213,14 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
           if (kMotion) rtime = r.time;
           group = r.group;
-          const DGroup G = S.groups[r.group];
-          ti = G.first; tend = G.first + G.count;
+          const DGroup *G = &ggroups[r.group];
+          ti = G->first; tend = ti + G->count;
           best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
           cur = TRAV_DONE; sp = 0;
           if (!kCurves) {
             o = r.o; d = r.d;
-            single = G.n_instances == 1;
-            gsb = S.groups[r.group].sbounds;
+            single = G->n_instances == 1;
+            gsb = G->sbounds;
             dead_ray = has_negative_zero(d);   // every box test of the reference fails (see above)
             winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
             plain = plain_dir(d);
@@ -227,14 +255,15 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
         pol.fetch(idx, &r);
         o = r.o; d = r.d;
-        single = S.groups[group].n_instances == 1;
-        gsb = S.groups[group].sbounds;
+        single = ggroups[group].n_instances == 1;
+        gsb = ggroups[group].sbounds;
         dead_ray = has_negative_zero(d);
         winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
         plain = plain_dir(d);
       }
+      bool into_curves = false;
       while (!dead_ray && ti < tend) {
-        const DTNode *tn_ = &S.group_nodes[ti];
+        const DTNode *tn_ = &gnodes[ti];
         if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
           double tq;
           ti = slab(tn_->box, tn_->box + 3, o, winv, tmin, tmax, &tq) ? ti + 1 : tn_->skip;
@@ -242,7 +271,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         }
         ii = tn_->inst;
         ti++;
-        const DInstance *I = &S.instances[ii];
+        const DInstEntry *I = &gents[ii];
         if (kCount) lc->insts++;
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
@@ -261,18 +290,19 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (has_negative_zero(od)) continue;
         const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
         P = &S.primsets[I->primset];
-        nodes = I->pnodes;
+        nodes = (const DNode *) I->nodes;
         if (I->pn_prims == 0) continue;
         if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-        if (FJ_CLOSEST_QNODES && !kCurves) { nodes = (const DNode *) I->pqnodes; s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell); }
+        if (FJ_CLOSEST_QNODES && !kCurves) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
         else s32 = slab32_setup(oo, inv, I->pbounds);
         root = I->proot;
+        into_curves = kCurves && I->ptype == FJ_PRIMSET_CURVE;
         found = true;
         break;
       }
       if (found) {
         cur = root; sp = 0; last_curve = 0xffffffffu;
-        if (kCurves && P->type == FJ_PRIMSET_CURVE) { RaySpace rsp = {stk.rayspace, oo, od}; rsp.set(oo, od); }
+        if (into_curves) { RaySpace rsp = {stk.rayspace, oo, od}; rsp.set(oo, od); }
       }
       else { pol.finish(idx, best); have = false; }
     }
@@ -444,8 +474,8 @@ template <bool kCount, bool kMotion, bool kInstLds, class Policy>
 __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
-  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + FJ_INST_LDS_NODES * 7) : S.inst_entries;
-  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + FJ_INST_LDS_NODES * 7 + FJ_INST_LDS_INSTS * FJ_INST_LDS_ENTRY_WORDS) : S.groups;
+  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT) : S.inst_entries;
+  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + InstLds::GROUPS_AT) : S.groups;
   const unsigned lane = __lane_id();
   bool head_live = true;
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
@@ -558,10 +588,10 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           }
           if (has_negative_zero(od)) continue;
           const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
-          nodes = I->pnodes;
+          nodes = (const DNode *) I->nodes;
           if (I->pn_prims == 0) continue;
           if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-          if (FJ_CLOSEST_QNODES) { nodes = (const DNode *) I->pqnodes; s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell); }
+          if (FJ_CLOSEST_QNODES) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
           else s32 = slab32_setup(oo, inv, I->pbounds);
           root = I->proot;
           found = true;
@@ -705,16 +735,18 @@ struct ClosestPolicy {
 #ifndef FJ_SHADOW_MINB
 #define FJ_SHADOW_MINB 3          // the general shadow walk of mesh scenes (translucent occluders): 166 VGPRs, 3 waves
 #endif
-template <bool kCurves, bool kCount, bool kMotion>
+template <bool kCurves, bool kCount, bool kMotion, bool kInstLds = false>
 __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? FJ_CURVE_MINB : FJ_CLOSEST_MINB)) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
+  __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
+  if (kInstLds) InstLds::fill(S, s_inst);
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc);
+  traverse_persistent<kCurves, kCount, kMotion, kInstLds>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -734,16 +766,8 @@ __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
-  __shared__ double s_inst[kInstLds ? FJ_INST_LDS_BYTES / 8 : 1];
-  if (kInstLds) {               // the scene's instance level, verbatim: DTNodes (7 words each), DInstEntry records, DGroups (8 words)
-    const unsigned long long *src_n = (const unsigned long long *) S.group_nodes, *src_e = (const unsigned long long *) S.inst_entries;
-    unsigned long long *dst = (unsigned long long *) s_inst;
-    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_group_nodes * 7u; w += BLOCK) dst[w] = src_n[w];
-    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * FJ_INST_LDS_ENTRY_WORDS; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + w] = src_e[w];
-    const unsigned long long *src_g = (const unsigned long long *) S.groups;
-    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_groups * 8u; w += BLOCK) dst[FJ_INST_LDS_NODES * 7 + FJ_INST_LDS_INSTS * FJ_INST_LDS_ENTRY_WORDS + w] = src_g[w];
-    __syncthreads();
-  }
+  __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
+  if (kInstLds) InstLds::fill(S, s_inst);         // (the launcher picked this instantiation because the scene fits)
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};

@@ -135,28 +135,33 @@ struct DInstance {
   double qorigin[3], qcell[3]; // the closest-hit walk of scenes without curve sets reads these 64-byte nodes too
 };
 
-// What the phase-scheduled closest-hit walk reads when a ray enters an instance, packed: a scene whose whole instance level
-// (every DTNode and one of these per instance) fits FJ_INST_LDS_BYTES is copied to LDS by each block of that walk, so the
-// dependent loads of the instance loop (node -> instance -> root) cost LDS instead of L1 / L2 round trips.
+// What the closest-hit walks and the general shadow walk read when a ray enters an instance, packed.  A scene whose whole
+// instance level (every DTNode, one of these per instance, every DGroup) fits the kernel's budget is copied to LDS by each
+// block of those (persistent) walks, so the dependent loads of the instance loop (group -> node -> instance -> root) cost
+// LDS instead of L1 / L2 round trips.
 struct DInstEntry {
   double Minv[12];             // world -> object (time 0; DInstance.xform >= 0: evaluated per ray instead)
   double pbounds[6];
   double qorigin[3], qcell[3];
-  const DNodeQ *pqnodes;
-  const DNode *pnodes;
+  const void *nodes;           // the node array the scene's walks read: DNodeQ (meshes, scenes without curve sets and motion) or DNode
   const double *tri_verts;     // the primitive set's leaf-order arrays (DPrimSet): the leaf phase reads them through this record
   const float *tri_verts32;
   const double *tri_vel;
   const uint32_t *prim_ids;
+  int32_t ptype;               // FJ_PRIMSET_*
+  int32_t pad;
   uint32_t proot;
   int32_t pn_prims;
   int32_t primset;
   int32_t xform;
 };
-#define FJ_INST_LDS_NODES 39            // DTNodes (56 B), ...
-#define FJ_INST_LDS_INSTS 20            // ... DInstEntry records (256 B) ...
-#define FJ_INST_LDS_GROUPS 12           // ... and DGroups (64 B) a block keeps in LDS: 8 072 bytes (with the 32 KB of stacks: 4 blocks per CU)
 #define FJ_INST_LDS_ENTRY_WORDS 32      // sizeof(DInstEntry) / 8
+// budgets: DTNodes (56 B), DInstEntry records (256 B), DGroups (64 B)
+#define FJ_INST_LDS_NODES 39            // 8 072 bytes next to the 32 KB of stacks of a block: the phased walk still has 4 blocks per CU.  (The curve /
+                                        // motion kernels -- 52 KB of stacks and ray space per block, 3 blocks per CU -- have no room: two stack entries
+                                        // less to make it cost C5's shadow walk 1733 -> 2227 ms.)
+#define FJ_INST_LDS_INSTS 20
+#define FJ_INST_LDS_GROUPS 12
 #define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
@@ -233,7 +238,7 @@ struct DScene {
   const DTNode *group_nodes;
   const DInstEntry *inst_entries;  // [n_instances]
   int32_t n_group_nodes;
-  int32_t inst_lds;            // the instance level fits FJ_INST_LDS_NODES / _INSTS / _GROUPS (k_trace_closest_phased keeps it in LDS)
+  int32_t inst_lds;            // 0: the walks read the instance level from global memory (option / FJGPU_NO_INST_LDS); else where it fits
   const fj_shader_desc *shaders;
   const DTexture *textures;
   const DLightSample *light_samples;
