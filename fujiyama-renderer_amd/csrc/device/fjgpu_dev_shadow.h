@@ -28,10 +28,22 @@
 #ifndef FJ_CULL_MINB_PLAIN
 #define FJ_CULL_MINB_PLAIN 3      // point lights, no hair: 166 VGPRs as written; the split instantiation is held to the same 3 waves
 #endif
-template <bool kHair, bool kArea, bool kSplit>
+// kNodesLds: every block keeps the scene's threaded instance nodes (DScene.group_nodes, at most FJ_CULL_LDS_NODES) in LDS -- the
+// candidate search of a (point, light) pair is a chain of dependent node reads (launch_shadow_cull picks it where the scene fits)
+#ifndef FJ_CULL_LDS_NODES
+#define FJ_CULL_LDS_NODES 292      // 16 352 bytes
+#endif
+template <bool kHair, bool kArea, bool kSplit, bool kNodesLds = false>
 __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CULL_MINB_PLAIN) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
+  __shared__ double s_nodes[kNodesLds ? FJ_CULL_LDS_NODES * 7 : 1];
+  if (kNodesLds) {
+    const unsigned long long *src = (const unsigned long long *) S.group_nodes;
+    for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_group_nodes * 7u; w += BLOCK) ((unsigned long long *) s_nodes)[w] = src[w];
+    __syncthreads();
+  }
+  const DTNode *gnodes = kNodesLds ? (const DTNode *) s_nodes : S.group_nodes;
   unsigned long long c_insts = 0, c_shadow = 0;
   const unsigned lane = __lane_id();
   const uint32_t n = rec_end - rec_begin;
@@ -90,7 +102,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
       g_sbounds = S.groups[R.group].sbounds;
       // a single-instance group's box is the same for every light of the record: read it once
       // (per pair it cost two dependent loads -- node, then box -- before any arithmetic)
-      if (g_single) { for (int q = 0; q < 6; q++) sb[q] = g_sbounds[q]; g_inst = S.group_nodes[g_first].inst; }
+      if (g_single) { for (int q = 0; q < 6; q++) sb[q] = g_sbounds[q]; g_inst = gnodes[g_first].inst; }
     }
     // A surface point well inside that box (every point of the occluder itself, but for its outermost
     // 2e-4) needs no box test per light: the unit-length ray leaves the box at t >= 2e-4 > tmin and
@@ -209,7 +221,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
                 k_s[0] = k[0]; k_s[1] = k[1]; k_s[2] = k[2];
               }
               for (int ti = g_first; !g_single && !pending && ti < g_first + g_count;) {      // threaded instance BVH (DTNode)
-                const DTNode *tn_ = &S.group_nodes[ti];
+                const DTNode *tn_ = &gnodes[ti];
                 if (tn_->inst < 0) {
                   double tq;
                   ti = slab(tn_->box, tn_->box + 3, Ps, winv, .0001, distance, &tq) ? ti + 1 : tn_->skip;
@@ -242,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
       if (kSplit && pending && be == nb) {
         nb = 0; be = 0;
         while (tcur < g_first + g_count && nb < 4u) {        // threaded instance BVH (DTNode), resumed where it stopped
-          const DTNode *tn_ = &S.group_nodes[tcur];
+          const DTNode *tn_ = &gnodes[tcur];
           if (tn_->inst < 0) {
             double tq;
             tcur = slab(tn_->box, tn_->box + 3, Ps, winv_s, .0001, dist_s, &tq) ? tcur + 1 : tn_->skip;
@@ -373,8 +385,8 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
-  __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
-  if (kInstLds) InstLds::fill(S, s_inst);
+  __shared__ double s_inst[kInstLds ? InstLdsBig::WORDS : 1];
+  if (kInstLds) InstLdsBig::fill(S, s_inst);
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;

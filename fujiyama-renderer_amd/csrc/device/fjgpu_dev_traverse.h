@@ -122,8 +122,8 @@ __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf
 }
 
 // ---- the instance level in LDS (DInstEntry, fjgpu_types.h): [NODES DTNodes][INSTS DInstEntry][GROUPS DGroup], verbatim copies
-struct InstLds {
-  static constexpr int NODES = FJ_INST_LDS_NODES, INSTS = FJ_INST_LDS_INSTS, GROUPS = FJ_INST_LDS_GROUPS;
+template <int NODES_, int INSTS_, int GROUPS_> struct InstLdsT {
+  static constexpr int NODES = NODES_, INSTS = INSTS_, GROUPS = GROUPS_;
   static constexpr int ENTRIES_AT = NODES * 7, GROUPS_AT = ENTRIES_AT + INSTS * FJ_INST_LDS_ENTRY_WORDS;      // in 8-byte words
   static constexpr int WORDS = GROUPS_AT + GROUPS * 8;
   static bool fits(const DScene &S)        // (host: the launchers pick the kInstLds instantiations by this)
@@ -141,6 +141,8 @@ struct InstLds {
     __syncthreads();
   }
 };
+typedef InstLdsT<FJ_INST_LDS_NODES, FJ_INST_LDS_INSTS, FJ_INST_LDS_GROUPS> InstLds;                    // the phased walk: 4 blocks per CU
+typedef InstLdsT<FJ_INST_LDS_NODES_BIG, FJ_INST_LDS_INSTS_BIG, FJ_INST_LDS_GROUPS_BIG> InstLdsBig;     // 3 blocks per CU: k_trace_closest, k_shadow_trace
 
 // kInstLds: the scene's instance level sits in LDS at s_inst (filled by the kernel: InstLds); otherwise the same records are read
 // from DScene.group_nodes / inst_entries / groups.  (A run-time choice through generic pointers was measured: the flat loads
@@ -150,8 +152,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     const double *s_inst)
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
-  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT) : S.inst_entries;
-  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + InstLds::GROUPS_AT) : S.groups;
+  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLdsBig::ENTRIES_AT) : S.inst_entries;
+  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + InstLdsBig::GROUPS_AT) : S.groups;
   const unsigned lane = __lane_id();
   bool head_live = true;                   // wave-uniform: the global head still has entries
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -741,8 +743,8 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
-  __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
-  if (kInstLds) InstLds::fill(S, s_inst);
+  __shared__ double s_inst[kInstLds ? InstLdsBig::WORDS : 1];
+  if (kInstLds) InstLdsBig::fill(S, s_inst);
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};

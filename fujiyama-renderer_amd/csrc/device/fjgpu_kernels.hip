@@ -256,7 +256,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
       else hipLaunchKernelGGL((k_trace_closest_phased<false, false>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
     }
   }
-  else if (InstLds::fits(S)) {
+  else if (InstLdsBig::fits(S)) {
     if (count_events) hipLaunchKernelGGL((k_trace_closest<false, true, false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
     else hipLaunchKernelGGL((k_trace_closest<false, false, false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
   }
@@ -306,6 +306,10 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
   const bool split = sp.join_capacity != 0 && S.shadow_join != nullptr;
   if (S.has_area) { if (split) FJ_LAUNCH_CULL(true, true, true); else FJ_LAUNCH_CULL(true, true, false); }          // general instantiation
   else if (S.has_hair) { if (split) FJ_LAUNCH_CULL(true, false, true); else FJ_LAUNCH_CULL(true, false, false); }
+  else if (S.inst_lds && S.multi_shadow_groups && S.n_group_nodes <= FJ_CULL_LDS_NODES) {      // instance nodes in the blocks' LDS
+    if (split) hipLaunchKernelGGL((k_shadow_cull<false, false, true, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    else hipLaunchKernelGGL((k_shadow_cull<false, false, false, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+  }
   else { if (split) FJ_LAUNCH_CULL(false, false, true); else FJ_LAUNCH_CULL(false, false, false); }
 #undef FJ_LAUNCH_CULL
   LAUNCH_CHECK();
@@ -326,7 +330,7 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
     else if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false); }
-    else if (InstLds::fits(S)) {      // the instance level in the blocks' LDS
+    else if (InstLdsBig::fits(S)) {      // the instance level in the blocks' LDS
       if (count_events) hipLaunchKernelGGL((k_shadow_trace<false, true, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
       else hipLaunchKernelGGL((k_shadow_trace<false, false, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
     }

@@ -162,6 +162,9 @@ struct DInstEntry {
                                         // less to make it cost C5's shadow walk 1733 -> 2227 ms.)
 #define FJ_INST_LDS_INSTS 20
 #define FJ_INST_LDS_GROUPS 12
+#define FJ_INST_LDS_NODES_BIG 79        // the walks with 3 blocks per CU (k_trace_closest, k_shadow_trace of mesh scenes): 16 200 bytes
+#define FJ_INST_LDS_INSTS_BIG 40
+#define FJ_INST_LDS_GROUPS_BIG 24
 #define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent
