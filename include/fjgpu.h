@@ -162,6 +162,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * queue order (default 65536).  "split_shadow" 1/0 (default 1): in scenes served by the lean any-hit walk, a shadow
  * ray into a group of several instances is queued once per instance whose box it passes (joined by a counter)
  * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).
+ * "inst_lds" 1/0 (default 1): scenes created from now on whose instance level is small (79 threaded nodes / 40 instances /
+ * 24 groups for the closest-hit and general shadow walks of mesh scenes, 39 / 20 / 12 for the phase-scheduled walk, 292 nodes
+ * for the light loop) have it copied to LDS by every block of those walks; 0: it is read from global memory (same results).
  * "batch_tiles" n: scenes created from now on start with the per-scene option of that name set to n (0 = sized by
  * memory; how a host that never sees the scene handle -- SiRenderScene -- cuts a frame into batches).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);

@@ -408,6 +408,32 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
         assert float(rel_err(frames[0][0], frames[1][0]).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("builder,kw", [
+    ("cornell", dict(res=(96, 54), spp=(3, 3), mesh="tiny")),          # the phase-scheduled walk (39 / 20 / 12)
+    ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="tiny")),          # k_trace_closest + the light loop's candidate search
+    ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=30)),      # 30 instances: beyond the phased walk's budget, inside the big one
+    ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=150)),     # fits no walk's budget (the light loop's node copy only)
+    ("arealights", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
+])
+def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
+    """option inst_lds: the walks of a scene whose instance level fits their budget read it from an LDS copy
+    (DInstEntry); off, from global memory.  Same event counters, same ray counts, same pixels, and the oracle's."""
+    text = getattr(workloads, builder)(asset_dir, **kw)
+    out = []
+    for on in (1, 0):
+        gpu.global_option("inst_lds", on)
+        try:
+            fb, st, ref, rc = render_both(text)
+        finally:
+            gpu.global_option("inst_lds", 1)
+        assert_parity(fb, st, ref, rc)
+        out.append((fb, st))
+    (fb1, st1), (fb0, st0) = out
+    assert st1.rays.as_dict() == st0.rays.as_dict()
+    assert (st1.nodes_visited, st1.prims_tested, st1.insts_tested) == (st0.nodes_visited, st0.prims_tested, st0.insts_tested)
+    assert float(rel_err(fb1, fb0).max()) <= 1e-5
+
+
 def test_hair_shader_declared_in_an_all_opaque_mesh_scene_with_split_shadow_rays(asset_dir):
     """a HairShader in a scene WITHOUT curves whose shadow groups hold several instances: the light loop runs its
     hair instantiation, and that one must queue rays per candidate instance exactly like the plain one does (the
