@@ -417,7 +417,7 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
 ])
 def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
     """option inst_lds: the walks of a scene whose instance level fits their budget read it from an LDS copy
-    (DInstEntry); off, from global memory.  Same event counters, same ray counts, same pixels, and the oracle's."""
+    (DInstEntry); off, from global memory.  Same ray counts, same instance-level events, same pixels, and the oracle's."""
     text = getattr(workloads, builder)(asset_dir, **kw)
     out = []
     for on in (1, 0):
@@ -430,7 +430,13 @@ def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
         out.append((fb, st))
     (fb1, st1), (fb0, st0) = out
     assert st1.rays.as_dict() == st0.rays.as_dict()
-    assert (st1.nodes_visited, st1.prims_tested, st1.insts_tested) == (st0.nodes_visited, st0.prims_tested, st0.insts_tested)
+    # instance-level events are per ray and order-free: equal.  Node / triangle counts of the ANY-HIT walk are not a function
+    # of the ray alone: a lane sets a leaf aside and walks on while its wave runs inner steps (FJ_ANYHIT_POSTPONE), so an
+    # occluded ray visits a few nodes more or less depending on which rays the light loop's atomics queued next to it
+    # (measured on the box: 75 of 412 663 between two runs) -- same order of magnitude is all that can be asserted.
+    assert st1.insts_tested == st0.insts_tested
+    assert abs(st1.nodes_visited - st0.nodes_visited) <= 0.01 * st0.nodes_visited
+    assert abs(st1.prims_tested - st0.prims_tested) <= 0.01 * st0.prims_tested
     assert float(rel_err(fb1, fb0).max()) <= 1e-5
 
 
