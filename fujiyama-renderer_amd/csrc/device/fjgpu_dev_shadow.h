@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
-  __shared__ double s_inst[kInstLds ? InstLdsBig::WORDS : 1];
-  if (kInstLds) InstLdsBig::fill(S, s_inst);
+  __shared__ double s_inst[kInstLds ? InstLdsOf<kCurves>::T::WORDS : 1];
+  if (kInstLds) InstLdsOf<kCurves>::T::fill(S, s_inst);
   const uint32_t n = cnt->shadow_count;         // written by k_shadow_cull earlier on this stream
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;

@@ -143,6 +143,9 @@ template <int NODES_, int INSTS_, int GROUPS_> struct InstLdsT {
 };
 typedef InstLdsT<FJ_INST_LDS_NODES, FJ_INST_LDS_INSTS, FJ_INST_LDS_GROUPS> InstLds;                    // the phased walk: 4 blocks per CU
 typedef InstLdsT<FJ_INST_LDS_NODES_BIG, FJ_INST_LDS_INSTS_BIG, FJ_INST_LDS_GROUPS_BIG> InstLdsBig;     // 3 blocks per CU: k_trace_closest, k_shadow_trace
+typedef InstLdsT<FJ_INST_LDS_NODES_CURVES, FJ_INST_LDS_INSTS_CURVES, FJ_INST_LDS_GROUPS_CURVES> InstLdsCurves;   // ... of scenes with curve sets
+template <bool kCurves> struct InstLdsOf { typedef InstLdsBig T; };
+template <> struct InstLdsOf<true> { typedef InstLdsCurves T; };
 
 // kInstLds: the scene's instance level sits in LDS at s_inst (filled by the kernel: InstLds); otherwise the same records are read
 // from DScene.group_nodes / inst_entries / groups.  (A run-time choice through generic pointers was measured: the flat loads
@@ -152,8 +155,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     const double *s_inst)
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
-  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLdsBig::ENTRIES_AT) : S.inst_entries;
-  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + InstLdsBig::GROUPS_AT) : S.groups;
+  typedef typename InstLdsOf<kCurves>::T IL;
+  const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + IL::ENTRIES_AT) : S.inst_entries;
+  const DGroup *ggroups = kInstLds ? (const DGroup *) (s_inst + IL::GROUPS_AT) : S.groups;
   const unsigned lane = __lane_id();
   bool head_live = true;                   // wave-uniform: the global head still has entries
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -743,8 +747,8 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
 {
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
-  __shared__ double s_inst[kInstLds ? InstLdsBig::WORDS : 1];
-  if (kInstLds) InstLdsBig::fill(S, s_inst);
+  __shared__ double s_inst[kInstLds ? InstLdsOf<kCurves>::T::WORDS : 1];
+  if (kInstLds) InstLdsOf<kCurves>::T::fill(S, s_inst);
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};

@@ -246,7 +246,13 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
 #define FJ_LAUNCH_CLOSEST(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT, MOTION>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
   if (S.has_motion) {      // time-sampled instance transforms: one general instantiation
     if (count_events) FJ_LAUNCH_CLOSEST(true, true, true); else FJ_LAUNCH_CLOSEST(true, false, true);
-  } else if (S.has_curves) { if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false); }
+  } else if (S.has_curves) {
+    if (InstLdsCurves::fits(S)) {      // the instance level in the blocks' LDS
+      if (count_events) hipLaunchKernelGGL((k_trace_closest<true, true, false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+      else hipLaunchKernelGGL((k_trace_closest<true, false, false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
+    }
+    else if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false);
+  }
   else if (S.incoherent_rays) {   // glass / pathtracing scenes: the phase-scheduled walk (see k_trace_closest_phased)
     if (InstLds::fits(S)) {     // the instance level in the blocks' LDS
       if (count_events) hipLaunchKernelGGL((k_trace_closest_phased<true, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
@@ -329,7 +335,13 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
-    else if (S.has_curves) { if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false); }
+    else if (S.has_curves) {
+      if (InstLdsCurves::fits(S)) {      // the instance level in the blocks' LDS
+        if (count_events) hipLaunchKernelGGL((k_shadow_trace<true, true, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+        else hipLaunchKernelGGL((k_shadow_trace<true, false, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+      }
+      else if (count_events) FJ_LAUNCH_SHADOW(true, true, false); else FJ_LAUNCH_SHADOW(true, false, false);
+    }
     else if (InstLdsBig::fits(S)) {      // the instance level in the blocks' LDS
       if (count_events) hipLaunchKernelGGL((k_shadow_trace<false, true, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
       else hipLaunchKernelGGL((k_shadow_trace<false, false, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());

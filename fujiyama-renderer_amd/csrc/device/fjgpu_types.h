@@ -65,7 +65,7 @@ static_assert(sizeof(DNodeQ8) == 128, "DNodeQ8 must be 128 bytes");
 // kernels instantiated with the ribbon test keep fewer stack entries in LDS: they also hold the
 // ray-space frame and one cached node of the curve subdivision per lane (fjgpu_dev_curve.h)
 #ifndef FJ_STACK_LDS_CURVES
-#define FJ_STACK_LDS_CURVES 24
+#define FJ_STACK_LDS_CURVES 20          // (measured in round 3: 20 / 24 entries and 40 without the subdivision cache give the same C5 walk, 1740 / 1743 / 1767 ms)
 #endif
 // the lean any-hit walk runs SIX blocks per CU: 12 entries x 1 KB per block + 12 KB for the object-space rays
 // (FJ_ANYHIT_RAY_LDS, fjgpu_dev_anyhit.h) = 24 KB per block; 14 entries: the same time
@@ -165,6 +165,9 @@ struct DInstEntry {
 #define FJ_INST_LDS_NODES_BIG 79        // the walks with 3 blocks per CU (k_trace_closest, k_shadow_trace of mesh scenes): 16 200 bytes
 #define FJ_INST_LDS_INSTS_BIG 40
 #define FJ_INST_LDS_GROUPS_BIG 24
+#define FJ_INST_LDS_NODES_CURVES 15     // the curve instantiations (3 blocks per CU, 20 KB of stacks + 28 KB of ray space per block): 3 656 bytes
+#define FJ_INST_LDS_INSTS_CURVES 8
+#define FJ_INST_LDS_GROUPS_CURVES 12
 #define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent

@@ -414,6 +414,7 @@ def test_shadow_rays_split_per_candidate_instance(asset_dir):
     ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=30)),      # 30 instances: beyond the phased walk's budget, inside the big one
     ("crowd", dict(res=(64, 48), spp=(2, 2), mesh="tiny", n=150)),     # fits no walk's budget (the light loop's node copy only)
     ("arealights", dict(res=(64, 48), spp=(2, 2), mesh="tiny", kind="both")),
+    ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),   # the curve instantiations' own budget (15 / 8 / 12)
 ])
 def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
     """option inst_lds: the walks of a scene whose instance level fits their budget read it from an LDS copy
