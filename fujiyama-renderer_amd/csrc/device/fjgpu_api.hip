@@ -339,6 +339,24 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
       P.qnodes = q;
     }
+    // curve sets: the same quantised twin for the closest-hit / general shadow walks of scenes with curve sets (kept out of
+    // DPrimSet.qnodes, which the lean any-hit walk's tables read as "a mesh with pre-gathered triangles").  The grid spans the
+    // set's bounds widened by 1e-4 of their size (at least 1e-4), so no node box is clamped at the rim.
+    std::vector<const DNodeQ *> cq(dps.size(), nullptr);
+    for (size_t i = 0; FJ_CURVE_QNODES && FJ_CLOSEST_QNODES && i < dps.size(); i++) {
+      const DPrimSet &P = dps[i];
+      if (P.type != FJ_PRIMSET_CURVE || P.n_prims == 0 || e) continue;
+      const size_t n_nodes = std::max<size_t>(1, hs.primsets[i].nodes.size());
+      for (int a = 0; a < 3; a++) {
+        const double pad = 1e-4 * std::max(1., P.bounds[3 + a] - P.bounds[a]);
+        qgrid[i][a] = P.bounds[a] - pad;
+        qgrid[i][3 + a] = std::max(1e-300, (P.bounds[3 + a] - P.bounds[a] + 2 * pad) / 65535. * (1 + 1e-9));
+      }
+      DNodeQ *q = nullptr;
+      if (M.alloc(n_nodes, &q)) { e = 1; continue; }
+      if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
+      cq[i] = q;
+    }
     // ... and of the 8-wide twin (host builds of meshes: DNode8 -> DNodeQ8, the same grid)
     std::vector<const DNodeQ8 *> q8(dps.size(), nullptr);
     bool wide_all = true, any_mesh = false;
@@ -370,7 +388,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         const DPrimSet &P = dps[I.primset];
         std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
         I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
-        I.pqnodes = P.qnodes;
+        I.pqnodes = P.qnodes ? P.qnodes : cq[I.primset];
         for (int k = 0; k < 3; k++) { I.qorigin[k] = qgrid[I.primset][k]; I.qcell[k] = qgrid[I.primset][3 + k]; }
       }
       e |= M.upload(di.data(), di.size(), &S.instances);
@@ -387,7 +405,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         std::memcpy(E.pbounds, I.pbounds, sizeof(E.pbounds));
         for (int a = 0; a < 3; a++) { E.qorigin[a] = I.qorigin[a]; E.qcell[a] = I.qcell[a]; }
         const DPrimSet &P = dps[I.primset];
-        const bool quantised = FJ_CLOSEST_QNODES && !any_curves && !any_motion;     // (the instantiations launch_trace_closest picks)
+        const bool quantised = FJ_CLOSEST_QNODES && (!any_curves || FJ_CURVE_QNODES) && !any_motion;     // (the instantiations launch_trace_closest picks)
         E.nodes = quantised ? (const void *) I.pqnodes : (const void *) I.pnodes;
         E.ptype = P.type; E.pad = 0;
         E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
@@ -678,7 +696,7 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   // 2 k_trace_closest<true, *, false> (curve sets), 3 k_trace_closest<true, *, true> (time-sampled transforms / vertex velocities)
   if (n == "closest_kernel") { *value = scene->S.has_motion ? 3 : (scene->S.has_curves ? 2 : (scene->S.incoherent_rays ? 1 : 0)); return 0; }
   // ... and the node record it reads: the 64-byte quantised twin unless the ribbon test / motion instantiation runs
-  if (n == "closest_node_record_bytes") { *value = (double) ((scene->S.has_motion || scene->S.has_curves || !FJ_CLOSEST_QNODES) ? sizeof(DNode) : sizeof(DNodeQ)); return 0; }
+  if (n == "closest_node_record_bytes") { *value = (double) ((scene->S.has_motion || (scene->S.has_curves && !FJ_CURVE_QNODES) || !FJ_CLOSEST_QNODES) ? sizeof(DNode) : sizeof(DNodeQ)); return 0; }
   if (n == "has_curves") { *value = scene->S.has_curves; return 0; }
   if (n == "has_motion") { *value = scene->S.has_motion; return 0; }
   return fail(FJGPU_EINVAL, "unknown query " + n);

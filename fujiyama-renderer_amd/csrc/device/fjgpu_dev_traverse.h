@@ -189,6 +189,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   uint32_t cur = TRAV_DONE;
   uint32_t last_curve = 0xffffffffu;      // curve tested last for this (ray, instance)
   uint32_t pend = 0xffffffffu;            // BLAS slot of a curve whose second-stage test is deferred (the lane walks on)
+                                           // (a SECOND deferred slot, so that a lane waits only at its third candidate, was measured on C5: shadow
+                                           // walk 1692 -> 1695 ms with 3 % more nodes visited -- lanes waiting at a candidate are not what it lacks)
   int sp = 0;
 #ifdef FJ_PHASE_STATS
   unsigned long long it_all = 0, it_tail = 0;   // wave iterations; ... after the queue ran dry for this wave
@@ -299,7 +301,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         nodes = (const DNode *) I->nodes;
         if (I->pn_prims == 0) continue;
         if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
-        if (FJ_CLOSEST_QNODES && !kCurves) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
+        if (FJ_CLOSEST_QNODES && (!kCurves || (FJ_CURVE_QNODES && !kMotion))) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
         else s32 = slab32_setup(oo, inv, I->pbounds);
         root = I->proot;
         into_curves = kCurves && I->ptype == FJ_PRIMSET_CURVE;
@@ -325,7 +327,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         float t0, t1, t2, t3;
         bool h0, h1, h2, h3;
         fj_v4u e;
-        if (FJ_CLOSEST_QNODES && !kCurves) {
+        if (FJ_CLOSEST_QNODES && (!kCurves || (FJ_CURVE_QNODES && !kMotion))) {
           // 64-byte quantised node (DNodeQ): four 16-byte loads, sign-aware packed slab tests (slab32q_test)
           const FJ_GLOBAL fj_v4u *nq = (const FJ_GLOBAL fj_v4u *) ((const DNodeQ *) nodes + cur);
           const fj_v4u w0 = nq[0], w1 = nq[1], w2 = nq[2];

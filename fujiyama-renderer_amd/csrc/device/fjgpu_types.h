@@ -48,6 +48,9 @@ struct DNodeQ8 {
 };
 static_assert(sizeof(DNodeQ8) == 128, "DNodeQ8 must be 128 bytes");
 
+#ifndef FJ_CURVE_QNODES
+#define FJ_CURVE_QNODES 1                // 1: the curve instantiations (scenes with curve sets, no motion) read quantised 64-byte nodes too
+#endif
 #ifndef FJ_CLOSEST_QNODES
 #define FJ_CLOSEST_QNODES 1              // 0: the closest-hit walk reads the 128-byte f32 nodes in every instantiation
 #endif

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 900 python -m pytest tests -m gpu -q -x -k "curve or hair or frames_match or adaptive" > gpurun_out/r03_job46_pytest.log 2>&1
+tail -n 3 gpurun_out/r03_job46_pytest.log | cut -c1-300
+A='--no-pmc --steps 3 --warmup 1 --workload furry'
+timeout 1200 python scripts/exp.py r03_exp46 "furry_qnodes||$A"
