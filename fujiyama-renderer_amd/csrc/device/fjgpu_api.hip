@@ -458,14 +458,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     }
     e |= M.upload(ai.data(), ai.size(), &S.any_insts);
   }
-  if (getenv("FJGPU_EXP_SWAP2")) {      // EXPERIMENT: the two instances of two-instance groups in the other order (any-hit walks only care about cost)
-    for (auto &g : hs.groups) if (g.n_instances == 2) {
-      int a = -1, b = -1;
-      for (int k = g.first; k < g.first + g.count; k++) if (hs.group_nodes[k].inst >= 0) { if (a < 0) a = k; else b = k; }
-      if (a >= 0 && b >= 0) { std::swap(hs.group_nodes[a].inst, hs.group_nodes[b].inst); for (int q = 0; q < 6; q++) std::swap(hs.group_nodes[a].box[q], hs.group_nodes[b].box[q]); }
-    }
-  }
-  if (g_device_tlas && !getenv("FJGPU_EXP_SWAP2") && e == 0 && !hs.groups.empty()) {
+  if (g_device_tlas && e == 0 && !hs.groups.empty()) {
     // instance level on the device, from the instance table just uploaded
     std::vector<int> mcount(hs.groups.size()), nfirst, ncount;
     for (size_t g = 0; g < hs.groups.size(); g++) mcount[g] = hs.groups[g].n_instances;
