@@ -160,9 +160,8 @@ struct DInstEntry {
 };
 #define FJ_INST_LDS_ENTRY_WORDS 32      // sizeof(DInstEntry) / 8
 // budgets: DTNodes (56 B), DInstEntry records (256 B), DGroups (64 B)
-#define FJ_INST_LDS_NODES 39            // 8 072 bytes next to the 32 KB of stacks of a block: the phased walk still has 4 blocks per CU.  (The curve /
-                                        // motion kernels -- 52 KB of stacks and ray space per block, 3 blocks per CU -- have no room: two stack entries
-                                        // less to make it cost C5's shadow walk 1733 -> 2227 ms.)
+#define FJ_INST_LDS_NODES 39            // 8 072 bytes next to the 32 KB of stacks of a block: the phased walk still has 4 blocks per CU.  (The curve
+                                        // instantiations have a budget of their own below; the motion kernels read global memory.)
 #define FJ_INST_LDS_INSTS 20
 #define FJ_INST_LDS_GROUPS 12
 #define FJ_INST_LDS_NODES_BIG 79        // the walks with 3 blocks per CU (k_trace_closest, k_shadow_trace of mesh scenes): 16 200 bytes
