@@ -150,7 +150,9 @@ template <> struct InstLdsOf<true> { typedef InstLdsCurves T; };
 // kInstLds: the scene's instance level sits in LDS at s_inst (filled by the kernel: InstLds); otherwise the same records are read
 // from DScene.group_nodes / inst_entries / groups.  (A run-time choice through generic pointers was measured: the flat loads
 // cost the fallback 8 % -- C2's closest-hit walk 20.1 -> 21.9 ms.)
-template <bool kCurves, bool kCount, bool kMotion, bool kInstLds, class Policy>
+// kAnyOnly: every ray of the launch is an any-hit ray and an occluded one adds nothing (shadow rays of scenes whose occluders are all
+// opaque): no hit record is kept at all -- a hit retires the ray on the spot, a ray that runs out of instances reaches the light.
+template <bool kCurves, bool kCount, bool kMotion, bool kInstLds, bool kAnyOnly, class Policy>
 __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc,
     const double *s_inst)
 {
@@ -181,7 +183,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   int group = 0;
   bool single = false;                     // the group has one instance (its padded box is the test)
   const double *gsb = nullptr;
-  bool anyhit = false, dead_ray = false, plain = false;
+  bool anyhit = kAnyOnly, dead_ray = false, plain = false;
   bool deep = false;                       // holding a curve whose ribbon test awaits its second stage
   const DPrimSet *P = nullptr;
   const DNode *nodes = nullptr;            // P->nodes, kept in registers: re-reading it through P put a
@@ -191,6 +193,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   uint32_t pend = 0xffffffffu;            // BLAS slot of a curve whose second-stage test is deferred (the lane walks on)
                                            // (a SECOND deferred slot, so that a lane waits only at its third candidate, was measured on C5: shadow
                                            // walk 1692 -> 1695 ms with 3 % more nodes visited -- lanes waiting at a candidate are not what it lacks)
+                                           // (POSTPONED leaves for any-hit rays as in the lean any-hit walk -- a lane at a leaf with a non-empty stack
+                                           // sets the leaf aside and stays in the inner steps -- parity green, 1515 -> 1570 ms: every piece of added
+                                           // state has cost this 168-VGPR kernel more in spills than it saved in iterations)
   int sp = 0;
 #ifdef FJ_PHASE_STATS
   unsigned long long it_all = 0, it_tail = 0;   // wave iterations; ... after the queue ran dry for this wave
@@ -218,7 +223,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
           have = pol.fetch(my, &r);
           idx = my;
-          tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
+          tmin = r.tmin; tmax = r.tmax; anyhit = kAnyOnly ? true : r.anyhit;
           if (kMotion) rtime = r.time;
           group = r.group;
           const DGroup *G = &ggroups[r.group];
@@ -402,6 +407,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           }
           if (!tri_ray(v0, v1, v2, oo, od, &t, &u, &v)) continue;
           if (!(tmin <= t && t <= tmax)) continue;
+          if (kAnyOnly) { stop = true; break; }
           const int pid = (int) FJ_G(uint32_t, P->prim_ids)[first + k];
           if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
             best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
@@ -409,7 +415,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           }
         }
       }
-      if (stop) { pol.finish(idx, best); have = false; cur = TRAV_DONE; }
+      if (stop) { if (!kAnyOnly) pol.finish(idx, best); have = false; cur = TRAV_DONE; }
       else if (!deep) cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
     }
 
@@ -446,14 +452,17 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
                 (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
                 (tmin <= t && t <= tmax)) {
-              const int pid = (int) FJ_G(uint32_t, P->prim_ids)[sl];
               FJ_CURVE_STAT(4, 1);          // second-stage tests that hit
-              if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
-                best.t = t; best.u = u; best.v = (double) sl; best.inst = ii; best.prim = pid;
-                stop = anyhit;
+              if (kAnyOnly) stop = true;
+              else {
+                const int pid = (int) FJ_G(uint32_t, P->prim_ids)[sl];
+                if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+                  best.t = t; best.u = u; best.v = (double) sl; best.inst = ii; best.prim = pid;
+                  stop = anyhit;
+                }
               }
             }
-            if (stop) { pol.finish(idx, best); have = false; deep = false; cur = TRAV_DONE; }
+            if (stop) { if (!kAnyOnly) pol.finish(idx, best); have = false; deep = false; cur = TRAV_DONE; }
             else if (deep) {
               // the curve this lane was waiting at becomes the deferred one; walk on
               pend = (cur & 0x7fffffffu) >> 3;
@@ -754,7 +763,7 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion, kInstLds>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
+  traverse_persistent<kCurves, kCount, kMotion, kInstLds, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

@@ -336,7 +336,11 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
     else if (S.has_curves) {
-      if (InstLdsCurves::fits(S)) {      // the instance level in the blocks' LDS
+      if (InstLdsCurves::fits(S) && S.all_opaque) {      // ... and no hit records: every ray any-hit, an occluded one adds nothing
+        if (count_events) hipLaunchKernelGGL((k_shadow_trace<true, true, false, true, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+        else hipLaunchKernelGGL((k_shadow_trace<true, false, false, true, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+      }
+      else if (InstLdsCurves::fits(S)) {      // the instance level in the blocks' LDS
         if (count_events) hipLaunchKernelGGL((k_shadow_trace<true, true, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
         else hipLaunchKernelGGL((k_shadow_trace<true, false, false, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
       }
