@@ -352,7 +352,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         h2 = e.z != FJ_NO_CHILD && slab32_test(q3.xy, q3.zw, q4.xy, s32, tmin32, tmax32, &t2);
         h3 = e.w != FJ_NO_CHILD && slab32_test(q4.zw, q5.xy, q5.zw, s32, tmin32, tmax32, &t3);
         }
-        // near-to-far order is a heuristic only: f32 keys, misses sort last
+        // near-to-far order is a heuristic only: f32 keys, misses sort last.  (Any-hit rays do not need an order, but the network of
+        // five compare-exchanges is cheaper than what replaces it: children in slot order visit 7 % more nodes, the nearest child first
+        // and the rest in slot order costs four data-dependent pushes instead of three nested ones -- C5 shadow walk 1408 -> 1488 ms.)
         float k0 = h0 ? t0 : INFINITY, k1 = h1 ? t1 : INFINITY;
         float k2 = h2 ? t2 : INFINITY, k3 = h3 ? t3 : INFINITY;
         uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
