@@ -748,7 +748,9 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
     // owns at least two queue entries
     sc->d_join = nullptr; sc->join_cap = 0;
-    if (sc->split_shadow) { sc->join_cap = sc->squeue_cap / 2 + 1; e |= W.alloc(sc->join_cap, &sc->d_join); }
+    // (a slot per ray with >= 2 entries, + the slots the light loop's waves reserve 64 at a time and may leave unused: 32 launches' worth;
+    // more than that overflows like the queue does and the frame is rendered again without the split)
+    if (sc->split_shadow) { sc->join_cap = sc->squeue_cap / 2 + 1 + 32 * (persistent_threads() / 64) * 64; e |= W.alloc(sc->join_cap, &sc->d_join); }
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
     if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }

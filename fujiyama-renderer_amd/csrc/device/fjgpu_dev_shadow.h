@@ -20,6 +20,9 @@
 #ifndef SQ_CHUNK
 #define SQ_CHUNK 512u          // shadow-queue slots a wave reserves per global atomic
 #endif
+#ifndef JQ_CHUNK
+#define JQ_CHUNK 64u           // join slots a wave reserves per global atomic (split shadow rays; >= 64: one round may need a slot per lane); fjgpu_api.hip sizes the slack
+#endif
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
 
 #ifndef FJ_CULL_MINB
@@ -58,6 +61,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
   // instead of one per wave iteration (a single-address atomic per iteration
   // serialised the whole kernel in L2)
   uint32_t chunk_base = 0, chunk_used = SQ_CHUNK;   // wave-uniform; "used == CHUNK" = no chunk yet
+  uint32_t jchunk_base = 0, jchunk_used = JQ_CHUNK; // the same for the join slots of split rays
 
   uint32_t slice_end = 0, r0 = 0;
   for (;; r0 += 64u) {
@@ -277,13 +281,20 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
       // a second candidate: the ray gets a join slot (one atomic per wave) before any of its entries is written
       const unsigned long long m_slot = kSplit ? __ballot(need_slot) : 0ull;
       if (kSplit && m_slot) {
-        uint32_t base = 0;
-        if (lane == (unsigned) __ffsll((long long) m_slot) - 1u) base = atomicAdd(&cnt->join_count, (uint32_t) __popcll(m_slot));
-        base = __shfl(base, __ffsll((long long) m_slot) - 1);
+        // join slots are reserved JQ_CHUNK at a time like the queue's: one atomic per wave and ROUND on the one counter
+        // serialised in L2 (slots a wave reserves and does not use are never referenced)
+        const uint32_t n_slot = (uint32_t) __popcll(m_slot);
+        if (jchunk_used + n_slot > JQ_CHUNK) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&cnt->join_count, JQ_CHUNK);
+          jchunk_base = __shfl(base, 0);
+          jchunk_used = 0;
+        }
         if (need_slot) {
-          jslot1 = base + (uint32_t) __popcll(m_slot & ((1ull << lane) - 1ull)) + 1u;
+          jslot1 = jchunk_base + jchunk_used + (uint32_t) __popcll(m_slot & ((1ull << lane) - 1ull)) + 1u;
           if (jslot1 > sp.join_capacity) { cnt->overflow = 1; jslot1 = 1; }
         }
+        jchunk_used += n_slot;
       }
       if (kSplit && pending && be < nb) {
         const int cand = be == 0u ? cb0 : (be == 1u ? cb1 : (be == 2u ? cb2 : cb3));

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 900 python -m pytest tests -m gpu -q -x -k "split or crowd or frames_match or instance_level or whole_frame_c2" > gpurun_out/r03_job54_pytest.log 2>&1
+tail -n 3 gpurun_out/r03_job54_pytest.log | cut -c1-300
+timeout 1500 python scripts/exp.py r03_exp54 \
+  "buddhas_jchunk||--no-pmc --steps 8 --warmup 3 --workload buddhas" \
+  "crowd||--no-pmc --steps 8 --warmup 3 --workload crowd"
