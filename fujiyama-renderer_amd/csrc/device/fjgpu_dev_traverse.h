@@ -176,7 +176,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o, winv = o;
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};        // conservative f32 slab constants of (ray, instance)
-  double tmin = 0, tmax = 0, rtime = 0;
+  double tmin = kAnyOnly ? .0001 : 0, tmax = 0, rtime = 0;    // (kAnyOnly = shadow rays: tmin is the constant ShadowPolicy hands out)
   Best best;
   best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
   int ti = 0, tend = 0, ii = -1;           // cursor in the group's threaded instance BVH
@@ -223,7 +223,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           r.o = r.d = mk(0, 0, 1); r.tmin = r.tmax = r.time = 0; r.group = 0; r.anyhit = false;
           have = pol.fetch(my, &r);
           idx = my;
-          tmin = r.tmin; tmax = r.tmax; anyhit = kAnyOnly ? true : r.anyhit;
+          tmin = kAnyOnly ? .0001 : r.tmin; tmax = r.tmax; anyhit = kAnyOnly ? true : r.anyhit;
           if (kMotion) rtime = r.time;
           group = r.group;
           const DGroup *G = &ggroups[r.group];
