@@ -41,6 +41,7 @@ import torch.distributed as dist  # noqa: E402
 from fujiyama_renderer_amd import distributed as fjdist  # noqa: E402
 from fujiyama_renderer_amd import gpu, host, workloads  # noqa: E402
 
+TRAFFIC_OVER_ALGORITHMIC_LAST_MEASURED = 0.33   # fabric-side bytes / algorithmic bytes of the dominant walk, last counter run (roofline.frac_source)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per traversal event (SURVEY.md 8d / DESIGN.md 7)
 # (node and triangle record sizes are those of the built layout: fjgpu_scene_query)
@@ -466,9 +467,19 @@ def main():
         # (`binding_resource`: "valu" when the VALU issue utilisation is the larger fraction).  The algorithmic
         # bytes of SURVEY 8(d) are reported under `algorithmic` and never priced against the HBM peak.
         bound, frac, achieved, peak, unit = "hbm", None, None, HBM_PEAK_GBPS, "GB/s"
+        frac_source = "hardware counters (rocprofv3 --pmc child passes of this run)"
         if hbm:
             achieved = min(hbm["GBps"], HBM_PEAK_GBPS)
             frac = achieved / HBM_PEAK_GBPS
+        elif walk_alg and avg_ms:
+            # no counter passes in this run (rocprofv3 missing, --no-pmc, a rank-share run or world > 1): the contract's fields
+            # stay numbers -- an ESTIMATE from this run's algorithmic bytes and the traffic / algorithmic ratio the counters gave
+            # for this kernel family last time they ran (profiles/r03_bench_dragon1080p.json: 0.33) -- and say so
+            traffic = TRAFFIC_OVER_ALGORITHMIC_LAST_MEASURED * walk_alg / walk_nl
+            achieved = min(traffic / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBPS)
+            frac = achieved / HBM_PEAK_GBPS
+            frac_source = ("UNCALIBRATED estimate: algorithmic bytes of this run x %.2f (the traffic / algorithmic ratio of the last counter run, "
+                           "profiles/r03_bench_dragon1080p.json); the counter passes did not run" % TRAFFIC_OVER_ALGORITHMIC_LAST_MEASURED)
         binding = None
         if issue and frac is not None:
             binding = "valu" if issue["valu_busy"] > frac else "hbm"
@@ -477,7 +488,7 @@ def main():
                 "kernel": kname, "launches": int(walk_nl), "avg_launch_ms": avg_ms,
                 "share_of_frame": walk_ms / frame_ms_sum,
                 "picked_by": "largest measured HIP-event time among the traversal kernels",
-                "binding_resource": binding,
+                "binding_resource": binding, "frac_source": frac_source, "uncalibrated": hbm is None,
                 "hbm_counters": hbm, "valu_issue": issue,
                 "algorithmic": {"bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
                                 "GBps": walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,

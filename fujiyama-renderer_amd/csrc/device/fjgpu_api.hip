@@ -357,28 +357,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (launch_quantize_nodes(nullptr, P.nodes, (uint32_t) n_nodes, &qgrid[i][0], &qgrid[i][3], q)) e = 1;
       cq[i] = q;
     }
-    // ... and of the 8-wide twin (host builds of meshes: DNode8 -> DNodeQ8, the same grid)
-    std::vector<const DNodeQ8 *> q8(dps.size(), nullptr);
-    bool wide_all = true, any_mesh = false;
-    for (size_t i = 0; i < dps.size(); i++) {
-      const DPrimSet &P = dps[i];
-      if (P.type != FJ_PRIMSET_MESH || P.n_prims == 0) continue;
-      any_mesh = true;
-      const fjgpu::HostPrimSet &h = hs.primsets[i];
-      if (!P.qnodes || e) { wide_all = false; continue; }
-      if (h.root8 & FJ_LEAF_FLAG) continue;               // a tree that is one leaf: nothing to read
-      if (h.nodes8.size() == 0) { wide_all = false; continue; }
-      const DNode8 *src = nullptr;
-      DNodeQ8 *q = nullptr;
-      void *tmp = nullptr;
-      if (hipMalloc(&tmp, h.nodes8.size() * sizeof(DNode8)) != hipSuccess) { e = 1; continue; }
-      src = static_cast<const DNode8 *>(tmp);
-      if (hipMemcpy(tmp, h.nodes8.data(), h.nodes8.size() * sizeof(DNode8), hipMemcpyHostToDevice) != hipSuccess || M.alloc(h.nodes8.size(), &q) ||
-          launch_quantize_nodes8(nullptr, src, (uint32_t) h.nodes8.size(), &qgrid[i][0], &qgrid[i][3], q) || hipDeviceSynchronize() != hipSuccess) e = 1;
-      (void) hipFree(tmp);
-      q8[i] = q;
-    }
-    S.anyhit_wide = (wide_all && any_mesh && getenv("FJGPU_WIDE8")) ? 1 : 0;
     lap("quantised nodes");
     e |= M.upload(dps.data(), dps.size(), &S.primsets);      // (after the loops above: DPrimSet.qnodes is set)
     {
@@ -422,14 +400,12 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (!P.qnodes) continue;
       const uintptr_t pn = (uintptr_t) P.qnodes, pt = tris_of(P);
       lo = std::min(lo, std::min(pn, pt)); hi = std::max(hi, std::max(pn, pt));
-      if (q8[i]) { lo = std::min(lo, (uintptr_t) q8[i]); hi = std::max(hi, (uintptr_t) q8[i]); }
     }
     // (hipMalloc returns 256-byte aligned blocks: offsets in units of 128 B span 512 GB)
     bool fits = lo != UINTPTR_MAX && lo % 128 == 0 && (hi - lo) / 128 < 0xffffffffull;
     for (size_t i = 0; i < dps.size(); i++) {
       const DPrimSet &P = dps[i];
       if (P.qnodes && (((uintptr_t) P.qnodes - lo) % 128 != 0 || (tris_of(P) - lo) % 128 != 0)) fits = false;
-      if (q8[i] && ((uintptr_t) q8[i] - lo) % 128 != 0) fits = false;
     }
     // the lean walk reads f32 triangle records only (every PLY mesh): a mesh that needs f64
     // vertices sends the scene's shadow rays through the general walk
@@ -452,8 +428,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         a.node_base = (uint32_t) (((uintptr_t) P.qnodes - lo) / 128);
         a.tri_base = (uint32_t) ((tris_of(P) - lo) / 128);
         a.tris_f32 = P.tri_verts32 ? 1 : 0;
-        a.root8 = hs.primsets[I.primset].root8;
-        a.node8_base = q8[I.primset] ? (uint32_t) (((uintptr_t) q8[I.primset] - lo) / 128) : 0u;
       }
     }
     e |= M.upload(ai.data(), ai.size(), &S.any_insts);
@@ -520,7 +494,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
   {
     int need = 0;
-    for (const auto &ps : hs.primsets) need = std::max(need, std::max(ps.stack_need, S.anyhit_wide ? ps.stack_need8 : 0));
+    for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;
     // (scenes with curve sets run the kernels that keep FJ_STACK_LDS_CURVES entries in LDS)
@@ -532,6 +506,10 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       const size_t entries = (size_t) (need - lds_entries) * persistent_threads();
       if (M.alloc(entries, &S.stack_overflow) || M.alloc(entries, &S.stack_overflow_shadow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
+    // chunk lists of the walks' end games (DEndGame): zero between launches
+    if (M.alloc((size_t) FJ_LEFT_CAP, &S.left_trace) || M.alloc((size_t) FJ_LEFT_CAP, &S.left_shadow) ||
+        hipMemset(S.left_trace, 0, sizeof(unsigned long long) * FJ_LEFT_CAP) != hipSuccess || hipMemset(S.left_shadow, 0, sizeof(unsigned long long) * FJ_LEFT_CAP) != hipSuccess)
+      return fail(FJGPU_ENOMEM, "device allocation failed for the end-game chunk lists");
     sc->stack_need = need;
     sc->tri_record_bytes = 36; sc->blas_nodes = 0;
     for (const auto &ps : hs.primsets) {
@@ -540,8 +518,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     }
     if (getenv("FJGPU_VERBOSE"))
       for (const auto &ps : hs.primsets)
-        fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d; 8-wide nodes %zu stack need %d\n", ps.type, ps.n_prims,
-            ps.nodes.size(), ps.max_depth, ps.stack_need, ps.nodes8.size(), ps.stack_need8);
+        fprintf(stderr, "fjgpu: primset type %d prims %d nodes %zu binary depth %d stack need %d\n", ps.type, ps.n_prims,
+            ps.nodes.size(), ps.max_depth, ps.stack_need);
   }
   S.has_curves = 0;
   S.all_opaque = 1;
@@ -678,8 +656,7 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (!scene || !name || !value) return fail(FJGPU_EINVAL, "bad query call");
   const std::string n(name);
   if (n == "node_record_bytes") { *value = (double) sizeof(DNode); return 0; }
-  if (n == "anyhit_node_record_bytes") { *value = (double) (scene->S.anyhit_wide ? sizeof(DNodeQ8) : sizeof(DNodeQ)); return 0; }
-  if (n == "anyhit_wide") { *value = scene->S.anyhit_wide; return 0; }
+  if (n == "anyhit_node_record_bytes") { *value = (double) sizeof(DNodeQ); return 0; }
   if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
@@ -748,9 +725,11 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
     // owns at least two queue entries
     sc->d_join = nullptr; sc->join_cap = 0;
-    // (a slot per ray with >= 2 entries, + the slots the light loop's waves reserve 64 at a time and may leave unused: 32 launches' worth;
-    // more than that overflows like the queue does and the frame is rendered again without the split)
-    if (sc->split_shadow) { sc->join_cap = sc->squeue_cap / 2 + 1 + 32 * (persistent_threads() / 64) * 64; e |= W.alloc(sc->join_cap, &sc->d_join); }
+    // (a slot per ray with >= 2 entries -- at most squeue_cap / 2 of them -- but the light loop's waves reserve slots JQ_CHUNK = 64 at a
+    // time and a chunk roll-over discards up to 63 of them, i.e. up to about half of what is reserved over a launch: sized for that
+    // worst case plus one chunk per resident wave and launch; 4 bytes per slot.  Beyond it the join area overflows like the queue
+    // does and the frame is rendered again without the split)
+    if (sc->split_shadow) { sc->join_cap = sc->squeue_cap + 1 + 32 * (persistent_threads() / 64) * 64; e |= W.alloc(sc->join_cap, &sc->d_join); }
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
     if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }
@@ -825,7 +804,9 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
   if (e == FJGPU_ENOMEM && sc->split_overflowed) {
     // rays queued once per candidate instance outgrew the host's bound on the shadow queue (a scene whose
     // instance boxes overlap many times over): this scene goes back to whole rays and the tiles are rendered again
-    if (getenv("FJGPU_VERBOSE")) fprintf(stderr, "fjgpu: shadow queue overflow with split rays: rendering again without the split\n");
+    // (said once per scene, verbose or not: from here on the scene's frames take the slower path)
+    fprintf(stderr, "fjgpu: shadow queue overflow with rays split per candidate instance: rendering the tiles again without the split, "
+        "which stays off for this scene (option split_shadow)\n");
     sc->split_shadow = false;
     e = render_tiles_once(sc, r, tile_ids, n_tiles, d_fb, hip_stream, stats);
   }

@@ -346,68 +346,6 @@ struct Builder {
 
 }  // namespace
 
-namespace {
-
-// The 8-wide collapse of the same binary tree (DNode8): as `collapse`, eight slots.  Serial below the
-// top levels, which run on their own threads.
-struct Collapse8 {
-  const Node2 *nodes;
-  DNode8 *wide;
-  std::atomic<uint32_t> next_wide{0};
-  static float half_area(const float *mn, const float *mx) { return Builder::half_area(mn, mx); }
-  uint32_t run(uint32_t ref2, int *need, int par_depth, ChunkAlloc &alloc)
-  {
-    Builder::Cand c[8];
-    int k = 2;
-    {
-      const Node2 &n = nodes[ref2];
-      for (int a = 0; a < 3; a++) { c[0].mn[a] = n.lmin[a]; c[0].mx[a] = n.lmax[a]; c[1].mn[a] = n.rmin[a]; c[1].mx[a] = n.rmax[a]; }
-      c[0].ref = n.lc; c[1].ref = n.rc;
-    }
-    while (k < 8) {
-      int pick = -1;
-      float area = -1.f;
-      for (int i = 0; i < k; i++) {
-        if (c[i].ref & FJ_LEAF_FLAG) continue;
-        const float a = half_area(c[i].mn, c[i].mx);
-        if (a > area) { area = a; pick = i; }
-      }
-      if (pick < 0) break;
-      const Node2 &n = nodes[c[pick].ref];
-      for (int a = 0; a < 3; a++) { c[pick].mn[a] = n.lmin[a]; c[pick].mx[a] = n.lmax[a]; c[k].mn[a] = n.rmin[a]; c[k].mx[a] = n.rmax[a]; }
-      c[pick].ref = n.lc; c[k].ref = n.rc;
-      k++;
-    }
-    std::sort(c, c + k, [](const Builder::Cand &a, const Builder::Cand &b) { return half_area(a.mn, a.mx) > half_area(b.mn, b.mx); });
-    const uint32_t me = alloc.get();
-    int nd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t child[8];
-    std::vector<std::thread> th;
-    for (int i = 0; i < 8; i++) {
-      if (i >= k) { child[i] = FJ_NO_CHILD; continue; }
-      if (c[i].ref & FJ_LEAF_FLAG) { child[i] = c[i].ref; continue; }
-      if (par_depth > 0) th.emplace_back([&, i]() { ChunkAlloc a2(&next_wide); child[i] = run(c[i].ref, &nd[i], par_depth - 1, a2); });
-      else child[i] = run(c[i].ref, &nd[i], 0, alloc);
-    }
-    for (auto &x : th) x.join();
-    int worst = 0;
-    for (int i = 0; i < 8; i++) worst = std::max(worst, nd[i]);
-    DNode8 &w = wide[me];
-    for (int i = 0; i < 8; i++) {
-      for (int a = 0; a < 3; a++) {
-        w.box[i][2 * a] = i < k ? c[i].mn[a] : FLT_MAX;
-        w.box[i][2 * a + 1] = i < k ? c[i].mx[a] : -FLT_MAX;
-      }
-      w.child[i] = child[i];
-      w.pad[i] = 0;
-    }
-    *need = k + worst;       // the walk pushes every hit child (k entries), then pops one and descends
-    return me;
-  }
-};
-
-}  // namespace
-
 int BuildTopTree(const float *boxes6, int K, std::vector<TopNode> *out, int32_t *root)
 {
   out->clear();
@@ -485,7 +423,6 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float 
   }
   StageTimer tm;
   ps->stack_need = 0;
-  const uint32_t root2 = ps->root;          // binary root (or the leaf ref of a tiny mesh)
   const int cpar = n > 200000 ? 3 : 0;
   const size_t wide_cap = (size_t) b.next_node.load() + 1024 * (cpar ? 128 : 2);
   b.wide.reset(new DNode[wide_cap]);
@@ -495,24 +432,6 @@ void BuildBlas(HostPrimSet *ps, std::vector<PrimRef> &refs, int max_leaf, float 
     ps->root = b.collapse(ps->root, &ps->stack_need, cpar, alloc);
   }
   tm.lap("collapse to 4-wide", n);
-  // the 8-wide twin of the same tree (meshes: the lean any-hit walk; see DNode8)
-  ps->root8 = ps->root; ps->stack_need8 = 0;
-  if (ps->type == FJ_PRIMSET_MESH && getenv("FJGPU_WIDE8")) {      // opt-in experiment: measured slower (see DNode8)
-    Collapse8 c8;
-    c8.nodes = b.nodes.get();
-    // (at most one 8-wide node per binary node; every allocator -- 1 + 8 + 64 with two threaded levels -- may leave a chunk unfinished)
-    const int cpar8 = cpar ? 2 : 0;
-    const size_t cap8 = (size_t) b.next_node.load() + 1024 * (cpar8 ? 80 : 2);
-    ps->nodes8.p.reset(new DNode8[cap8]);
-    c8.wide = ps->nodes8.p.get();
-    // (the root as the binary build left it: `collapse` above replaced ps->root by the 4-wide index)
-    if (n > 0 && !(root2 & FJ_LEAF_FLAG)) {
-      ChunkAlloc alloc8(&c8.next_wide);
-      ps->root8 = c8.run(root2, &ps->stack_need8, cpar8, alloc8);
-      ps->nodes8.n = std::min<size_t>(cap8, c8.next_wide.load());
-    } else { ps->root8 = root2; ps->nodes8.n = 0; ps->nodes8.p.reset(); }
-    tm.lap("collapse to 8-wide", n);
-  }
   ps->nodes.n = std::max<size_t>(1, std::min<size_t>(wide_cap, b.next_wide.load()));
   ps->nodes.p = std::move(b.wide);
   ps->max_depth = b.max_depth;

@@ -19,19 +19,9 @@ struct NodeArray {
   size_t size() const { return n; }
 };
 
-struct NodeArray8 {
-  std::unique_ptr<DNode8[]> p;
-  size_t n = 0;
-  const DNode8 *data() const { return p.get(); }
-  size_t size() const { return n; }
-};
-
 struct HostPrimSet {
   int type;
   NodeArray nodes;
-  NodeArray8 nodes8;                  // meshes, host build: the same binary tree collapsed 8-wide (lean any-hit walk)
-  uint32_t root8 = 0;
-  int stack_need8 = 0;                // worst-case traversal stack entries of the 8-wide tree
   std::vector<double> tri_verts;      // mesh: [n][9]  (empty when tri_verts32 is used)
   std::vector<double> tri_vel;        // mesh: [n][9] vertex velocities in leaf order (empty = static)
   std::vector<float> tri_verts32;     // mesh: [n][9]  all coordinates exactly representable in f32

@@ -19,12 +19,21 @@
 // with 17, inner steps with 42, triangle tests with 16 of 64 lanes).  The leaf phase tests ONE
 // triangle per lane and execution, so lanes with 1 and 4 triangles do not wait for each other.
 //
-// Box tests are the conservative f32 slab test (slab32_test, fjgpu_dev_math.h): 3 packed
-// fma + 8 min/max per box instead of 12 conversions + 24 f64 operations.
+// Box tests are the conservative sign-aware f32 slab test on the quantised 64-byte nodes
+// (slab32q_test, fjgpu_dev_math.h).
 //
 // Entry.  The light loop has already tested the (single) instance box of single-instance
 // shadow groups and writes ~instance into the queue entry: the walk reads one flat record
 // (DAnyInst) and starts.  Groups with several instances walk the threaded instance BVH here.
+//
+// End of a launch: EndGame (fjgpu_dev_traverse.h) -- unfetched rays go back into a shared list
+// once the queue is dry, so the launch ends within a few rays of the moment the work runs out.
+//
+// Measured and dropped, with their numbers (the code is kept as a patch: profiles/r04_anyhit_dropped_experiments.patch):
+// an 8-wide twin of the tree (29 % fewer node visits, 15 % more VALU instructions: C3 walk 64.4 -> 72.7 ms), cache-warming
+// touches of the node / triangle a lane will come back to (63.3 -> 68.3 .. 75.6 ms), the unsigned slab variant, ALU / load
+// padding and the f64 validation of the slab test (profiles/r03_anyhit_bound_experiments.txt, r03_anyhit_wide8_and_perm.txt).
+
 // lane id the compiler cannot treat as a loop invariant
 __device__ __forceinline__ uint32_t opaque_lane_id()
 {
@@ -39,7 +48,7 @@ __device__ __forceinline__ uint32_t opaque_lane_id()
 #endif
 // tri_ray (fjgpu_dev_math.h) statement for statement, with scheduling fences between its steps:
 // left to itself the scheduler overlaps them and the leaf phase needs a dozen registers more than
-// the 96 the walk runs 5 waves with
+// the walk has
 __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
 {
   const V3 edge1 = v1 - v0;
@@ -64,58 +73,18 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   return true;
 }
 
-#ifndef FJ_ANYHIT_SIGNED_SLABS
-#define FJ_ANYHIT_SIGNED_SLABS 1
-#endif
-#if !FJ_ANYHIT_SIGNED_SLABS && FJ_SLAB_PERM
-#error "the unsigned slab variant converts the grid coordinates itself: build it with -DFJ_SLAB_PERM=0"
-#endif
-#ifndef FJ_ANYHIT_POSTPONE
-#define FJ_ANYHIT_POSTPONE 1
-#endif
 #ifdef FJ_PHASE_STATS
 // debug build only: wave-level phase executions and the lanes active in them
 #define PH(i, v) do { ph[i] += (unsigned long long) (v); } while (0)
 #else
 #define PH(i, v) do { } while (0)
 #endif
-// Cache-warming touches (experiment switch FJ_ANYHIT_PREFETCH, bit 0: the first triangle of a leaf when it is set aside,
-// bit 1: the node that goes on top of the stack): one dword of the record is loaded into a register nobody reads, so that
-// the line is on its way (L2 / Infinity Cache) when the walk comes back for it.  The register is the same for the whole
-// kernel and is never reused, so the hardware may write it whenever the data arrives; the compiler's own wait counts only
-// become stricter through an older load it does not know of (loads return in order).
-#ifndef FJ_ANYHIT_PREFETCH
-#define FJ_ANYHIT_PREFETCH 0
-#endif
-#ifndef FJ_ANYHIT_RAY_LDS
-#define FJ_ANYHIT_RAY_LDS 1
-#endif
-#if FJ_ANYHIT_RAY_LDS
-#define AH_RAYV(k) AH_RAY(k)
-#else
-#define AH_RAYV(k) ((k) == 0 ? oo.x : (k) == 1 ? oo.y : (k) == 2 ? oo.z : (k) == 3 ? od.x : (k) == 4 ? od.y : od.z)
-#endif
-#if FJ_ANYHIT_PREFETCH
-#define AH_TOUCH(addr) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_) : "v"(addr))
-#else
-#define AH_TOUCH(addr) do { } while (0)
-#endif
-#define AH_TOUCH_TRI(leaf) AH_TOUCH((const FJ_GLOBAL char *) (S.blas_base + ((size_t) tri_base << 7) + (size_t) (((leaf) & 0x7fffffffu) >> 3) * 36u))
-#define AH_TOUCH_NODE(ref) AH_TOUCH((const FJ_GLOBAL char *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) (ref) << 6)))
-
-#ifdef FJ_EXP_SLAB_VALIDATE
-__device__ unsigned long long g_slab_lost, g_slab_extra, g_slab_tests;
-#endif
 
 // kMulti = false: every shadow group that can receive shadow rays has one instance, so every queue
 // entry names its instance (the instance-BVH walk and its registers are compiled out).
-// kWide: the walk reads the 8-wide twin of the tree (DNodeQ8, DScene.anyhit_wide): eight box tests per dependent node
-// fetch instead of four -- about half as many round trips per ray (the walk is bound by their latency x occupancy,
-// profiles/r03_anyhit_bound_experiments.txt) and half as many step overheads; every hit child goes onto the stack, the
-// largest (stored first) on top, and the next node is popped.
-template <bool kCount, bool kMulti, bool kWide>
+template <bool kCount, bool kMulti>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
-    uint32_t n, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
+    uint32_t n, uint32_t *xheads, uint32_t *egoverflow, uint32_t *s_stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
   // Per-lane traversal stack: FJ_STACK_LDS_ANYHIT entries in LDS ([depth][thread]), deeper ones
@@ -135,66 +104,69 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   tune.grab = adaptive_grab(tune.grab, n);
   QueueClaim qc;                           // queue regions by XCD (DCounters.shadow_xcd_head)
   qc.init(xheads, n, tune.grab);
+  EndGame eg;                              // unfetched rays go back into a shared list once the queue is dry
+  eg.init(xheads, S.left_shadow);
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
-  // object-space ray (f64: the triangle test's operands).  FJ_ANYHIT_RAY_LDS: it lives in LDS ([k][thread]) instead of in
-  // 12 registers -- only the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
-#if FJ_ANYHIT_RAY_LDS
+  // object-space ray (f64: the triangle test's operands): it lives in LDS ([k][thread]) instead of in 12 registers -- only
+  // the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
   double *s_ray = reinterpret_cast<double *>(s_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
 #define AH_RAY(k) s_ray[(k) * BLOCK + AH_TID()]
-#else
-  V3 oo = mk(0, 0, 0), od = oo;
-#endif
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#ifdef FJ_EXP_SLAB_VALIDATE
-  V3 inv_keep = mk(0, 0, 0);
-  int vinst = 0;
-#endif
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
   const float tmin32 = 9.9999e-5f;         // <= .0001
   int gi = 0, gend = 0;                    // cursor in the group's instance BVH; gi < 0: ~instance, settled by the light loop
   uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base (triangles: f32 records, see fjgpu_api.hip)
   uint32_t cur = TRAV_DONE;
-#if FJ_ANYHIT_POSTPONE
   // a POSTPONED leaf: a lane that reaches a leaf while its stack is not empty sets the leaf aside and
   // walks on, so it has work in whichever phase the wave runs next (any hit ends the ray and 7 of 8
   // rays reach the light: the order of the tests is free, nothing is wasted but the inner steps an
   // occluded ray takes before its postponed leaf is tested)
   uint32_t pleaf = TRAV_DONE;
-#endif
   int sp = 0;
-#if FJ_ANYHIT_PREFETCH
-  uint32_t pf_ = 0;
-#endif
   const double tmin = .0001;
 #ifdef FJ_PHASE_STATS
   unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
+#ifdef FJ_WAVE_TIMELINE
+  uint32_t ray_steps = 0;
+#endif
+  FJ_TL_DECL();
   for (;;) {
     PH(0, 1);
-#if FJ_ANYHIT_POSTPONE
-    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
+    FJ_TL_ITER(!head_live && next >= range_end);
+    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
     const bool fin = cur == TRAV_DONE && pleaf == TRAV_DONE;
     const bool at_inner = cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG);
     const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
-#else
-    const bool fin = cur == TRAV_DONE;
-    const bool at_leaf = !fin && (cur & FJ_LEAF_FLAG);
-    const bool at_inner = !fin && !at_leaf;
-#endif
     const unsigned long long m_leaf = __ballot(at_leaf), m_inner = __ballot(at_inner);
     const unsigned n_leaf = (unsigned) __popcll(m_leaf), n_inner = (unsigned) __popcll(m_inner);
+    // end game: another wave found the queue dry -- this one claims nothing more and gives its unfetched rays back at once
+    bool hand_back = false;
+    if (FJ_ENDGAME && head_live && eg.poll_dry(qc.late)) { head_live = false; hand_back = true; eg.queue_died(); }
     // lanes for which a turnover does something: a ray to retire / move on, or a new one to fetch
-    const bool can_fetch = head_live || next < range_end;
+    // (end game: idle lanes ask for a turnover only when the lists may be looked at -- a wave with nothing in flight always may)
+    const bool idle_wave = n_inner == 0 && n_leaf == 0 && __ballot(have) == 0ull;
+    const bool can_fetch = head_live || next < range_end || (FJ_ENDGAME && !eg.dead() && (idle_wave || eg.may_look()));
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
     const unsigned n_turn = (unsigned) __popcll(m_turn);
 
-    if (n_turn >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
-      if (m_turn == 0ull) break;           // nothing in flight, nothing left to fetch
+    if (n_turn >= (head_live ? TRAV_REFILL : tune.eg_refill) || hand_back || (n_inner == 0 && n_leaf == 0)) {
+      if (m_turn == 0ull && !hand_back) { FJ_TL_END(); break; }           // nothing in flight, nothing left to fetch
       PH(1, 1); PH(2, n_turn);
       // ---- turnover: retire, fetch, enter
-      if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
+      if (next >= range_end && head_live) {
+        head_live = qc.claim(lane, &next, &range_end);
+        FJ_TL_CLAIM();
+        if (FJ_ENDGAME && !head_live) { eg.raise_dry(lane); eg.queue_died(); }
+      }
+      if (FJ_ENDGAME && !head_live && next >= range_end && can_fetch) {
+        eg.set_published();                                            // (nothing of its own left to give)
+        // a chunk of a list, if some lane can take a ray now (else it would only sit here); a wave with nothing in flight looks
+        // everywhere, then leaves
+        if (n_turn) eg.pop(lane, &next, &range_end, idle_wave);
+      }
       bool fetch = false;
       if (fin) {
         fetch = true;
@@ -218,6 +190,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
               if (r2 != 0.f) atomicAdd(acc + 2, r2);
             }
             have = false;
+#ifdef FJ_WAVE_TIMELINE
+            FJ_TL_RAY(ray_steps);
+#endif
           }
         }
       }
@@ -227,6 +202,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         if (my < range_end) {
           const int g = squeue[my].group;
           if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
+#ifdef FJ_WAVE_TIMELINE
+            ray_steps = 0;
+#endif
             have = true;
             idx = my;
             if (!kMulti || g < 0) { gi = g; gend = 0; }
@@ -236,6 +214,8 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       }
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
+      // end game: what this wave has claimed and not fetched goes back into the shared list
+      if (FJ_ENDGAME && !head_live && !eg.published()) { if (!eg.publish(lane, next, range_end, tune.eg_chunk)) *egoverflow = 1; range_end = next; }
       if (fin && have) {
         const DShadowRay *q = &squeue[idx];
         const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
@@ -275,11 +255,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (A->n_prims == 0) continue;
           const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
           if (has_negative_zero(od_)) continue;
-#if FJ_ANYHIT_RAY_LDS
           AH_RAY(0) = oo_.x; AH_RAY(1) = oo_.y; AH_RAY(2) = oo_.z; AH_RAY(3) = od_.x; AH_RAY(4) = od_.y; AH_RAY(5) = od_.z;
-#else
-          oo = oo_; od = od_;
-#endif
           const V3 inv = mk(filter_rcp(od_.x), filter_rcp(od_.y), filter_rcp(od_.z));
           // the primitive set's own box: only where several instances are tried (a ray that misses
           // it finds no child box at the root either; in the single-instance walk the 12 registers
@@ -289,13 +265,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (!slab(A->bounds, A->bounds + 3, oo_, inv, tmin, tmax, &tn)) continue;
           }
           s32 = slab32q_setup(oo_, inv, A->qorigin, A->qcell);
-#ifdef FJ_EXP_SLAB_VALIDATE
-          inv_keep = mk(1. / od_.x, 1. / od_.y, 1. / od_.z);
-          vinst = inst;
-#endif
           tmax32 = f32_above(tmax);
-          node_base = kWide ? A->node8_base : A->node_base; tri_base = A->tri_base;
-          cur = kWide ? A->root8 : A->root; sp = 0;
+          node_base = A->node_base; tri_base = A->tri_base;
+          cur = A->root; sp = 0;
           break;
         }
       }
@@ -303,89 +275,27 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
     }
 
     if (n_inner >= n_leaf) {
-      // ---- inner nodes: one 128-byte node per lane; further steps without a new vote while at
-      // least tune.min_inner lanes stay at inner nodes
+      // ---- inner nodes: one 64-byte node per lane; further steps without a new vote while at
+      // least min_inner lanes stay at inner nodes (fewer once the queue is dry: the wave is emptying anyway)
+      const uint32_t min_inner = head_live ? tune.min_inner : tune.eg_min_inner;
       for (uint32_t step = 0;; step++) {
       const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
       if (step > 0) {
         const unsigned n_now = (unsigned) __popcll(__ballot(in_now));
-        if (step >= tune.anyhit_steps || n_now < tune.min_inner) break;
+        if (step >= tune.anyhit_steps || n_now < min_inner) break;
         PH(3, 1); PH(4, n_now);
       } else { PH(3, 1); PH(4, n_inner); }
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
-      const bool deep = __ballot(in_now && sp + (kWide ? 8 : 3) > FJ_STACK_LDS_ANYHIT) != 0ull;
-      if (kWide && in_now) {
-        // 128-byte quantised 8-wide node: eight 16-byte loads (24 words of (min, max) pairs + 8 child refs)
-        const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 7));
-        if (kCount) lc->nodes++;
-        const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3], w4 = nd[4], w5 = nd[5], e0 = nd[6], e1 = nd[7];
-        const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
-        const bool h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32);
-        FJ_SCHED_FENCE();
-        const bool h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32);
-        FJ_SCHED_FENCE();
-        const bool h2 = slab32q_test(w1.z, w1.w, w2.x, s32, shx, shy, shz, tmin32, tmax32) && e0.z != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32) && e0.w != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h4 = slab32q_test(w3.x, w3.y, w3.z, s32, shx, shy, shz, tmin32, tmax32) && e1.x != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h5 = slab32q_test(w3.w, w4.x, w4.y, s32, shx, shy, shz, tmin32, tmax32) && e1.y != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h6 = slab32q_test(w4.z, w4.w, w5.x, s32, shx, shy, shz, tmin32, tmax32) && e1.z != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h7 = slab32q_test(w5.y, w5.z, w5.w, s32, shx, shy, shz, tmin32, tmax32) && e1.w != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        if (!deep) {
-          // every hit child onto the stack, the first (largest) last: an unconditional store per child
-          // (whatever lies above the new top is dead) and a conditional step of the top
-          int s_ = sp;
-          AH_LDS(s_) = e1.w; s_ += (int) h7;
-          AH_LDS(s_) = e1.z; s_ += (int) h6;
-          AH_LDS(s_) = e1.y; s_ += (int) h5;
-          AH_LDS(s_) = e1.x; s_ += (int) h4;
-          AH_LDS(s_) = e0.w; s_ += (int) h3;
-          AH_LDS(s_) = e0.z; s_ += (int) h2;
-          AH_LDS(s_) = e0.y; s_ += (int) h1;
-          AH_LDS(s_) = e0.x; s_ += (int) h0;
-          sp = s_;
-        } else {
-          if (h7) push(sp, e1.w);
-          if (h6) push(sp, e1.z);
-          if (h5) push(sp, e1.y);
-          if (h4) push(sp, e1.x);
-          if (h3) push(sp, e0.w);
-          if (h2) push(sp, e0.z);
-          if (h1) push(sp, e0.y);
-          if (h0) push(sp, e0.x);
-        }
-        cur = (sp == 0) ? TRAV_DONE : pop(sp);
-#if FJ_ANYHIT_POSTPONE
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
-#endif
-      }
-      if (!kWide && in_now) {
+      const bool deep = __ballot(in_now && sp + 3 > FJ_STACK_LDS_ANYHIT) != 0ull;
+      if (in_now) {
         // 64-byte quantised node: four 16-byte loads (12 words of (min, max) pairs + 4 child refs)
         const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
         if (kCount) lc->nodes++;
+#ifdef FJ_WAVE_TIMELINE
+        ray_steps++;
+#endif
         const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], e = nd[3];
-#ifdef FJ_EXP_ALU_PAD
-        // experiment (profiles/r03_anyhit_bound_experiments.txt): FJ_EXP_ALU_PAD extra VALU instructions per inner step that
-        // depend on nothing the walk needs -- if the kernel's time follows them it is bound by VALU issue, not by node latency
-        { float pad_ = tmax32;
-#pragma unroll
-          for (int k_ = 0; k_ < FJ_EXP_ALU_PAD; k_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad_));
-          asm volatile("" :: "v"(pad_)); }
-#endif
-#ifdef FJ_EXP_LOAD_PAD
-        // experiment: FJ_EXP_LOAD_PAD extra 16-byte loads of the SAME node per inner step (L1 hits: request rate, no new latency)
-        { fj_v4u lp_ = {0, 0, 0, 0};
-#pragma unroll
-          for (int k_ = 0; k_ < FJ_EXP_LOAD_PAD; k_++) { const fj_v4u x_ = __builtin_nontemporal_load(&nd[k_ & 3]); lp_ ^= x_; }
-          asm volatile("" :: "v"(lp_.x ^ lp_.y ^ lp_.z ^ lp_.w)); }
-#endif
         // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
-#if FJ_ANYHIT_SIGNED_SLABS
         const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
         const bool h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32);
         FJ_SCHED_FENCE();
@@ -395,35 +305,6 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         FJ_SCHED_FENCE();
         const bool h3 = slab32q_test(w2.y, w2.z, w2.w, s32, shx, shy, shz, tmin32, tmax32) && e.w != FJ_NO_CHILD;
         FJ_SCHED_FENCE();
-#else
-        float tq;
-        const bool h0 = slab32_test(unpack_q(w0.x), unpack_q(w0.y), unpack_q(w0.z), s32, tmin32, tmax32, &tq);
-        FJ_SCHED_FENCE();
-        const bool h1 = slab32_test(unpack_q(w0.w), unpack_q(w1.x), unpack_q(w1.y), s32, tmin32, tmax32, &tq);
-        FJ_SCHED_FENCE();
-        const bool h2 = slab32_test(unpack_q(w1.z), unpack_q(w1.w), unpack_q(w2.x), s32, tmin32, tmax32, &tq) && e.z != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-        const bool h3 = slab32_test(unpack_q(w2.y), unpack_q(w2.z), unpack_q(w2.w), s32, tmin32, tmax32, &tq) && e.w != FJ_NO_CHILD;
-        FJ_SCHED_FENCE();
-#endif
-#ifdef FJ_EXP_SLAB_VALIDATE
-        {   // every box the f64 test accepts on the DECODED box must be accepted by the f32 test
-          const DAnyInst *Av = &S.any_insts[vinst];
-          auto dec = [&](uint32_t w, int a) { fj_v2f p; p.x = (float) 0; p.y = (float) 0; double lo_ = Av->qorigin[a] + (double) (w & 0xffffu) * Av->qcell[a], hi_ = Av->qorigin[a] + (double) (w >> 16) * Av->qcell[a]; (void) p; return std::pair<double, double>(lo_, hi_); };
-          const uint32_t ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-          const bool hh[4] = {h0, h1, h2, h3};
-          const uint32_t ee[4] = {e.x, e.y, e.z, e.w};
-          for (int k = 0; k < 4; k++) {
-            if (ee[k] == FJ_NO_CHILD) continue;
-            double mn[3], mx[3], td;
-            for (int a = 0; a < 3; a++) { const auto pr = dec(ww[3 * k + a], a); mn[a] = pr.first; mx[a] = pr.second; }
-            const bool g = slab(mn, mx, mk(AH_RAYV(0), AH_RAYV(1), AH_RAYV(2)), inv_keep, tmin, squeue[idx].tmax, &td);
-            if (g && !hh[k]) atomicAdd(&g_slab_lost, 1ull);
-            if (hh[k] && !g) atomicAdd(&g_slab_extra, 1ull);
-            atomicAdd(&g_slab_tests, 1ull);
-          }
-        }
-#endif
         // any hit ends the ray and 7 of 8 rays reach the light, so the visiting order is free:
         // no distance sort (children are stored by decreasing surface area)
         uint32_t r0 = e.x, r1 = e.y, r2 = e.z, r3 = e.w;
@@ -439,10 +320,6 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             // three predicated ones
             uint32_t *top = &AH_LDS(sp);
             top[0] = r1; top[BLOCK] = r2; top[2 * BLOCK] = r3;
-            if ((FJ_ANYHIT_PREFETCH & 2) && nh > 1) {      // the node (or leaf) that is now on top of the stack
-              const uint32_t tp = nh == 2 ? r1 : (nh == 3 ? r2 : r3);
-              if (tp & FJ_LEAF_FLAG) AH_TOUCH_TRI(tp); else AH_TOUCH_NODE(tp);
-            }
             sp += nh - 1;
           } else {
             if (nh > 1) push(sp, r1);
@@ -450,21 +327,15 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (nh > 3) push(sp, r3);
           }
         }
-#if FJ_ANYHIT_POSTPONE
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; if (FJ_ANYHIT_PREFETCH & 1) AH_TOUCH_TRI(pleaf); cur = pop(sp); }
-#endif
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
       }
       }
     } else {
       // ---- leaves: ONE triangle per lane; the first hit inside [tmin, tmax] ends the ray
       PH(5, 1); PH(6, n_leaf);
       if (at_leaf) {
-#if FJ_ANYHIT_POSTPONE
         const bool from_p = pleaf != TRAV_DONE;        // the postponed leaf first: its slot frees
         const uint32_t lf = from_p ? pleaf : cur;
-#else
-        const uint32_t lf = cur;
-#endif
         const uint32_t first = (lf & 0x7fffffffu) >> 3;
         const uint32_t more = lf & 7u;
         double t, u, v;
@@ -473,24 +344,20 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         V3 v0, v1, v2;
         load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
         FJ_SCHED_FENCE();
-        if (tri_ray_fenced(v0, v1, v2, mk(AH_RAYV(0), AH_RAYV(1), AH_RAYV(2)), mk(AH_RAYV(3), AH_RAYV(4), AH_RAYV(5)), &t, &u, &v) && tmin <= t && t <= tmax) {
+        if (tri_ray_fenced(v0, v1, v2, mk(AH_RAY(0), AH_RAY(1), AH_RAY(2)), mk(AH_RAY(3), AH_RAY(4), AH_RAY(5)), &t, &u, &v) && tmin <= t && t <= tmax) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
-#if FJ_ANYHIT_POSTPONE
           pleaf = TRAV_DONE;
+#ifdef FJ_WAVE_TIMELINE
+          FJ_TL_RAY(ray_steps);
 #endif
           PH(10, 1);
         }
-#if FJ_ANYHIT_POSTPONE
         else if (from_p) pleaf = more ? (FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u)) : TRAV_DONE;
-#endif
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (sp == 0) ? TRAV_DONE : pop(sp);
       }
     }
   }
-#if FJ_ANYHIT_PREFETCH
-  asm volatile("s_waitcnt vmcnt(0)" :: "v"(pf_));
-#endif
 #undef AH_LDS
 #undef AH_OVF
 #undef AH_TID
@@ -507,25 +374,25 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 // blocks per CU (= waves per SIMD): what the registers allow WITHOUT a spill (any spill in the loop
 // doubled the frame time).  The walk is bound by node-fetch latency x occupancy (profiles/r03_anyhit_bound_experiments.txt:
 // 3 / 4 / 5 waves 85 / 71 / 63.5 ms), so round 3 bought a SIXTH wave: the object-space ray -- 12 registers that only the
-// leaf phase reads -- lives in LDS (FJ_ANYHIT_RAY_LDS) next to a stack of 12 instead of 24 entries (deeper ones in the global
+// leaf phase reads -- lives in LDS next to a stack of 12 instead of 24 entries (deeper ones in the global
 // overflow area), which brings the instantiation without the instance-BVH walk to 80 VGPRs, no spill: C3 63.3 -> 60.4 ms, C6
 // 294.5 -> 281.9, C2 53.8 -> 52.0 (profiles/r03_exp13_six_waves.txt).  A seventh wave (72 VGPRs: 10 spills, 8 stack entries)
-// loses again: 67.4 ms.  The general instantiation needs 98 = 4 waves.  Cache-warming touches of the node / triangle a lane
-// will come back to (FJ_ANYHIT_PREFETCH) cost more in L1 requests than they save: 63.3 -> 68.3 / 70.1 / 75.6 ms.
+// loses again: 67.4 ms.  The general instantiation needs 98 = 4 waves.
 #ifndef FJ_ANYHIT_MINB
 #define FJ_ANYHIT_MINB 6
 #endif
 #ifndef FJ_ANYHIT_MINB_MULTI
 #define FJ_ANYHIT_MINB_MULTI 5          // (96 VGPRs, no spill: C2 without the split 134.5 -> 124.1 ms; with the split 117.9)
 #endif
-template <bool kCount, bool kMulti, bool kWide>
+static_assert((FJ_STACK_LDS_ANYHIT * BLOCK * 4) % 8 == 0, "the object-space rays behind the LDS stack are doubles");
+template <bool kCount, bool kMulti>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + (FJ_ANYHIT_RAY_LDS ? 12 * BLOCK : 0)];     // (+ the rays: 6 doubles per thread)
+  __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + 12 * BLOCK];     // (+ the rays: 6 doubles per thread)
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti, kWide>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], &cnt->overflow, s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

@@ -65,7 +65,6 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
     float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events);
 // the quantised node array of the lean any-hit walk from the f32 one (same indices)
-int launch_quantize_nodes8(hipStream_t st, const DNode8 *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ8 *out);
 int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ *out);
 // multi-GPU frame: pack a device's tiles (d_rects [n][4] = xmin ymin xmax ymax) into a slab of
 // tile_px pixels per tile, or scatter such a slab into the framebuffer (unpack)

@@ -138,34 +138,6 @@ __global__ void __launch_bounds__(BLOCK) k_quantize_nodes(const DNode *nodes, ui
   out[i] = q;
 }
 
-// the same for the 8-wide twin (DNode8 -> DNodeQ8); empty slots come out as an inverted box (min 65535, max 0)
-__global__ void __launch_bounds__(BLOCK) k_quantize_nodes8(const DNode8 *nodes, uint32_t n, double ox, double oy, double oz,
-    double cx, double cy, double cz, DNodeQ8 *out)
-{
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const DNode8 *nd = &nodes[i];
-  DNodeQ8 q;
-  const double o[3] = {ox, oy, oz}, c[3] = {cx, cy, cz};
-  for (int k = 0; k < 8; k++) {
-    q.child[k] = nd->child[k];
-    for (int a = 0; a < 3; a++) {
-      const double lo = (double) nd->box[k][2 * a], hi = (double) nd->box[k][2 * a + 1];
-      if (nd->child[k] == FJ_NO_CHILD) { q.q[k][2 * a] = 65535; q.q[k][2 * a + 1] = 0; continue; }
-      double ql = floor((lo - o[a]) / c[a]), qh = ceil((hi - o[a]) / c[a]);
-      if (!(ql >= 0)) ql = 0;
-      if (!(qh <= 65535)) qh = 65535;
-      if (!(qh >= 0)) qh = 0;
-      if (!(ql <= 65535)) ql = 65535;
-      if (o[a] + ql * c[a] > lo && ql > 0) ql -= 1;
-      if (o[a] + qh * c[a] < hi && qh < 65535) qh += 1;
-      q.q[k][2 * a] = (uint16_t) ql;
-      q.q[k][2 * a + 1] = (uint16_t) qh;
-    }
-  }
-  out[i] = q;
-}
-
 // ----------------------------------------------------------- host launchers
 // persistent launches: at most PERSIST_BLOCKS_PER_CU resident blocks per CU
 #define PERSIST_BLOCKS_PER_CU 4
@@ -197,7 +169,7 @@ static int anyhit_blocks_per_cu(bool multi)
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -214,6 +186,10 @@ static TravTune trav_tune()
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
     t.min_inner_phased = env("FJGPU_TRAV_MININNER_PHASED", 12);
+    // end game (EndGame, fjgpu_dev_traverse.h): chunk size of the rays handed back, refill threshold and min_inner once the queue is dry
+    t.eg_chunk = env("FJGPU_EG_CHUNK", 32);
+    t.eg_refill = env("FJGPU_EG_REFILL", 24);
+    t.eg_min_inner = env("FJGPU_EG_MININNER", 8);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
@@ -222,6 +198,46 @@ static TravTune trav_tune()
   }
   return t;
 }
+
+#ifdef FJ_WAVE_TIMELINE
+// debug builds: the per-wave clock table of the walk just launched (WaveTimeline, fjgpu_dev_traverse.h) appended to $FJGPU_TIMELINE
+static void timeline_zero(hipStream_t st)
+{
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_timeline)) == hipSuccess) (void) hipMemsetAsync(p, 0, sizeof(unsigned long long) * FJ_TL_WAVES * 6, st);
+}
+static void timeline_dump(hipStream_t st, const char *kernel, unsigned waves)
+{
+  const char *path = getenv("FJGPU_TIMELINE");
+  if (!path) return;
+  static unsigned long long h[FJ_TL_WAVES * 6];
+  void *p = nullptr;
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(g_timeline)) != hipSuccess) return;
+  if (hipMemcpy(h, p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  if (waves > FJ_TL_WAVES) waves = FJ_TL_WAVES;
+  fprintf(f, "# %s waves %u\n", kernel, waves);
+  {
+    unsigned long long rh[64];
+    void *q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_rayhist)) == hipSuccess && hipMemcpy(rh, q, sizeof(rh), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(f, "#hist");
+      for (int b = 0; b < 20; b++) fprintf(f, " %llu:%llu", rh[b], rh[32 + b]);
+      fprintf(f, "\n");
+      (void) hipMemset(q, 0, sizeof(rh));
+    }
+  }
+  for (unsigned w = 0; w < waves; w++) if (h[6 * w + 2]) fprintf(f, "%u %llu %llu %llu %llu %llu %llu %llu %llu\n", w, h[6 * w], h[6 * w + 1], h[6 * w + 2], h[6 * w + 3] >> 32, h[6 * w + 3] & 0xffffffffull,
+      h[6 * w + 4] >> 32, h[6 * w + 4] & 0xffffffffull, h[6 * w + 5]);
+  fclose(f);
+}
+#define TL_ZERO(st) timeline_zero(st)
+#define TL_DUMP(st, name, grid) timeline_dump(st, name, (grid) * (BLOCK / 64))
+#else
+#define TL_ZERO(st) do { } while (0)
+#define TL_DUMP(st, name, grid) do { } while (0)
+#endif
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
 
@@ -239,10 +255,12 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head), st);
+  (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head) + sizeof(cnt->trace_eg), st);      // heads + end game
+  if (FJ_ENDGAME) (void) hipMemsetAsync(S.left_trace, 0, sizeof(unsigned long long) * FJ_LEFT_CAP, st);                 // ... and its chunk lists
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
   // (the event counters cost registers and issue slots: counting is its own instantiation)
   const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));
+  TL_ZERO(st);
 #define FJ_LAUNCH_CLOSEST(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT, MOTION>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
   if (S.has_motion) {      // time-sampled instance transforms: one general instantiation
     if (count_events) FJ_LAUNCH_CLOSEST(true, true, true); else FJ_LAUNCH_CLOSEST(true, false, true);
@@ -269,6 +287,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
   else { if (count_events) FJ_LAUNCH_CLOSEST(false, true, false); else FJ_LAUNCH_CLOSEST(false, false, false); }
 #undef FJ_LAUNCH_CLOSEST
   LAUNCH_CHECK();
+  TL_DUMP(st, "closest", grid.x);
   return 0;
 }
 
@@ -298,7 +317,7 @@ void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 {
   (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
   (void) hipMemsetAsync(&cnt->join_count, 0, sizeof(uint32_t), st);
-  (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head), st);
+  (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head) + sizeof(cnt->shadow_eg), st);   // heads + end game
 }
 
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
@@ -324,13 +343,13 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
+  TL_ZERO(st);
+  if (FJ_ENDGAME) (void) hipMemsetAsync(S.left_shadow, 0, sizeof(unsigned long long) * FJ_LEFT_CAP, st);      // chunk lists of the end game (DEndGame: reset with the heads)
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
-#define FJ_LAUNCH_ANYHIT2(COUNT, MULTI, WIDE) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI, WIDE>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
-#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) do { if (S.anyhit_wide) FJ_LAUNCH_ANYHIT2(COUNT, MULTI, true); else FJ_LAUNCH_ANYHIT2(COUNT, MULTI, false); } while (0)
+#define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     // (with DScene.shadow_join every queue entry names its instance: the instantiation without the instance-level walk)
     if (S.multi_shadow_groups && !S.shadow_join) { if (count_events) FJ_LAUNCH_ANYHIT(true, true); else FJ_LAUNCH_ANYHIT(false, true); }
     else { if (count_events) FJ_LAUNCH_ANYHIT(true, false); else FJ_LAUNCH_ANYHIT(false, false); }
-#undef FJ_LAUNCH_ANYHIT2
 #undef FJ_LAUNCH_ANYHIT
   } else {
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
@@ -354,6 +373,7 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 #undef FJ_LAUNCH_SHADOW
   }
   LAUNCH_CHECK();
+  TL_DUMP(st, "shadow", persistent_grid(1ull << 30, PERSIST_BLOCKS_PER_CU_MAX));
   return 0;
 }
 
@@ -366,34 +386,22 @@ int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const 
   return 0;
 }
 
-int launch_quantize_nodes8(hipStream_t st, const DNode8 *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ8 *out)
-{
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_quantize_nodes8, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, n, origin[0], origin[1], origin[2],
-      cell[0], cell[1], cell[2], out);
-  LAUNCH_CHECK();
-  return 0;
-}
-
 int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *slab)
 {
-  if (n_tiles <= 0) return 0;
-  const dim3 grid((tile_px + BLOCK - 1) / BLOCK, n_tiles);
-  if (unpack) hipLaunchKernelGGL(k_move_tiles<true>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects, tile_px, (float4 *) slab);
-  else hipLaunchKernelGGL(k_move_tiles<false>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects, tile_px, (float4 *) slab);
-  LAUNCH_CHECK();
+  // (the tile index is grid.y, at most 65535 per launch: more tiles go in several launches)
+  for (int t0 = 0; t0 < n_tiles; t0 += 65535) {
+    const int nt = n_tiles - t0 < 65535 ? n_tiles - t0 : 65535;
+    const dim3 grid((tile_px + BLOCK - 1) / BLOCK, nt);
+    float4 *sl = (float4 *) slab + (size_t) t0 * tile_px;
+    if (unpack) hipLaunchKernelGGL(k_move_tiles<true>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects + t0, tile_px, sl);
+    else hipLaunchKernelGGL(k_move_tiles<false>, grid, dim3(BLOCK), 0, st, (float4 *) fb, xres, (const int4 *) d_rects + t0, tile_px, sl);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 
 void debug_phase_stats()
 {
-#ifdef FJ_EXP_SLAB_VALIDATE
-  unsigned long long lost = 0, extra = 0, tests = 0;
-  (void) hipMemcpyFromSymbol(&lost, HIP_SYMBOL(g_slab_lost), sizeof(lost));
-  (void) hipMemcpyFromSymbol(&extra, HIP_SYMBOL(g_slab_extra), sizeof(extra));
-  (void) hipMemcpyFromSymbol(&tests, HIP_SYMBOL(g_slab_tests), sizeof(tests));
-  fprintf(stderr, "fjgpu phase slab32 validation: %llu box tests, %llu lost (must be 0), %llu extra\n", tests, lost, extra);
-#endif
 #ifdef FJ_PHASE_STATS
   {
     unsigned long long c[8];

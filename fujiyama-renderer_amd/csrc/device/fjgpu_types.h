@@ -29,25 +29,6 @@ struct DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 64, "DNodeQ must be 64 bytes");
 
-// ---- 8-wide twin of the tree for the lean any-hit walk (host SAH builds; EXPERIMENT, built and used only with the
-// environment variable FJGPU_WIDE8): the same binary tree collapsed to eight children per node, so that a ray makes fewer
-// DEPENDENT node fetches (the walk is bound by the latency of those, profiles/r03_anyhit_bound_experiments.txt).  Measured
-// (profiles/r03_anyhit_wide8_and_perm.txt): 29 % fewer node visits, not the 45 % hoped for, 15 % MORE VALU instructions (eight
-// box tests + eight stack stores per step), C3 walk 64.4 -> 72.7 ms, C2 54.2 -> 60.2, C6 297 -> 333: the 4-wide tree stays.  DNode8 is the builder's f32 form, DNodeQ8 what the walk reads:
-// 128 B = eight 16-byte loads, child k's (min, max) grid words of x, y, z at q[k], same grid as DNodeQ.  Any hit ends
-// a shadow ray, so the children need no distance order: they are stored by decreasing surface area.
-struct DNode8 {
-  float box[8][6];             // child k: (min, max) pairs of x, y, z; empty slots: (FLT_MAX, -FLT_MAX)
-  uint32_t child[8];           // same child refs as DNode (node refs index the DNode8 / DNodeQ8 array)
-  uint32_t pad[8];
-};
-static_assert(sizeof(DNode8) == 256, "DNode8 must be 256 bytes");
-struct DNodeQ8 {
-  uint16_t q[8][6];
-  uint32_t child[8];
-};
-static_assert(sizeof(DNodeQ8) == 128, "DNodeQ8 must be 128 bytes");
-
 #ifndef FJ_CURVE_QNODES
 #define FJ_CURVE_QNODES 1                // 1: the curve instantiations (scenes with curve sets, no motion) read quantised 64-byte nodes too
 #endif
@@ -185,9 +166,7 @@ struct DAnyInst {
   uint32_t root;
   uint32_t tris_f32;           // 1: f32 records
   int32_t n_prims;
-  uint32_t node8_base;         // DNodeQ8 array (the 8-wide twin; DScene.anyhit_wide) ...
-  uint32_t root8;              // ... and its root ref
-  uint32_t pad;
+  uint32_t pad[3];
 };
 static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 
@@ -266,12 +245,14 @@ struct DScene {
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
   uint32_t *stack_overflow_shadow;   // the same for the shadow kernels (they run concurrently on their own stream)
+  unsigned long long *left_trace, *left_shadow;   // [FJ_LEFT_CAP] chunk lists of the walks' end games (DEndGame): (end << 32) | start of a
+                               // run of queue entries, 0 = empty, 1 = abandoned by the wave that held its ticket; zeroed before every launch
   int32_t all_opaque;          // every group is all_opaque: shadow rays run the lean any-hit kernel
   int32_t has_area;            // any rectangle / sphere light: the light loop draws positions per event
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
-  int32_t anyhit_wide;         // every mesh has the 8-wide twin of its tree (DAnyInst.node8_base): the lean any-hit walk reads it
+  int32_t pad_wide_;
   int32_t incoherent_rays;     // some shader emits two children per hit or diffuse bounces (glass, pathtracing): the
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
   const double *cam_uv;        // implicit camera rays: the (u, v) table of the batch's samples (sample slot = ray index of
@@ -344,6 +325,22 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
   uint32_t tindex;             // sample index in its tile: the ray's time is time_tab[tindex] (motion blur)
 };
 
+// End game of a persistent walk (EndGame, fjgpu_dev_traverse.h): once the queue's heads are exhausted, the rays that waves
+// have claimed but not yet fetched go back into shared lists of small chunks, so that no wave idles while another sits on
+// unfetched rays (the property of the reference's worker pool: MtRunParallelLoop hands out ONE tile at a time,
+// src/fj_multi_thread.cc:86-132).  Every counter on a 128-byte line of its own; reset to zero per launch, like the lists.
+struct DEndGame {
+  uint32_t dry, pad0_[31];           // set by the first wave whose claim finds every region of the queue exhausted
+  // one list per XCD (a single ticket word saturates at ~88 dequeues per microsecond, MI355X_MICROARCH.md "dequeue"; six
+  // thousand waves want a chunk every few microseconds): the waves of XCD x publish into list x and look there first
+  struct { uint32_t v, pad_[31]; } count[8];       // slots of list x handed to publishers
+  struct { uint32_t v, pad_[31]; } head[8];        // slots of list x handed to poppers (tickets)
+};
+#define FJ_LEFT_PER_WAVE 8           // a wave publishes at most this many chunks (its unfetched range is cut accordingly)
+#define FJ_LEFT_LIST 16384u          // slots per list: 1024 waves of an XCD (PERSIST_BLOCKS_PER_CU_MAX x 32 CUs x 4) x FJ_LEFT_PER_WAVE chunks
+                                     // + a slot every wave of the chip may abandon when it leaves
+#define FJ_LEFT_CAP (8u * FJ_LEFT_LIST)
+
 struct DCounters {
   // Counters that many waves add to at the same time sit on their own 128-byte lines:
   // same-line atomics serialise in L2 (and a queue's slot counter must not wait behind tallies).
@@ -366,9 +363,13 @@ struct DCounters {
   // start in region x (their L2 then holds the nodes of ONE stretch of the queue, not of eight) and
   // move on to the next region when theirs is empty; one head per 128-byte line
   uint32_t shadow_xcd_head[8][32];
-  uint32_t trace_xcd_head[8][32];     // the same for the closest-hit walk
+  DEndGame shadow_eg;                 // end game of the shadow walk (reset together with its heads; EndGame finds it BEHIND the heads)
+  uint32_t trace_xcd_head[8][32];     // the same for the closest-hit walk (the two may run on streams of their own)
+  DEndGame trace_eg;
   uint32_t join_count;         // join slots handed out to shadow rays with several candidate instances (DScene.shadow_join);
   uint32_t pad4_[31];          // on a line of its own: one atomic per wave and light
 };
+#include <stddef.h>
+static_assert(offsetof(DCounters, shadow_eg) == offsetof(DCounters, shadow_xcd_head) + 8 * 32 * 4 && offsetof(DCounters, trace_eg) == offsetof(DCounters, trace_xcd_head) + 8 * 32 * 4, "EndGame finds DEndGame behind the heads");
 
 #endif

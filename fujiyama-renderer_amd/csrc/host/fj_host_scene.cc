@@ -557,7 +557,10 @@ static int render_scene(Scene *sc, Renderer *ren)
 
   // tile_done once per rendered tile, in queue order, when the frame is in host memory
   // (TileInfo.framebuffer is readable for the finished tile, src/fj_callback.h:39-59)
+  // (the core may report a batch twice -- it renders the tiles again after a split-shadow queue overflow, include/fjgpu.h --
+  // while the reference reports a tile exactly once)
   std::sort(bctx.done.begin(), bctx.done.end());
+  bctx.done.erase(std::unique(bctx.done.begin(), bctx.done.end()), bctx.done.end());
   for (int32_t t : bctx.done) {
     const fj::TileInfo ti = tile_info(t);
     if (ren->tile_done) ren->tile_done(ren->tile_data, &ti);

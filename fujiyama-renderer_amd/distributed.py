@@ -105,7 +105,9 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None, rects=None
     ds = None
     if dev_path:
         from . import gpu
-        key = (fb.data_ptr(), n_tiles, tile_w, tile_h, rank, world)
+        # (the rectangle table and the frame size are part of the key: another region or resolution with the same tile count
+        # and the same framebuffer allocation must not scatter with the old tables)
+        key = (fb.data_ptr(), H, W, n_tiles, tile_w, tile_h, rank, world, hash(tuple(tuple(int(v) for v in r) for r in rects)))
         if _state.get("slabs_key") != key:
             _state["slabs"], _state["slabs_key"] = _DeviceSlabs(fb, rects, n_tiles, tile_w, tile_h, rank, world), key
         ds = _state["slabs"]

@@ -2,6 +2,7 @@
 `roofline` object and a `cpu_baseline` object (here on the small teapot workload, seconds)."""
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -28,11 +29,16 @@ def test_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
-    # a counter-measured HBM fraction (rocprofv3 child passes of the same run): <= 1 by construction
-    assert r["traffic"] is not None and r["frac"] is not None, "the rocprofv3 counter passes did not run"
+    # an HBM fraction <= 1 by construction, never null: counter-measured (rocprofv3 child passes of the same run) where
+    # rocprofv3 exists, else an estimate that says so (roofline.uncalibrated)
+    assert r["traffic"] is not None and r["frac"] is not None and r["achieved"] is not None
     assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["hbm_counters"]["read_bytes_per_frame"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
-    assert r["binding_resource"] in ("hbm", "valu")
+    if shutil.which("rocprofv3"):
+        assert r["uncalibrated"] is False, "the rocprofv3 counter passes did not run: " + r["frac_source"]
+        assert r["hbm_counters"]["read_bytes_per_frame"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
+        assert r["binding_resource"] in ("hbm", "valu")
+    else:
+        assert r["uncalibrated"] is True and "UNCALIBRATED" in r["frac_source"]
     # the dominant kernel by measured time, named; the SURVEY 8(d) bytes are kept apart
     assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_trace", "k_trace_closest", "k_trace_closest_phased")
     assert r["launches"] >= 1 and r["avg_launch_ms"] > 0 and r["algorithmic"]["bytes_per_launch"] > 0
