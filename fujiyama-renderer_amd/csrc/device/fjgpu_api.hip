@@ -506,10 +506,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       const size_t entries = (size_t) (need - lds_entries) * persistent_threads();
       if (M.alloc(entries, &S.stack_overflow) || M.alloc(entries, &S.stack_overflow_shadow)) return fail(FJGPU_ENOMEM, "device allocation failed for the traversal stack overflow area");
     }
-    // chunk lists of the walks' end games (DEndGame): zero between launches
-    if (M.alloc((size_t) FJ_LEFT_CAP, &S.left_trace) || M.alloc((size_t) FJ_LEFT_CAP, &S.left_shadow) ||
-        hipMemset(S.left_trace, 0, sizeof(unsigned long long) * FJ_LEFT_CAP) != hipSuccess || hipMemset(S.left_shadow, 0, sizeof(unsigned long long) * FJ_LEFT_CAP) != hipSuccess)
-      return fail(FJGPU_ENOMEM, "device allocation failed for the end-game chunk lists");
     sc->stack_need = need;
     sc->tri_record_bytes = 36; sc->blas_nodes = 0;
     for (const auto &ps : hs.primsets) {

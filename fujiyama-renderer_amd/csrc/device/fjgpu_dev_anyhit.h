@@ -26,9 +26,6 @@
 // shadow groups and writes ~instance into the queue entry: the walk reads one flat record
 // (DAnyInst) and starts.  Groups with several instances walk the threaded instance BVH here.
 //
-// End of a launch: EndGame (fjgpu_dev_traverse.h) -- unfetched rays go back into a shared list
-// once the queue is dry, so the launch ends within a few rays of the moment the work runs out.
-//
 // Measured and dropped, with their numbers (the code is kept as a patch: profiles/r04_anyhit_dropped_experiments.patch):
 // an 8-wide twin of the tree (29 % fewer node visits, 15 % more VALU instructions: C3 walk 64.4 -> 72.7 ms), cache-warming
 // touches of the node / triangle a lane will come back to (63.3 -> 68.3 .. 75.6 ms), the unsigned slab variant, ALU / load
@@ -84,7 +81,7 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
 // entry names its instance (the instance-BVH walk and its registers are compiled out).
 template <bool kCount, bool kMulti>
 __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float *s_accum, TravTune tune,
-    uint32_t n, uint32_t *xheads, uint32_t *egoverflow, uint32_t *s_stack, LocalCounters *lc)
+    uint32_t n, uint32_t *xheads, uint32_t *s_stack, LocalCounters *lc)
 {
   const unsigned lane = __lane_id();
   // Per-lane traversal stack: FJ_STACK_LDS_ANYHIT entries in LDS ([depth][thread]), deeper ones
@@ -95,22 +92,25 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   // loop as an invariant and then spilled all the same)
   const uint32_t wave_first = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;     // SGPR
 #define AH_TID() (wave_first + opaque_lane_id())
-#define AH_LDS(depth) s_stack[(depth) * BLOCK + AH_TID()]
+  // (the block's LDS through a pointer the compiler KNOWS to be LDS: through the generic parameter the stack's pop was a flat load --
+  // the choice between the LDS part and the overflow area became a choice between two generic pointers -- which waits for both counters)
+  typedef __attribute__((address_space(3))) uint32_t ah_lds_u32;
+  typedef __attribute__((address_space(3))) double ah_lds_f64;
+  ah_lds_u32 *const ls_stack = (ah_lds_u32 *) s_stack;
+#define AH_LDS(depth) ls_stack[(depth) * BLOCK + AH_TID()]
 #define AH_OVF(depth) S.stack_overflow_shadow[(size_t) ((depth) - FJ_STACK_LDS_ANYHIT) * (gridDim.x * BLOCK) + (size_t) blockIdx.x * BLOCK + AH_TID()]
   auto push = [&](int &sp_, uint32_t v) { if (sp_ < FJ_STACK_LDS_ANYHIT) AH_LDS(sp_) = v; else AH_OVF(sp_) = v; sp_++; };
-  auto pop = [&](int &sp_) -> uint32_t { --sp_; return sp_ < FJ_STACK_LDS_ANYHIT ? AH_LDS(sp_) : AH_OVF(sp_); };
+  auto pop = [&](int &sp_) -> uint32_t { --sp_; uint32_t v_; if (sp_ < FJ_STACK_LDS_ANYHIT) v_ = AH_LDS(sp_); else v_ = AH_OVF(sp_); return v_; };
   bool head_live = true;                   // wave-uniform: the global head still has entries
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
   tune.grab = adaptive_grab(tune.grab, n);
   QueueClaim qc;                           // queue regions by XCD (DCounters.shadow_xcd_head)
   qc.init(xheads, n, tune.grab);
-  EndGame eg;                              // unfetched rays go back into a shared list once the queue is dry
-  eg.init(xheads, S.left_shadow);
   bool have = false;                       // the lane holds a ray whose fate is open
   uint32_t idx = 0;
   // object-space ray (f64: the triangle test's operands): it lives in LDS ([k][thread]) instead of in 12 registers -- only
   // the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
-  double *s_ray = reinterpret_cast<double *>(s_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
+  ah_lds_f64 *const s_ray = (ah_lds_f64 *) (ls_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
 #define AH_RAY(k) s_ray[(k) * BLOCK + AH_TID()]
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
@@ -142,31 +142,16 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
     const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
     const unsigned long long m_leaf = __ballot(at_leaf), m_inner = __ballot(at_inner);
     const unsigned n_leaf = (unsigned) __popcll(m_leaf), n_inner = (unsigned) __popcll(m_inner);
-    // end game: another wave found the queue dry -- this one claims nothing more and gives its unfetched rays back at once
-    bool hand_back = false;
-    if (FJ_ENDGAME && head_live && eg.poll_dry(qc.late)) { head_live = false; hand_back = true; eg.queue_died(); }
     // lanes for which a turnover does something: a ray to retire / move on, or a new one to fetch
-    // (end game: idle lanes ask for a turnover only when the lists may be looked at -- a wave with nothing in flight always may)
-    const bool idle_wave = n_inner == 0 && n_leaf == 0 && __ballot(have) == 0ull;
-    const bool can_fetch = head_live || next < range_end || (FJ_ENDGAME && !eg.dead() && (idle_wave || eg.may_look()));
+    const bool can_fetch = head_live || next < range_end;
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
     const unsigned n_turn = (unsigned) __popcll(m_turn);
 
-    if (n_turn >= (head_live ? TRAV_REFILL : tune.eg_refill) || hand_back || (n_inner == 0 && n_leaf == 0)) {
-      if (m_turn == 0ull && !hand_back) { FJ_TL_END(); break; }           // nothing in flight, nothing left to fetch
+    if (n_turn >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
+      if (m_turn == 0ull) { FJ_TL_END(); break; }           // nothing in flight, nothing left to fetch
       PH(1, 1); PH(2, n_turn);
       // ---- turnover: retire, fetch, enter
-      if (next >= range_end && head_live) {
-        head_live = qc.claim(lane, &next, &range_end);
-        FJ_TL_CLAIM();
-        if (FJ_ENDGAME && !head_live) { eg.raise_dry(lane); eg.queue_died(); }
-      }
-      if (FJ_ENDGAME && !head_live && next >= range_end && can_fetch) {
-        eg.set_published();                                            // (nothing of its own left to give)
-        // a chunk of a list, if some lane can take a ray now (else it would only sit here); a wave with nothing in flight looks
-        // everywhere, then leaves
-        if (n_turn) eg.pop(lane, &next, &range_end, idle_wave);
-      }
+      if (next >= range_end && head_live) { head_live = qc.claim(lane, &next, &range_end); FJ_TL_CLAIM(); }
       bool fetch = false;
       if (fin) {
         fetch = true;
@@ -214,8 +199,6 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       }
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
-      // end game: what this wave has claimed and not fetched goes back into the shared list
-      if (FJ_ENDGAME && !head_live && !eg.published()) { if (!eg.publish(lane, next, range_end, tune.eg_chunk)) *egoverflow = 1; range_end = next; }
       if (fin && have) {
         const DShadowRay *q = &squeue[idx];
         const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
@@ -276,13 +259,12 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 
     if (n_inner >= n_leaf) {
       // ---- inner nodes: one 64-byte node per lane; further steps without a new vote while at
-      // least min_inner lanes stay at inner nodes (fewer once the queue is dry: the wave is emptying anyway)
-      const uint32_t min_inner = head_live ? tune.min_inner : tune.eg_min_inner;
+      // least tune.min_inner lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
       const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
       if (step > 0) {
         const unsigned n_now = (unsigned) __popcll(__ballot(in_now));
-        if (step >= tune.anyhit_steps || n_now < min_inner) break;
+        if (step >= tune.anyhit_steps || n_now < tune.min_inner) break;
         PH(3, 1); PH(4, n_now);
       } else { PH(3, 1); PH(4, n_inner); }
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
@@ -318,7 +300,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (!deep) {
             // three unconditional stores (whatever lies above the new top is dead) instead of
             // three predicated ones
-            uint32_t *top = &AH_LDS(sp);
+            ah_lds_u32 *top = &AH_LDS(sp);
             top[0] = r1; top[BLOCK] = r2; top[2 * BLOCK] = r3;
             sp += nh - 1;
           } else {
@@ -392,7 +374,7 @@ __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYH
   __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + 12 * BLOCK];     // (+ the rays: 6 doubles per thread)
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
-  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], &cnt->overflow, s_stack, &lc);
+  traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

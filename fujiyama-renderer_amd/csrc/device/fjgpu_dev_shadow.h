@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
   ShadowPolicy pol;
   pol.S = &S; pol.squeue = squeue; pol.s_accum = s_accum;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion, kInstLds, kAnyOnly>(S, pol, tune, n, &cnt->shadow_xcd_head[0][0], S.left_shadow, &cnt->overflow, make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
+  traverse_persistent<kCurves, kCount, kMotion, kInstLds, kAnyOnly>(S, pol, tune, n, &cnt->shadow_xcd_head[0][0], make_stack(s_stack, S.stack_overflow_shadow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     flush_shadow_walk_counters(cnt, lc.nodes, lc.prims, lc.insts);

@@ -76,8 +76,7 @@ __device__ unsigned long long g_rayhist[64];
 #define FJ_TL_ITER(dry) do { } while (0)
 #define FJ_TL_END() do { } while (0)
 #endif
-struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased,
-  eg_chunk, eg_refill, eg_min_inner; };      // end game (EndGame): rays per published chunk, refill threshold and min_inner once the queue is dry
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
@@ -109,7 +108,6 @@ __device__ __forceinline__ uint32_t xcc_id()      // the XCD this wave runs on (
 struct QueueClaim {
   uint32_t *heads;
   uint32_t n, per, grab, region, left;
-  bool late;            // the queue is nearly empty: this wave's last claim came from the last eighth of a region, or from a region not its own
   __device__ __forceinline__ void init(uint32_t *heads_, uint32_t n_, uint32_t grab_)
   {
     heads = heads_; n = n_; grab = grab_;
@@ -117,7 +115,6 @@ struct QueueClaim {
     per = ((n / parts + grab) / grab) * grab;       // a multiple of the claim; parts * per >= n
     region = FJ_XCD_HEADS ? (xcc_id() & 7u) : 0u;
     left = parts;
-    late = n < 64u * grab;
   }
   // the next slice [*next, *range_end) of the queue; false: the queue is empty
   __device__ __forceinline__ bool claim(unsigned lane, uint32_t *next, uint32_t *range_end)
@@ -129,172 +126,11 @@ struct QueueClaim {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&heads[region * 32u], grab);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (base < hi - lo) {
-          *next = lo + base; *range_end = (hi - *next < grab) ? hi : *next + grab;
-          if (left < (FJ_XCD_HEADS ? 8u : 1u) || (unsigned long long) (base + grab) * 8ull >= (unsigned long long) (hi - lo) * 7ull) late = true;
-          return true;
-        }
+        if (base < hi - lo) { *next = lo + base; *range_end = (hi - *next < grab) ? hi : *next + grab; return true; }
       }
       left--;
       region = (region + 1u) & 7u;
     }
-    return false;
-  }
-};
-
-// ---- End game of a persistent walk: no wave idles while another sits on rays it has claimed but not fetched.
-// The reference's worker pool hands out one tile at a time, so its workers finish within one tile of each other
-// (MtRunParallelLoop / checkout_iteration_id, src/fj_multi_thread.cc:86-132).  Here a wave claims `grab` consecutive rays per
-// atomic -- large claims keep the atomics off the walk's critical path and the rays of a wave coherent -- and ray costs are
-// heavy tailed AND clustered (neighbouring queue entries cost alike: a claim of 256 grazing shadow rays is ~60 times the
-// average claim), so a launch used to end with a few waves working through their last claims for milliseconds while
-// everyone else had left (profiles/r04_wave_timeline.txt: 24 % of a rank's shadow walk).  Now:
-//   * the first wave whose claim finds every region exhausted raises DEndGame.dry; every wave polls that flag (every FJ_EG_POLL
-//     iterations once it knows the queue is nearly empty, QueueClaim.late; every FJ_EG_POLL_EARLY before) and, once it is up or its
-//     own claim failed, PUBLISHES the unfetched rest of its claim as chunks of `chunk` rays in its XCD's list;
-//   * a list is a rendezvous: slot i is filled by the i-th publisher (DEndGame.count) and taken by the i-th popper
-//     (DEndGame.head; fetch-adds -- a CAS loop would starve with thousands of poppers; one list per XCD, its own first, because
-//     one ticket word saturates at ~88 dequeues per microsecond).  A popper only takes a ticket where it has seen count > head;
-//     a ticket whose slot is still empty is KEPT and looked at again at the wave's next turnover;
-//   * nobody waits for anybody: a wave with nothing in flight looks at every list once more, marks the slot of a ticket it
-//     still holds ABANDONED (compare-and-swap: if the chunk arrived first it takes it) and leaves; a publisher that finds its
-//     slot abandoned takes the next one.  A chunk published after everybody else has left is popped by its own publisher, which
-//     goes on as a popper -- the launch then ends as it used to, never worse.
-// Everything here is wave-uniform; the lists are zeroed before every launch.
-#ifndef FJ_EG_POLL
-#define FJ_EG_POLL 16
-#endif
-#ifndef FJ_EG_POLL_EARLY
-#define FJ_EG_POLL_EARLY 128
-#endif
-#ifndef FJ_ENDGAME
-#define FJ_ENDGAME 0                // (in progress: parity-green when on, but it does not pay yet)
-#endif
-#define FJ_EG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define FJ_EG_ABANDONED 1ull
-// Register-lean on purpose (the lean any-hit walk has no scalar register to spare either): the control block is found from the
-// queue's heads (DCounters: shadow_xcd_head is followed by shadow_eg, trace_xcd_head by trace_eg), the wave's state is one word.
-struct EndGame {
-  uint32_t *heads;               // the walk's QueueClaim heads; DEndGame follows them
-  unsigned long long *chunks;
-  // bits 0-14 held ticket + 1 (0: none), 15-17 its list, 18-20 back-off level, 21 published (this wave has given its unfetched rays
-  // back), 22 dead (it has looked everywhere with nothing in flight: it may leave), 24-31 a counter: iterations since the last look at the
-  // dry flag while the queue has entries, then iterations left until the next look at the lists
-  uint32_t st;
-  __device__ __forceinline__ DEndGame *ctl() const { return reinterpret_cast<DEndGame *>(heads + 8 * 32); }
-  __device__ __forceinline__ void init(uint32_t *heads_, unsigned long long *chunks_) { heads = heads_; chunks = chunks_; st = 0; }
-  __device__ __forceinline__ bool published() const { return (st >> 21) & 1u; }
-  __device__ __forceinline__ bool dead() const { return (st >> 22) & 1u; }
-  __device__ __forceinline__ void set_published() { st |= 1u << 21; }
-  // (a relaxed agent-scope load: served by L2, ~1 us under load and the wave waits for it -- hence rarely while the queue is far from empty)
-  __device__ __forceinline__ bool poll_dry(bool late)
-  {
-    st += 1u << 24;
-    return ((st >> 24) % (late ? FJ_EG_POLL : FJ_EG_POLL_EARLY)) == 0u && FJ_EG_LOAD(&ctl()->dry) != 0u;
-  }
-  // The lists are looked at when lanes are idle -- but not in every iteration: a look costs a few L2 round trips, the walks that run one
-  // phase per iteration would starve their busy lanes, and thousands of waves looking at the same lines slow everybody down.  After a
-  // look that found nothing the wave waits 8, 16, ... 128 iterations (a wave with nothing in flight looks everywhere at once and leaves).
-  __device__ __forceinline__ void queue_died() { st &= 0x00ffffffu; }
-  __device__ __forceinline__ bool may_look()
-  {
-    if ((st >> 24) == 0u) return true;
-    st -= 1u << 24;
-    return false;
-  }
-  __device__ __forceinline__ void found(bool yes)
-  {
-    uint32_t lvl = (st >> 18) & 7u;
-    if (yes) { st &= ~((7u << 18) | 0xff000000u); return; }
-    st = (st & ~((7u << 18) | 0xff000000u)) | ((lvl < 4u ? lvl + 1u : 4u) << 18) | ((8u << lvl) << 24);
-  }
-  __device__ __forceinline__ void raise_dry(unsigned lane) const { if (lane == 0) __hip_atomic_store(&ctl()->dry, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ unsigned long long *slot(uint32_t list, uint32_t i) const { return &chunks[(size_t) list * FJ_LEFT_LIST + i]; }
-  // give [next, range_end) back (possibly empty); false: a list ran out of slots (cannot happen by the sizes in fjgpu_types.h)
-  __device__ __forceinline__ bool publish(unsigned lane, uint32_t next, uint32_t range_end, uint32_t chunk)
-  {
-    set_published();
-    if (range_end <= next) return true;
-    const uint32_t home = xcc_id() & 7u;
-    const uint32_t left = range_end - next;
-    uint32_t len = chunk < 4u ? 4u : chunk;
-    if ((left + len - 1u) / len > (uint32_t) FJ_LEFT_PER_WAVE) len = (left + FJ_LEFT_PER_WAVE - 1u) / FJ_LEFT_PER_WAVE;
-    const uint32_t n = (left + len - 1u) / len;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl()->count[home].v, n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    bool ok = true;
-    if (lane < n) {
-      const uint32_t a = next + lane * len, b = (a + len < range_end) ? a + len : range_end;
-      const unsigned long long v = ((unsigned long long) b << 32) | a;
-      uint32_t idx = base + lane;
-      for (;;) {
-        if (idx >= FJ_LEFT_LIST) { ok = false; break; }
-        if (atomicCAS(slot(home, idx), 0ull, v) == 0ull) break;
-        idx = atomicAdd(&ctl()->count[home].v, 1u);        // the popper that held this slot's ticket has left: the next slot
-      }
-    }
-    return __ballot(!ok) == 0ull;
-  }
-  __device__ __forceinline__ bool take(unsigned long long v, uint32_t *next, uint32_t *range_end)
-  {
-    st &= ~0x3ffffu;             // no ticket held
-    *next = (uint32_t) (v & 0xffffffffull);
-    *range_end = (uint32_t) (v >> 32);
-    return true;
-  }
-  // hand a held ticket back (this wave is about to leave), unless the chunk arrives first
-  __device__ __forceinline__ bool give_up(unsigned lane, uint32_t *next, uint32_t *range_end)
-  {
-    const uint32_t t = (st & 0x7fffu) - 1u, y = (st >> 15) & 7u;
-    unsigned long long old = 0ull;
-    if (lane == 0) old = atomicCAS(slot(y, t), 0ull, FJ_EG_ABANDONED);
-    old = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (old >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) old);
-    if (old > FJ_EG_ABANDONED) return take(old, next, range_end);
-    st &= ~0x3ffffu;
-    return false;
-  }
-  // one list: a ticket if it has more publishers than poppers
-  __device__ __forceinline__ bool try_list(unsigned lane, uint32_t y, uint32_t *next, uint32_t *range_end)
-  {
-    const uint32_t c = FJ_EG_LOAD(&ctl()->count[y].v), h = FJ_EG_LOAD(&ctl()->head[y].v);
-    if (c <= h || h >= FJ_LEFT_LIST) return false;
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(&ctl()->head[y].v, 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= FJ_LEFT_LIST) return false;
-    unsigned long long v = FJ_EG_LOAD(slot(y, t));
-    // a slot below the count this wave saw belongs to a publisher that is about to write it (its store follows its fetch-add):
-    // wait for it -- handing such a ticket back would only send the publisher to the next slot
-    if (t < c) while (v == 0ull) { __builtin_amdgcn_s_sleep(1); v = FJ_EG_LOAD(slot(y, t)); }
-    if (v > FJ_EG_ABANDONED) return take(v, next, range_end);
-    st = (st & ~0x3ffffu) | (t + 1u) | (y << 15);
-    return false;
-  }
-  // a chunk for this wave: true = [*next, *range_end) is set.  everywhere: look at all eight lists (a wave with nothing in flight: if it
-  // finds nothing it may leave), else at its own and one other.
-  __device__ __forceinline__ bool pop(unsigned lane, uint32_t *next, uint32_t *range_end, bool everywhere)
-  {
-    const uint32_t home = xcc_id() & 7u;
-    if (st & 0x7fffu) {
-      const unsigned long long v = FJ_EG_LOAD(slot((st >> 15) & 7u, (st & 0x7fffu) - 1u));
-      if (v > FJ_EG_ABANDONED) { found(true); return take(v, next, range_end); }
-      if (!everywhere) { found(false); return false; }
-      if (give_up(lane, next, range_end)) return true;
-    }
-    if (!everywhere) {
-      bool got = try_list(lane, home, next, range_end);
-      if (!got && !(st & 0x7fffu)) got = try_list(lane, (home + 1u + (uint32_t) (__builtin_readcyclecounter() % 7ull)) & 7u, next, range_end);   // ... and one of the others
-      found(got);
-      return got;
-    }
-#pragma nounroll
-    for (uint32_t k = 0; k < 8u; k++) {
-      if (try_list(lane, (home + k) & 7u, next, range_end)) return true;
-      // (a ticket whose slot is empty: this wave is idle, so it hands it back at once and looks on)
-      if ((st & 0x7fffu) && give_up(lane, next, range_end)) return true;
-    }
-    st |= 1u << 22;      // nothing in flight, nothing anywhere: this wave leaves
     return false;
   }
 };
@@ -367,8 +203,7 @@ template <> struct InstLdsOf<true> { typedef InstLdsCurves T; };
 // kAnyOnly: every ray of the launch is an any-hit ray and an occluded one adds nothing (shadow rays of scenes whose occluders are all
 // opaque): no hit record is kept at all -- a hit retires the ray on the spot, a ray that runs out of instances reaches the light.
 template <bool kCurves, bool kCount, bool kMotion, bool kInstLds, bool kAnyOnly, class Policy>
-__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, unsigned long long *egchunks, uint32_t *egoverflow,
-    TravStack stk, LocalCounters *lc, const double *s_inst)
+__device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
   typedef typename InstLdsOf<kCurves>::T IL;
@@ -385,10 +220,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
   tune.grab = adaptive_grab(tune.grab, n);
   QueueClaim qc;
   qc.init(head, n, tune.grab);
-  EndGame eg;                              // unfetched rays go back into a shared list once the queue is dry
-  eg.init(head, egchunks);
   if (kCurves) { tune.refill = tune.refill_curves; tune.steps = tune.steps_curves; }
-  if (tune.eg_refill > tune.refill) tune.eg_refill = tune.refill;
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o, winv = o;
@@ -432,21 +264,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 #endif
     // ---- refill idle lanes from the wave's slice
     const unsigned long long idle = __ballot(!have);
-    // end game: another wave found the queue dry -- this one claims nothing more and gives its unfetched rays back (below)
-    if (FJ_ENDGAME && head_live && eg.poll_dry(qc.late)) { head_live = false; eg.queue_died(); }
-    const unsigned refill_now = head_live ? TRAV_REFILL : tune.eg_refill;
-    if (next >= range_end && (idle == ~0ull || (unsigned) __popcll(idle) >= refill_now)) {
-      if (head_live) {
-        head_live = qc.claim(lane, &next, &range_end);
-        if (FJ_ENDGAME && !head_live) { eg.raise_dry(lane); eg.queue_died(); }
-      }
-      if (FJ_ENDGAME && !head_live && next >= range_end && !eg.dead()) {
-        eg.set_published();                                            // (nothing of its own left to give)
-        // (a wave with nothing in flight looks everywhere, then leaves; the others look now and then: EndGame::may_look)
-        if (idle == ~0ull || eg.may_look()) eg.pop(lane, &next, &range_end, idle == ~0ull);
-      }
-    }
-    if (idle == ~0ull || ((unsigned) __popcll(idle) >= refill_now && next < range_end)) {
+    if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL))
+      head_live = qc.claim(lane, &next, &range_end);
+    if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
       if (!have) {
         const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
         if (my < range_end) {
@@ -472,9 +292,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         }
       }
       next += (uint32_t) __popcll(idle);
-      if (next > range_end) next = range_end;
       if (__ballot(have) == 0ull) {
-        if (next >= range_end && !head_live && (!FJ_ENDGAME || eg.dead())) {
+        if (next >= range_end && !head_live) {
 #ifdef FJ_PHASE_STATS
           if (lane == 0) { atomicMax(&g_phase[12], it_tail); atomicAdd(&g_phase[13], it_tail); atomicAdd(&g_phase[14], it_all); atomicAdd(&g_phase[15], 1ull);
             atomicAdd(&g_phase[1], cyc[0]); atomicAdd(&g_phase[3], cyc[1]); atomicAdd(&g_phase[5], cyc[2]); atomicAdd(&g_phase[7], cyc[3]); }
@@ -482,12 +301,9 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           FJ_TL_END();
           break;
         }
-        if (FJ_ENDGAME && !head_live && !eg.published()) { if (!eg.publish(lane, next, range_end, tune.eg_chunk)) *egoverflow = 1; range_end = next; }
         continue;               // only padding slots were fetched / slice exhausted: claim more
       }
     }
-    // end game: what this wave has claimed and not fetched goes back into the shared list
-    if (FJ_ENDGAME && !head_live && !eg.published()) { if (!eg.publish(lane, next, range_end, tune.eg_chunk)) *egoverflow = 1; range_end = next; }
 
     // (Round 3 measured the phases of this walk on C5 in clock ticks -- debug build: instance entry 24 %, inner steps 38 % with 24
     // of 64 lanes, leaf phase 18 %, second stage of the ribbon test 20 % -- and tried GATING them like the lean any-hit walk does,
@@ -726,8 +542,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
 // kInstLds: the scene's instance level (DTNodes, then one DInstEntry per instance) sits in LDS at s_inst (DScene.inst_lds;
 // filled by the kernel); otherwise the same records are read from DScene.group_nodes / inst_entries.
 template <bool kCount, bool kMotion, bool kInstLds, class Policy>
-__device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, unsigned long long *egchunks, uint32_t *egoverflow,
-    TravStack stk, LocalCounters *lc, const double *s_inst)
+__device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
   const DTNode *gnodes = kInstLds ? (const DTNode *) s_inst : S.group_nodes;
   const DInstEntry *gents = kInstLds ? (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT) : S.inst_entries;
@@ -738,8 +553,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
   tune.grab = adaptive_grab(tune.grab, n);
   QueueClaim qc;
   qc.init(head, n, tune.grab);
-  EndGame eg;                              // unfetched rays go back into a shared list once the queue is dry
-  eg.init(head, egchunks);
   bool have = false;
   uint32_t idx = 0;
   V3 o = mk(0, 0, 0), oo = o, od = o, d = o;
@@ -766,16 +579,11 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
     const bool at_leaf = !fin && (cur & FJ_LEAF_FLAG);
     const bool at_inner = !fin && !at_leaf;
     const unsigned n_leaf = (unsigned) __popcll(__ballot(at_leaf)), n_inner = (unsigned) __popcll(__ballot(at_inner));
-    // end game: another wave found the queue dry -- this one claims nothing more and gives its unfetched rays back at once
-    bool hand_back = false;
-    if (FJ_ENDGAME && head_live && eg.poll_dry(qc.late)) { head_live = false; hand_back = true; eg.queue_died(); }
-    // (end game: idle lanes ask for a turnover only when the lists may be looked at -- a wave with nothing in flight always may)
-    const bool idle_wave = n_inner == 0 && n_leaf == 0 && __ballot(have) == 0ull;
-    const bool can_fetch = head_live || next < range_end || (FJ_ENDGAME && !eg.dead() && (idle_wave || eg.may_look()));
+    const bool can_fetch = head_live || next < range_end;
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
 
-    if ((unsigned) __popcll(m_turn) >= (head_live ? TRAV_REFILL : tune.eg_refill) || hand_back || (n_inner == 0 && n_leaf == 0)) {
-      if (m_turn == 0ull && !hand_back) {
+    if ((unsigned) __popcll(m_turn) >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
+      if (m_turn == 0ull) {
 #ifdef FJ_PHASE_STATS
         if (lane == 0) {
           for (int k = 0; k < 3; k++) { atomicAdd(&g_phase[1 + 2 * k], pcyc[k]); atomicAdd(&g_phase[2 + 2 * k], pln[k]); atomicAdd(&g_phase[7 + k], pex[k]); }
@@ -785,16 +593,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
         break;
       }
       // ---- turnover: fetch, enter the next instance, or retire
-      if (next >= range_end && head_live) {
-        head_live = qc.claim(lane, &next, &range_end);
-        if (FJ_ENDGAME && !head_live) { eg.raise_dry(lane); eg.queue_died(); }
-      }
-      if (FJ_ENDGAME && !head_live && next >= range_end && can_fetch) {
-        eg.set_published();                                            // (nothing of its own left to give)
-        // a chunk of a list, if some lane can take a ray now (else it would only sit here); a wave with nothing in flight looks
-        // everywhere, then leaves
-        if (m_turn) eg.pop(lane, &next, &range_end, idle_wave);
-      }
+      if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
       const bool fetch = fin && !have;
       const unsigned long long m_fetch = __ballot(fetch);
       if (fetch) {
@@ -814,8 +613,6 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       }
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
-      // end game: what this wave has claimed and not fetched goes back into the shared list
-      if (FJ_ENDGAME && !head_live && !eg.published()) { if (!eg.publish(lane, next, range_end, tune.eg_chunk)) *egoverflow = 1; range_end = next; }
 #ifdef FJ_PHASE_STATS
       unsigned my_trips = 0;
 #endif
@@ -1020,7 +817,7 @@ __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? F
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_persistent<kCurves, kCount, kMotion, kInstLds, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], S.left_trace, &cnt->overflow, make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
+  traverse_persistent<kCurves, kCount, kMotion, kInstLds, false>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, kCurves ? s_rayspace : nullptr), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);
@@ -1045,7 +842,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_phased<kCount, false, kInstLds>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], S.left_trace, &cnt->overflow, make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc, s_inst);
+  traverse_phased<kCount, false, kInstLds>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

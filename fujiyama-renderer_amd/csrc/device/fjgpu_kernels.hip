@@ -169,7 +169,7 @@ static int anyhit_blocks_per_cu(bool multi)
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -186,10 +186,6 @@ static TravTune trav_tune()
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
     t.min_inner_phased = env("FJGPU_TRAV_MININNER_PHASED", 12);
-    // end game (EndGame, fjgpu_dev_traverse.h): chunk size of the rays handed back, refill threshold and min_inner once the queue is dry
-    t.eg_chunk = env("FJGPU_EG_CHUNK", 32);
-    t.eg_refill = env("FJGPU_EG_REFILL", 24);
-    t.eg_min_inner = env("FJGPU_EG_MININNER", 8);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
@@ -255,8 +251,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     uint32_t n, DCounters *cnt, int count_events)
 {
   if (n == 0) return 0;
-  (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head) + sizeof(cnt->trace_eg), st);      // heads + end game
-  if (FJ_ENDGAME) (void) hipMemsetAsync(S.left_trace, 0, sizeof(unsigned long long) * FJ_LEFT_CAP, st);                 // ... and its chunk lists
+  (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head), st);
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
   // (the event counters cost registers and issue slots: counting is its own instantiation)
   const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));
@@ -317,7 +312,7 @@ void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 {
   (void) hipMemsetAsync(&cnt->shadow_count, 0, 2 * sizeof(uint32_t), st);   // shadow_count + shadow_head
   (void) hipMemsetAsync(&cnt->join_count, 0, sizeof(uint32_t), st);
-  (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head) + sizeof(cnt->shadow_eg), st);   // heads + end game
+  (void) hipMemsetAsync(&cnt->shadow_xcd_head[0][0], 0, sizeof(cnt->shadow_xcd_head), st);
 }
 
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
@@ -344,7 +339,6 @@ int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, 
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events)
 {
   TL_ZERO(st);
-  if (FJ_ENDGAME) (void) hipMemsetAsync(S.left_shadow, 0, sizeof(unsigned long long) * FJ_LEFT_CAP, st);      // chunk lists of the end game (DEndGame: reset with the heads)
   if (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) {
 #define FJ_LAUNCH_ANYHIT(COUNT, MULTI) hipLaunchKernelGGL((k_shadow_anyhit<COUNT, MULTI>), dim3(persistent_grid(1ull << 30, anyhit_blocks_per_cu(MULTI))), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     // (with DScene.shadow_join every queue entry names its instance: the instantiation without the instance-level walk)

@@ -245,8 +245,6 @@ struct DScene {
   int32_t n_instances, n_groups, n_primsets;
   uint32_t *stack_overflow;    // [stack_need - FJ_STACK_LDS][persistent threads] or null (see TravStack)
   uint32_t *stack_overflow_shadow;   // the same for the shadow kernels (they run concurrently on their own stream)
-  unsigned long long *left_trace, *left_shadow;   // [FJ_LEFT_CAP] chunk lists of the walks' end games (DEndGame): (end << 32) | start of a
-                               // run of queue entries, 0 = empty, 1 = abandoned by the wave that held its ticket; zeroed before every launch
   int32_t all_opaque;          // every group is all_opaque: shadow rays run the lean any-hit kernel
   int32_t has_area;            // any rectangle / sphere light: the light loop draws positions per event
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
@@ -325,22 +323,6 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
   uint32_t tindex;             // sample index in its tile: the ray's time is time_tab[tindex] (motion blur)
 };
 
-// End game of a persistent walk (EndGame, fjgpu_dev_traverse.h): once the queue's heads are exhausted, the rays that waves
-// have claimed but not yet fetched go back into shared lists of small chunks, so that no wave idles while another sits on
-// unfetched rays (the property of the reference's worker pool: MtRunParallelLoop hands out ONE tile at a time,
-// src/fj_multi_thread.cc:86-132).  Every counter on a 128-byte line of its own; reset to zero per launch, like the lists.
-struct DEndGame {
-  uint32_t dry, pad0_[31];           // set by the first wave whose claim finds every region of the queue exhausted
-  // one list per XCD (a single ticket word saturates at ~88 dequeues per microsecond, MI355X_MICROARCH.md "dequeue"; six
-  // thousand waves want a chunk every few microseconds): the waves of XCD x publish into list x and look there first
-  struct { uint32_t v, pad_[31]; } count[8];       // slots of list x handed to publishers
-  struct { uint32_t v, pad_[31]; } head[8];        // slots of list x handed to poppers (tickets)
-};
-#define FJ_LEFT_PER_WAVE 8           // a wave publishes at most this many chunks (its unfetched range is cut accordingly)
-#define FJ_LEFT_LIST 16384u          // slots per list: 1024 waves of an XCD (PERSIST_BLOCKS_PER_CU_MAX x 32 CUs x 4) x FJ_LEFT_PER_WAVE chunks
-                                     // + a slot every wave of the chip may abandon when it leaves
-#define FJ_LEFT_CAP (8u * FJ_LEFT_LIST)
-
 struct DCounters {
   // Counters that many waves add to at the same time sit on their own 128-byte lines:
   // same-line atomics serialise in L2 (and a queue's slot counter must not wait behind tallies).
@@ -363,13 +345,9 @@ struct DCounters {
   // start in region x (their L2 then holds the nodes of ONE stretch of the queue, not of eight) and
   // move on to the next region when theirs is empty; one head per 128-byte line
   uint32_t shadow_xcd_head[8][32];
-  DEndGame shadow_eg;                 // end game of the shadow walk (reset together with its heads; EndGame finds it BEHIND the heads)
   uint32_t trace_xcd_head[8][32];     // the same for the closest-hit walk (the two may run on streams of their own)
-  DEndGame trace_eg;
   uint32_t join_count;         // join slots handed out to shadow rays with several candidate instances (DScene.shadow_join);
   uint32_t pad4_[31];          // on a line of its own: one atomic per wave and light
 };
-#include <stddef.h>
-static_assert(offsetof(DCounters, shadow_eg) == offsetof(DCounters, shadow_xcd_head) + 8 * 32 * 4 && offsetof(DCounters, trace_eg) == offsetof(DCounters, trace_xcd_head) + 8 * 32 * 4, "EndGame finds DEndGame behind the heads");
 
 #endif

@@ -13,11 +13,15 @@ import numpy as np
 
 
 hists = {}
+splits = {}
 
 
 def launches(path):
     name, rows = None, []
     for line in open(path):
+        if line.startswith("#split"):
+            splits[name] = line[1:].strip()
+            continue
         if line.startswith("#hist"):
             hists[name] = line.split()[1:]
             continue
@@ -62,6 +66,8 @@ def main():
             print("    claims per wave: median %d | a wave's LONGEST claim: median %.0f us / %d iterations, p99 %.0f us, max %.0f us; the eight longest: %s" % (
                 int(np.median(nc)), us(np.median(wt)), int(np.median(wi)), us(np.percentile(wt, 99)), us(wt.max()),
                 "  ".join("%.0f us / %d it (%.2f us per it)" % (us(wt[k]), int(wi[k]), us(wt[k]) / max(1, wi[k])) for k in o)))
+        if splits.get(name):
+            print("    ray splitting: " + splits[name])
         h = hists.get(name)
         if h and any(x != "0:0" for x in h):
             tot_r = sum(int(x.split(":")[0]) for x in h) or 1
