@@ -36,6 +36,8 @@ int fail(int code, const std::string &msg)
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
   return fail(FJGPU_ENODEV, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+#define FJ_LREC_BUFS 4
+
 struct DeviceBuffers {
   std::vector<void *> ptrs;
   size_t bytes = 0;
@@ -90,11 +92,14 @@ struct fjgpu_scene {
   int max_children;                // most child rays one shading event can emit in this scene
   bool bounce_diffuse, bounce_reflect, bounce_refract;   // bounce types some shader of the scene emits
   DHit *d_hits;
-  DLightRec *d_lrecs[2];           // double buffered: the shadow stream consumes one while shading fills the other
-  DLightHair *d_lhair[2];          // only when the scene has a HairShader
-  long overlap;                    // option "overlap_shadow"
+  DLightRec *d_lrecs[FJ_LREC_BUFS];   // several buffers: the shadow stream consumes one while shading fills another (two are used without the overlap)
+  DLightHair *d_lhair[FJ_LREC_BUFS];  // only when the scene has a HairShader
+  int lrec_bufs = 2;                  // buffers allocated: 2, or FJ_LREC_BUFS once the overlap option is on
+  long overlap;                    // option "overlap_shadow": 0 off, 1 on, 2 by the batch size
+  bool overlap_now = false;        // ... what this render call does
+  long early_shadow = 0;           // with it: level 0's shadow rays are walked as soon as its light loop has run (FJGPU_EARLY_SHADOW)
   hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
-  hipEvent_t ev_shadow_done[2];    // shadow work reading d_lrecs[k] has finished
+  hipEvent_t ev_shadow_done[FJ_LREC_BUFS];    // shadow work reading d_lrecs[k] has finished
   std::vector<hipEvent_t> ev_pool; // per-launch timing events (resolved at the end of the frame: no host sync per launch)
   DShadowRay *d_squeue;
   size_t squeue_cap;
@@ -133,18 +138,31 @@ static int grow(void **p, size_t *have, size_t want, size_t elem)
   return 0;
 }
 
-// Option "overlap_shadow": the light loop + shadow traversal of a level on their own stream,
-// concurrent with the next level's closest-hit work.  Measured on C3: the kernels do overlap,
-// but a persistent kernel fills the chip until its tail, so a frame gains nothing at 1 GPU and
-// 2.5 % at the per-rank load of an 8-GPU job, while per-kernel durations (and the roofline
-// derived from them) inflate; since the shadow traversal became ONE launch per batch (its
-// tail was what overlapped) it even loses, because the queue bound cannot be refreshed from
-// the device without synchronising the second stream.  Off by default; kept as an experiment.
+// Option "overlap_shadow" (0 off, 1 on, 2 = by the size of the batch, the default): the light loops on a stream of their own, concurrent
+// with the NEXT recursion levels' closest-hit walks, and with only FJ_OVERLAP_CULL_BLOCKS resident blocks per CU so that they leave the
+// walks room.  It pays where the launches are small -- a rank's share of an 8-GPU frame, a small frame: the closest-hit walks of the deeper
+// levels are then a few long rays each (a launch per level: 0.7 ms of dependent fetches and nothing else, profiles/r04_wave_timeline_*.txt),
+// and the light loops' VALU work fits underneath: a rank's share of C3 20.9 -> 19.7 ms (profiles/r04_overlap_small_launches.txt).  A whole
+// 1080p frame on one GPU loses with it (123 -> 136 ms: its walks fill the chip for most of their time), so "by size" turns it on below
+// FJ_OVERLAP_MAX_SAMPLES samples per batch, for scenes whose shaders bounce.  (Round 1-3 kept it off: with the light loop at full
+// occupancy the two streams only took turns.  Walking level 0's shadow rays early, under the deeper levels, was measured too
+// (FJGPU_EARLY_SHADOW): the persistent walk fills every slot and the shading kernels of the deeper levels wait behind it: 20.3 ms.)
+#ifndef FJ_OVERLAP_MAX_SAMPLES
+#define FJ_OVERLAP_MAX_SAMPLES ((size_t) 24 << 20)    // (a quarter of a 1080p, 64 spp frame still loses with it: 35.5 -> 36.1 ms; an eighth gains)
+#endif
+#ifndef FJ_OVERLAP_CULL_BLOCKS
+#define FJ_OVERLAP_CULL_BLOCKS 1
+#endif
 static int enable_overlap(fjgpu_scene *sc)
 {
   if (sc->shadow_stream) return 0;
-  if (hipStreamCreateWithFlags(&sc->shadow_stream, hipStreamNonBlocking) != hipSuccess) { sc->shadow_stream = nullptr; return -1; }
-  for (int k = 0; k < 2; k++)
+  // (FJGPU_OVERLAP_PRIO: the stream gets the LOWEST priority, so that its blocks only take the slots the main stream's kernels leave)
+  int prio_lo = 0, prio_hi = 0;
+  if (getenv("FJGPU_OVERLAP_PRIO") && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi) {
+    if (hipStreamCreateWithPriority(&sc->shadow_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) { sc->shadow_stream = nullptr; return -1; }
+  }
+  else if (hipStreamCreateWithFlags(&sc->shadow_stream, hipStreamNonBlocking) != hipSuccess) { sc->shadow_stream = nullptr; return -1; }
+  for (int k = 0; k < FJ_LREC_BUFS; k++)
     if (hipEventCreateWithFlags(&sc->ev_shadow_done[k], hipEventDisableTiming) != hipSuccess) return -1;
   return 0;
 }
@@ -248,10 +266,11 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   sc->count_all_shadow = 1;
   sc->work_samples = sc->work_rays = 0;
   sc->tab_len = 0;
-  sc->overlap = 0;
+  sc->overlap = 2;
   sc->shadow_stream = nullptr;
-  sc->ev_shadow_done[0] = sc->ev_shadow_done[1] = nullptr;
-  if (getenv("FJGPU_OVERLAP")) { if (enable_overlap(sc.get())) return fail(FJGPU_ENODEV, "could not create the shadow stream"); sc->overlap = 1; }
+  for (int k = 0; k < FJ_LREC_BUFS; k++) { sc->ev_shadow_done[k] = nullptr; sc->d_lrecs[k] = nullptr; sc->d_lhair[k] = nullptr; }
+  if (getenv("FJGPU_EARLY_SHADOW")) sc->early_shadow = atoi(getenv("FJGPU_EARLY_SHADOW"));
+  if (const char *e = getenv("FJGPU_OVERLAP")) sc->overlap = std::max(0, std::min(2, atoi(e)));
   DeviceBuffers &M = sc->mem;
   int e = 0;
 
@@ -683,8 +702,8 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
   if (n == "count_nodes") { scene->count_events = value != 0; return 0; }
   if (n == "count_all_shadow") { scene->count_all_shadow = value != 0; return 0; }
   if (n == "overlap_shadow") {
-    if (value) { if (enable_overlap(scene)) return fail(FJGPU_ENODEV, "could not create the shadow stream"); scene->overlap = 1; }
-    else scene->overlap = 0;
+    if (value < 0 || value > 2) return fail(FJGPU_EINVAL, "overlap_shadow: 0 off, 1 on, 2 by the batch size");
+    scene->overlap = value;
     return 0;
   }
   return fail(FJGPU_EINVAL, "unknown option " + n);
@@ -698,7 +717,9 @@ struct BatchTile { fjgpu::TileRect r; int nx, ny; uint32_t offset; };
 
 int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t tab_len)
 {
-  if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap) {
+  const int want_bufs = sc->overlap_now ? FJ_LREC_BUFS : 2;
+  if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap || want_bufs > sc->lrec_bufs) {
+    sc->lrec_bufs = want_bufs;
     sc->work.reset(new DeviceBuffers());
     // the adaptive sampler's buffers lived in the old arena (a new arena may be allocated at the
     // old one's address, so the owner pointer alone does not tell)
@@ -710,13 +731,16 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     e |= W.alloc(samples * 4, &sc->d_accum);
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
     e |= W.alloc(rays, &sc->d_hits);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < sc->lrec_bufs; k++) {
       e |= W.alloc(rays, &sc->d_lrecs[k]);
       sc->d_lhair[k] = nullptr;
       if (sc->S.has_hair) e |= W.alloc(rays, &sc->d_lhair[k]);
     }
     // (rays queued once per candidate instance: room for twice the entries, or the light loop runs in many short launches)
-    sc->squeue_cap = std::min<size_t>(rays * (sc->split_shadow ? 16 : 8), sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
+    // (sized for the light loop's WORST case -- every (record, light) pair survives the cull -- where the memory is there: the bound decides
+    // into how many launches the light loop of a level is cut, and each cut is a host round trip: a rank's share of C3 took three)
+    const size_t per_ray = std::max<size_t>(sc->split_shadow ? 16 : 8, std::min<size_t>(64, (size_t) std::max(1, sc->n_light_samples) * (sc->split_shadow ? 2 : 1)));
+    sc->squeue_cap = std::min<size_t>(rays * per_ray, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
     e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
     // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
     // owns at least two queue entries
@@ -869,6 +893,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   bt = std::min<long>(bt, (long) ids.size());
   bt = std::min<long>(bt, (long) (((size_t) 1 << 31) / full_tile_samples));   // sample slots are 32-bit
   if (bt < 1) bt = 1;
+  // light loops beside the next levels' closest-hit walks (option overlap_shadow): on, or by the size of the batch
+  sc->overlap_now = !adaptive && sc->n_light_samples > 0 && (sc->overlap == 1 || (sc->overlap == 2 && deepest >= 1 && full_tile_samples * (size_t) bt <= FJ_OVERLAP_MAX_SAMPLES));
+  if (sc->overlap_now && enable_overlap(sc)) sc->overlap_now = false;
   sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
   if (sc->n_light_samples == 0) sc->squeue_max = (size_t) 4 << 20;
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
@@ -978,9 +1005,10 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // The light loop and the shadow traversal of level L are independent of the closest-hit
   // work of level L+1 (both consume what shading L produced), so they run on their own
   // stream and fill each other's tails; light records are double buffered between them.
-  hipStream_t sst = (sc->overlap && sc->shadow_stream) ? sc->shadow_stream : st;
+  hipStream_t sst = (sc->overlap_now && sc->shadow_stream) ? sc->shadow_stream : st;
   unsigned shade_seq = 0;
-  bool shadow_pending[2] = {false, false};
+  bool shadow_pending[FJ_LREC_BUFS] = {false, false, false, false};
+  const unsigned lrec_ring = (sst != st && sc->lrec_bufs >= FJ_LREC_BUFS) ? FJ_LREC_BUFS : 2;
   int rc = 0;
   hipEvent_t ev_all[2];
   HIP_TRY(hipEventCreate(&ev_all[0]));
@@ -1084,7 +1112,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         });
         if (e) return e;
         acc.trace_launches++; acc.closest_launches++;
-        const unsigned lb = shade_seq++ & 1u;          // light-record buffer of this shading call
+        const unsigned lb = shade_seq++ % lrec_ring;   // light-record buffer of this shading call
         if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
         shadow_pending[lb] = false;
         DScene Sl = S;
@@ -1127,7 +1155,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
             }
             acc.light_loop_launches++;
             e = timed(sst, &acc.light_loop_ms, [&]() {
-              return launch_shadow_cull(sst, Sl, swp, sc->d_lrecs[lb], b, b + can, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events);
+              return launch_shadow_cull(sst, Sl, swp, sc->d_lrecs[lb], b, b + can, sc->d_accum, sc->d_squeue, sc->d_cnt, (int) sc->count_events,
+                  sst != st ? FJ_OVERLAP_CULL_BLOCKS : 0);
             });
             if (e) return e;
             sq_bound += (uint64_t) can * nl_q + sq_pad;      // worst case: every pair survives, every wave leaves a padded chunk
@@ -1136,6 +1165,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
             b += can;
           }
           if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[lb], sst); shadow_pending[lb] = true; }
+          // overlap: the shadow rays of level 0 -- most of a frame's -- are walked NOW, on the shadow stream, while the main stream runs the
+          // deeper levels' closest-hit walks, which are a few long rays each (a launch of its own per level, latency bound): the big walk hides them
+          if (sst != st && level == 0 && can_emit && hc.next_count && sc->early_shadow) { e = flush_shadow(Sl); if (e) return e; }
         }
         if (hc.next_count) {
           if (!can_emit) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
@@ -1151,7 +1183,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
       const int fe = flush_shadow(Sf);
       if (fe) return fe;
       if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[0], sst); shadow_pending[0] = true; }
-      for (int k = 0; k < 2; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
+      for (int k = 0; k < FJ_LREC_BUFS; k++) if (shadow_pending[k] && sst != st) { (void) hipStreamWaitEvent(st, sc->ev_shadow_done[k], 0); shadow_pending[k] = false; }
       return 0;
     };
     if (!adaptive) {

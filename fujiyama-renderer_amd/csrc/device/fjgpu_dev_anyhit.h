@@ -97,10 +97,16 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   typedef __attribute__((address_space(3))) uint32_t ah_lds_u32;
   typedef __attribute__((address_space(3))) double ah_lds_f64;
   ah_lds_u32 *const ls_stack = (ah_lds_u32 *) s_stack;
-#define AH_LDS(depth) ls_stack[(depth) * BLOCK + AH_TID()]
-#define AH_OVF(depth) S.stack_overflow_shadow[(size_t) ((depth) - FJ_STACK_LDS_ANYHIT) * (gridDim.x * BLOCK) + (size_t) blockIdx.x * BLOCK + AH_TID()]
-  auto push = [&](int &sp_, uint32_t v) { if (sp_ < FJ_STACK_LDS_ANYHIT) AH_LDS(sp_) = v; else AH_OVF(sp_) = v; sp_++; };
-  auto pop = [&](int &sp_) -> uint32_t { --sp_; uint32_t v_; if (sp_ < FJ_STACK_LDS_ANYHIT) v_ = AH_LDS(sp_); else v_ = AH_OVF(sp_); return v_; };
+  // The stack pointer IS an LDS address: spa = the byte address of the lane's next free slot = stack base + (depth x BLOCK + thread) x 4.
+  // A push / pop is one LDS instruction with an immediate offset and one add; with depth and thread index kept apart every access rebuilt
+  // its address (two v_mbcnt, two shifts, an add3: a tenth of an inner step's instructions).  The thread's 4 x thread < 4 x BLOCK = one row:
+  // the stack is empty while spa lies in the first row, and beyond row FJ_STACK_LDS_ANYHIT the entries live in the global overflow area.
+  const uint32_t ah_base = (uint32_t) (uintptr_t) ls_stack;
+  const uint32_t ah_row1 = ah_base + BLOCK * 4u, ah_ovf0 = ah_base + (uint32_t) FJ_STACK_LDS_ANYHIT * BLOCK * 4u;
+#define AH_AT(addr) (*(ah_lds_u32 *) (uintptr_t) (addr))
+#define AH_OVF(addr) S.stack_overflow_shadow[(size_t) ((((addr) - ah_base) >> 10) - FJ_STACK_LDS_ANYHIT) * (gridDim.x * BLOCK) + (size_t) blockIdx.x * BLOCK + AH_TID()]
+  auto push = [&](uint32_t &spa_, uint32_t v) { if (spa_ < ah_ovf0) AH_AT(spa_) = v; else AH_OVF(spa_) = v; spa_ += BLOCK * 4u; };
+  auto pop = [&](uint32_t &spa_) -> uint32_t { spa_ -= BLOCK * 4u; uint32_t v_; if (spa_ < ah_ovf0) v_ = AH_AT(spa_); else v_ = AH_OVF(spa_); return v_; };
   bool head_live = true;                   // wave-uniform: the global head still has entries
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
   tune.grab = adaptive_grab(tune.grab, n);
@@ -123,7 +129,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   // rays reach the light: the order of the tests is free, nothing is wasted but the inner steps an
   // occluded ray takes before its postponed leaf is tested)
   uint32_t pleaf = TRAV_DONE;
-  int sp = 0;
+  uint32_t spa = ah_base;                  // (set to the lane's own column when a ray enters an instance)
   const double tmin = .0001;
 #ifdef FJ_PHASE_STATS
   unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -136,7 +142,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   for (;;) {
     PH(0, 1);
     FJ_TL_ITER(!head_live && next >= range_end);
-    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && spa >= ah_row1) { pleaf = cur; cur = pop(spa); }
     const bool fin = cur == TRAV_DONE && pleaf == TRAV_DONE;
     const bool at_inner = cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG);
     const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
@@ -250,7 +256,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           s32 = slab32q_setup(oo_, inv, A->qorigin, A->qcell);
           tmax32 = f32_above(tmax);
           node_base = A->node_base; tri_base = A->tri_base;
-          cur = A->root; sp = 0;
+          cur = A->root; spa = ah_base + AH_TID() * 4u;
           break;
         }
       }
@@ -268,7 +274,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         PH(3, 1); PH(4, n_now);
       } else { PH(3, 1); PH(4, n_inner); }
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
-      const bool deep = __ballot(in_now && sp + 3 > FJ_STACK_LDS_ANYHIT) != 0ull;
+      const bool deep = __ballot(in_now && spa + 3u * BLOCK * 4u > ah_ovf0) != 0ull;
       if (in_now) {
         // 64-byte quantised node: four 16-byte loads (12 words of (min, max) pairs + 4 child refs)
         const FJ_GLOBAL fj_v4u *nd = (const FJ_GLOBAL fj_v4u *) (S.blas_base + ((size_t) node_base << 7) + ((size_t) cur << 6));
@@ -294,22 +300,22 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         if (!h1) { r1 = r2; r2 = r3; }
         if (!h0) { r0 = r1; r1 = r2; r2 = r3; }
         const int nh = (int) h0 + (int) h1 + (int) h2 + (int) h3;
-        if (nh == 0) cur = (sp == 0) ? TRAV_DONE : pop(sp);
+        if (nh == 0) cur = (spa < ah_row1) ? TRAV_DONE : pop(spa);
         else {
           cur = r0;
           if (!deep) {
             // three unconditional stores (whatever lies above the new top is dead) instead of
             // three predicated ones
-            ah_lds_u32 *top = &AH_LDS(sp);
+            ah_lds_u32 *top = &AH_AT(spa);
             top[0] = r1; top[BLOCK] = r2; top[2 * BLOCK] = r3;
-            sp += nh - 1;
+            spa += (uint32_t) (nh - 1) * (BLOCK * 4u);
           } else {
-            if (nh > 1) push(sp, r1);
-            if (nh > 2) push(sp, r2);
-            if (nh > 3) push(sp, r3);
+            if (nh > 1) push(spa, r1);
+            if (nh > 2) push(spa, r2);
+            if (nh > 3) push(spa, r3);
           }
         }
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && sp > 0) { pleaf = cur; cur = pop(sp); }
+        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && spa >= ah_row1) { pleaf = cur; cur = pop(spa); }
       }
       }
     } else {
@@ -336,11 +342,11 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         }
         else if (from_p) pleaf = more ? (FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u)) : TRAV_DONE;
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
-        else cur = (sp == 0) ? TRAV_DONE : pop(sp);
+        else cur = (spa < ah_row1) ? TRAV_DONE : pop(spa);
       }
     }
   }
-#undef AH_LDS
+#undef AH_AT
 #undef AH_OVF
 #undef AH_TID
 #undef AH_RAY

@@ -62,7 +62,7 @@ int launch_shade(hipStream_t st, const DScene &S, const ShadeParams &sp, const D
 uint32_t shadow_queue_padding();
 void shadow_queue_reset(hipStream_t st, DCounters *cnt);
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
-    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events);
+    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events, int blocks_per_cu = 0);      // (0: what fits)
 int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeue, float *s_accum, DCounters *cnt, int count_events);
 // the quantised node array of the lean any-hit walk from the f32 one (same indices)
 int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const double *origin, const double *cell, DNodeQ *out);

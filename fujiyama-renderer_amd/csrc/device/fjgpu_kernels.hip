@@ -157,6 +157,10 @@ static unsigned persistent_grid(unsigned long long blocks_needed, int blocks_per
 
 size_t persistent_threads() { return (size_t) persistent_grid(~0ull, PERSIST_BLOCKS_PER_CU_MAX) * BLOCK; }
 
+// (experiment knobs: fewer resident blocks of the light loop / the closest-hit walk leave room for the other stream's kernels, option overlap_shadow)
+static int cull_blocks_per_cu(int asked) { static int b = -1; if (b < 0) { const char *e = getenv("FJGPU_CULL_BLOCKS"); b = e ? atoi(e) : 0; } return b > 0 ? b : (asked > 0 ? asked : PERSIST_BLOCKS_PER_CU); }
+static int closest_blocks_per_cu() { static int b = 0; if (!b) { const char *e = getenv("FJGPU_CLOSEST_BLOCKS"); b = e ? atoi(e) : PERSIST_BLOCKS_PER_CU; if (b < 1) b = 1; } return b; }
+
 // blocks per CU of the lean any-hit walk: what its registers and LDS stack allow
 static int anyhit_blocks_per_cu(bool multi)
 {
@@ -254,7 +258,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
   (void) hipMemsetAsync(&cnt->trace_xcd_head[0][0], 0, sizeof(cnt->trace_xcd_head), st);
   // scenes without curve sets run the lean instantiation (the ribbon test costs registers)
   // (the event counters cost registers and issue slots: counting is its own instantiation)
-  const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK));
+  const dim3 grid(persistent_grid((n + BLOCK - 1) / BLOCK, closest_blocks_per_cu()));
   TL_ZERO(st);
 #define FJ_LAUNCH_CLOSEST(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_trace_closest<CURVES, COUNT, MOTION>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune())
   if (S.has_motion) {      // time-sampled instance transforms: one general instantiation
@@ -316,19 +320,19 @@ void shadow_queue_reset(hipStream_t st, DCounters *cnt)
 }
 
 int launch_shadow_cull(hipStream_t st, const DScene &S, const ShadowParams &sp, const DLightRec *lrecs, uint32_t b, uint32_t e,
-    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
+    float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events, int blocks_per_cu)
 {
   if (e <= b) return 0;
   const unsigned long long threads = (unsigned long long) (e - b);       // one light record per lane
   (void) hipMemsetAsync(&cnt->cull_head, 0, sizeof(uint32_t), st);
-#define FJ_LAUNCH_CULL(HAIR, AREA, SPLIT) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA, SPLIT>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
+#define FJ_LAUNCH_CULL(HAIR, AREA, SPLIT) hipLaunchKernelGGL((k_shadow_cull<HAIR, AREA, SPLIT>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK, cull_blocks_per_cu(blocks_per_cu))), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events)
   // (SPLIT: rays into groups of several instances are queued once per candidate instance, DScene.shadow_join)
   const bool split = sp.join_capacity != 0 && S.shadow_join != nullptr;
   if (S.has_area) { if (split) FJ_LAUNCH_CULL(true, true, true); else FJ_LAUNCH_CULL(true, true, false); }          // general instantiation
   else if (S.has_hair) { if (split) FJ_LAUNCH_CULL(true, false, true); else FJ_LAUNCH_CULL(true, false, false); }
   else if (S.inst_lds && S.multi_shadow_groups && S.n_group_nodes <= FJ_CULL_LDS_NODES) {      // instance nodes in the blocks' LDS
-    if (split) hipLaunchKernelGGL((k_shadow_cull<false, false, true, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
-    else hipLaunchKernelGGL((k_shadow_cull<false, false, false, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    if (split) hipLaunchKernelGGL((k_shadow_cull<false, false, true, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK, cull_blocks_per_cu(blocks_per_cu))), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
+    else hipLaunchKernelGGL((k_shadow_cull<false, false, false, true>), dim3(persistent_grid((threads + BLOCK - 1) / BLOCK, cull_blocks_per_cu(blocks_per_cu))), dim3(BLOCK), 0, st, S, sp, lrecs, b, e, s_accum, squeue, cnt, count_events);
   }
   else { if (split) FJ_LAUNCH_CULL(false, false, true); else FJ_LAUNCH_CULL(false, false, false); }
 #undef FJ_LAUNCH_CULL

@@ -601,6 +601,32 @@ def test_whole_frame_c2_matches_oracle(asset_dir):
     assert float(rel_err(fb, ref).max()) <= REL_TOL
 
 
+def _whole_frame(text):
+    sp, rd = prepare(text)
+    gs = gpu.Scene(sp)
+    fb, st = gs.render_frame(rd)
+    gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    assert st.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(fb, ref).max()) <= REL_TOL
+
+
+def test_whole_frame_c3_matches_oracle(asset_dir):
+    """C3, the HEADLINE configuration (xyzrgb_dragon-class, 7.22 M triangles, 1920x1080, 64 spp, 32 lights), as a WHOLE frame against the
+    oracle on the host threads (~70 s of CPU on the GPU box): all 2040 tiles, 2.77 G rays -- ray counts per context equal, every pixel
+    within tolerance (execute_rendering, src/fj_renderer.cc:747-791)"""
+    _whole_frame(workloads.dragon(asset_dir))
+
+
+@pytest.mark.skipif(not os.environ.get("FJ_TEST_WHOLE_FRAMES"), reason="minutes of oracle time: set FJ_TEST_WHOLE_FRAMES=1 (scripts/full_frame_parity.py prints the table)")
+@pytest.mark.parametrize("builder", ["ibl", "cornell", "furry"])
+def test_whole_frame_other_configs_match_oracle(builder, asset_dir):
+    """C6 / C4 / C5 as whole frames (129 / 102 / 478 s of oracle time on 64 threads)"""
+    _whole_frame(workloads.BUILDERS[builder](asset_dir))
+
+
 def test_multi_device_frame_equals_single_device_frame(asset_dir):
     """fjgpu_render_frame_multi (the worker pool with GPUs for workers, src/fj_renderer.cc:747-791):
     two replicas -- on one device here -- deal the tiles k % 2, pack, peer-copy and scatter their
