@@ -43,10 +43,15 @@ __device__ __forceinline__ uint32_t opaque_lane_id()
 #else
 #define FJ_SCHED_FENCE() do { } while (0)
 #endif
-// tri_ray (fjgpu_dev_math.h) statement for statement, with scheduling fences between its steps:
-// left to itself the scheduler overlaps them and the leaf phase needs a dozen registers more than
-// the walk has
-__device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
+// TriRayIntersect (src/fj_triangle.cc:81-153, non-culling branch; tri_ray of fjgpu_dev_math.h) with scheduling fences between its steps:
+// left to itself the scheduler overlaps them and the leaf phase needs a dozen registers more than the walk has.
+// The same decision for rays that only ask WHETHER they hit (the any-hit walk: 7 of 8 rays hit nothing, and of the triangles tested
+// nearly all are missed): u = U / det and v = V / det are compared with 0 and 1, and most tests are settled by the SIGNS and the SIZES of
+// U, V and det -- without the division (a dozen instructions, one of them at a quarter of the rate).  Rejected early only where the
+// reference's own arithmetic provably rejects: u = U * fl(1 / det) < 0 when U and det differ in sign and the product cannot underflow
+// (|U| > 1e-100 |det|); u > 1 when |U| > |det| (1 + 1e-10) (fl(1 / det) and the product are each good to 2^-53); the same for v.
+// Whatever is left takes the reference's statements as they are.
+__device__ __forceinline__ bool tri_ray_anyhit(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double tmin, double tmax)
 {
   const V3 edge1 = v1 - v0;
   const V3 edge2 = v2 - v0;
@@ -55,19 +60,24 @@ __device__ __forceinline__ bool tri_ray_fenced(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   const double det = dot(edge1, pvec);
   FJ_SCHED_FENCE();
   if (det > -1e-6 && det < 1e-6) return false;
-  const double inv_det = 1.0 / det;
-  FJ_SCHED_FENCE();
+  const double adet = fabs(det);
   const V3 tvec = orig - v0;
-  const double uu = dot(tvec, pvec) * inv_det;
-  if (uu < 0.0 || uu > 1.0) return false;
+  const double U = dot(tvec, pvec);
+  const double aU = fabs(U);
+  if (((U < 0.0) != (det < 0.0)) ? aU > 1e-100 * adet : aU > adet * (1.0 + 1e-10)) return false;
   FJ_SCHED_FENCE();
   const V3 qvec = cross(tvec, edge1);
-  const double vv = dot(dir, qvec) * inv_det;
+  const double V = dot(dir, qvec);
+  const double aV = fabs(V);
+  if (((V < 0.0) != (det < 0.0)) ? aV > 1e-100 * adet : aV > adet * (1.0 + 1e-10)) return false;
+  FJ_SCHED_FENCE();
+  const double inv_det = 1.0 / det;
+  const double uu = U * inv_det;
+  if (uu < 0.0 || uu > 1.0) return false;
+  const double vv = V * inv_det;
   if (vv < 0.0 || uu + vv > 1.0) return false;
-  *t = dot(edge2, qvec) * inv_det;
-  *u = uu;
-  *v = vv;
-  return true;
+  const double t = dot(edge2, qvec) * inv_det;
+  return tmin <= t && t <= tmax;
 }
 
 #ifdef FJ_PHASE_STATS
@@ -118,8 +128,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   // the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
   ah_lds_f64 *const s_ray = (ah_lds_f64 *) (ls_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
 #define AH_RAY(k) s_ray[(k) * BLOCK + AH_TID()]
-  Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value is re-read from the queue entry by the triangle test)
+  Slab32P s32;                             // conservative slab constants of (ray, instance), in the packed fma's layout
+  s32.ix = s32.iy = s32.iz = 0.f; s32.lhx = s32.lhy = s32.lhz = (fj_v2f) (0.f);
+  float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value sits in LDS behind the ray, for the triangle test)
   const float tmin32 = 9.9999e-5f;         // <= .0001
   int gi = 0, gend = 0;                    // cursor in the group's instance BVH; gi < 0: ~instance, settled by the light loop
   uint32_t node_base = 0, tri_base = 0;    // DAnyInst: offsets from S.blas_base (triangles: f32 records, see fjgpu_api.hip)
@@ -244,7 +255,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (A->n_prims == 0) continue;
           const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
           if (has_negative_zero(od_)) continue;
-          AH_RAY(0) = oo_.x; AH_RAY(1) = oo_.y; AH_RAY(2) = oo_.z; AH_RAY(3) = od_.x; AH_RAY(4) = od_.y; AH_RAY(5) = od_.z;
+          { ah_lds_f64 *const wp_ = &s_ray[AH_TID()]; wp_[0] = oo_.x; wp_[BLOCK] = oo_.y; wp_[2 * BLOCK] = oo_.z; wp_[3 * BLOCK] = od_.x; wp_[4 * BLOCK] = od_.y; wp_[5 * BLOCK] = od_.z; wp_[6 * BLOCK] = tmax; }
           const V3 inv = mk(filter_rcp(od_.x), filter_rcp(od_.y), filter_rcp(od_.z));
           // the primitive set's own box: only where several instances are tried (a ray that misses
           // it finds no child box at the root either; in the single-instance walk the 12 registers
@@ -253,7 +264,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             double tn;
             if (!slab(A->bounds, A->bounds + 3, oo_, inv, tmin, tmax, &tn)) continue;
           }
-          s32 = slab32q_setup(oo_, inv, A->qorigin, A->qcell);
+          s32 = slab32p(slab32q_setup(oo_, inv, A->qorigin, A->qcell));
           tmax32 = f32_above(tmax);
           node_base = A->node_base; tri_base = A->tri_base;
           cur = A->root; spa = ah_base + AH_TID() * 4u;
@@ -284,7 +295,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #endif
         const fj_v4u w0 = nd[0], w1 = nd[1], w2 = nd[2], e = nd[3];
         // (one box after the other: interleaved by the scheduler, the four tests held 48 temporaries)
-        const uint32_t shx = slab32_shift(s32.x.i), shy = slab32_shift(s32.y.i), shz = slab32_shift(s32.z.i);
+        const uint32_t shx = slab32_shift(s32.ix), shy = slab32_shift(s32.iy), shz = slab32_shift(s32.iz);
         const bool h0 = slab32q_test(w0.x, w0.y, w0.z, s32, shx, shy, shz, tmin32, tmax32);
         FJ_SCHED_FENCE();
         const bool h1 = slab32q_test(w0.w, w1.x, w1.y, s32, shx, shy, shz, tmin32, tmax32);
@@ -326,13 +337,12 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const uint32_t lf = from_p ? pleaf : cur;
         const uint32_t first = (lf & 0x7fffffffu) >> 3;
         const uint32_t more = lf & 7u;
-        double t, u, v;
         if (kCount) lc->prims++;
-        const double tmax = squeue[idx].tmax;
         V3 v0, v1, v2;
         load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
         FJ_SCHED_FENCE();
-        if (tri_ray_fenced(v0, v1, v2, mk(AH_RAY(0), AH_RAY(1), AH_RAY(2)), mk(AH_RAY(3), AH_RAY(4), AH_RAY(5)), &t, &u, &v) && tmin <= t && t <= tmax) {
+        ah_lds_f64 *const rp_ = &s_ray[AH_TID()];       // (one address for the six loads: AH_RAY rebuilds the lane id every time)
+        if (tri_ray_anyhit(v0, v1, v2, mk(rp_[0], rp_[BLOCK], rp_[2 * BLOCK]), mk(rp_[3 * BLOCK], rp_[4 * BLOCK], rp_[5 * BLOCK]), tmin, rp_[6 * BLOCK])) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
           pleaf = TRAV_DONE;
 #ifdef FJ_WAVE_TIMELINE
@@ -377,7 +387,7 @@ template <bool kCount, bool kMulti>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
-  __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + 12 * BLOCK];     // (+ the rays: 6 doubles per thread)
+  __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + 14 * BLOCK];     // (+ the rays: 6 doubles per thread, and tmax)
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
   traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);

@@ -220,6 +220,26 @@ __device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t 
   if (tnear) *tnear = tn;
   return tn <= tf;
 }
+// the same with the slab constants held the way the packed fma wants them: (l, h) of an axis as ONE two-float value (a register pair: built
+// per test from two scalars it cost the any-hit walk ten moves per iteration), the slope as a scalar (broadcast by the instruction's op_sel)
+struct Slab32P { float ix, iy, iz; fj_v2f lhx, lhy, lhz; };
+__device__ __forceinline__ Slab32P slab32p(const Slab32 s)
+{
+  Slab32P p;
+  p.ix = s.x.i; p.iy = s.y.i; p.iz = s.z.i;
+  p.lhx.x = s.x.l; p.lhx.y = s.x.h; p.lhy.x = s.y.l; p.lhy.y = s.y.h; p.lhz.x = s.z.l; p.lhz.y = s.z.h;
+  return p;
+}
+__device__ __forceinline__ bool slab32q_test(uint32_t wx, uint32_t wy, uint32_t wz, const Slab32P s, uint32_t shx, uint32_t shy, uint32_t shz,
+    float tmin32, float tmax32)
+{
+  const fj_v2f tx = __builtin_elementwise_fma(slab32q_planes(wx, shx), (fj_v2f) (s.ix), s.lhx);
+  const fj_v2f ty = __builtin_elementwise_fma(slab32q_planes(wy, shy), (fj_v2f) (s.iy), s.lhy);
+  const fj_v2f tz = __builtin_elementwise_fma(slab32q_planes(wz, shz), (fj_v2f) (s.iz), s.lhz);
+  const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), tmin32);
+  const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax32);
+  return tn <= tf;
+}
 // f32 bounds of an f64 ray range: down / up to the neighbouring float
 __device__ __forceinline__ float f32_below(double x) { const float f = (float) x; return (double) f <= x ? f : nextafterf(f, -INFINITY); }
 __device__ __forceinline__ float f32_above(double x) { const float f = (float) x; return (double) f >= x ? f : nextafterf(f, INFINITY); }

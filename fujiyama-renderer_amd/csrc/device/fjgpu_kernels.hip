@@ -184,8 +184,9 @@ static TravTune trav_tune()
     // lean any-hit walk: up to `anyhit_steps` inner steps per iteration, the 2nd and later ones only
     // while at least `min_inner` lanes are at inner nodes (C3 -4.5 ms, C6 -30 ms; the general walk
     // keeps the fixed 3: incoherent rays (C4) and curve leaves (C5) lost 2-7 % with it)
-    t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 4);
-    t.min_inner = env("FJGPU_TRAV_MININNER", 24);
+    // (round 4, six waves and the cheaper step: 4 / 24 -> 8 / 16: C3 walk 58.1 -> 56.8 ms; 6 / 16 56.9, 6 / 12 57.3, 6 / 8 57.9, 4 / 32 59.2)
+    t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 8);
+    t.min_inner = env("FJGPU_TRAV_MININNER", 16);
     // the phase-scheduled closest-hit walk (incoherent rays): C4 closest-hit side 758 / 748 ms at 3 / 5 steps, 766 / 758 / 739 at
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
