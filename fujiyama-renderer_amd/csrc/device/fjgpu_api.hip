@@ -400,6 +400,26 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         DInstEntry &E = ie[k];
         std::memcpy(E.Minv, I.Minv, sizeof(E.Minv));
         std::memcpy(E.pbounds, I.pbounds, sizeof(E.pbounds));
+        // tight world box: the eight corners of the primitive set's padded box through M, widened by 1e-7 of its size (+ 1e-9): it must contain
+        // every point o + t d of a hit that the object-space test finds
+        for (int a = 0; a < 3; a++) { E.tbounds[a] = -INFINITY; E.tbounds[3 + a] = INFINITY; }
+        if (I.xform < 0 && I.pn_prims > 0) {
+          double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+          for (int c = 0; c < 8; c++) {
+            const double p[3] = {I.pbounds[(c & 1) ? 3 : 0], I.pbounds[(c & 2) ? 4 : 1], I.pbounds[(c & 4) ? 5 : 2]};
+            for (int a = 0; a < 3; a++) {
+              const double w = I.M[4 * a] * p[0] + I.M[4 * a + 1] * p[1] + I.M[4 * a + 2] * p[2] + I.M[4 * a + 3];
+              mn[a] = std::min(mn[a], w); mx[a] = std::max(mx[a], w);
+            }
+          }
+          bool finite = true;
+          for (int a = 0; a < 3; a++) finite = finite && std::isfinite(mn[a]) && std::isfinite(mx[a]);
+          if (finite)
+            for (int a = 0; a < 3; a++) {
+              const double pad = 1e-7 * (mx[a] - mn[a]) + 1e-7 * std::max(std::fabs(mn[a]), std::fabs(mx[a])) + 1e-9;
+              E.tbounds[a] = mn[a] - pad; E.tbounds[3 + a] = mx[a] + pad;
+            }
+        }
         for (int a = 0; a < 3; a++) { E.qorigin[a] = I.qorigin[a]; E.qcell[a] = I.qcell[a]; }
         const DPrimSet &P = dps[I.primset];
         const bool quantised = FJ_CLOSEST_QNODES && (!any_curves || FJ_CURVE_QNODES) && !any_motion;     // (the instantiations launch_trace_closest picks)

@@ -340,6 +340,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (kCount) lc->insts++;
         double tn;
         const double tfar = anyhit ? tmax : fmin(tmax, best.t);
+        // a tight box of the geometry first (pure culling, DInstEntry.tbounds): nothing of this instance can be hit nearer than tfar
+        if (!slab(I->tbounds, I->tbounds + 3, o, winv, tmin, tfar, &tn)) continue;
         // the reference's own (possibly non-enclosing) instance box, full ray range
         if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
         if (kMotion && I->xform >= 0) {
@@ -646,6 +648,8 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
           if (kCount) lc->insts++;
           double tn;
           const double tfar = anyhit ? tmax : fmin(tmax, best.t);
+          // a tight box of the geometry first (pure culling, DInstEntry.tbounds): nothing of this instance can be hit nearer than tfar
+          if (!slab(I->tbounds, I->tbounds + 3, o, winv, tmin, tfar, &tn)) continue;
           // the reference's own (possibly non-enclosing) instance box, full ray range
           if (!box_ray_ref_fast(single ? gsb : tn_->box, o, d, winv, plain, tmin, tmax)) continue;
           if (kMotion && I->xform >= 0) {

@@ -125,6 +125,11 @@ struct DInstance {
 // LDS instead of L1 / L2 round trips.
 struct DInstEntry {
   double Minv[12];             // world -> object (time 0; DInstance.xform >= 0: evaluated per ray instead)
+  double tbounds[6];           // a TIGHT world-space box of the instance's geometry (the image of pbounds under M, slightly widened; +-inf for
+                               // time-sampled transforms): pure culling, tested before anything else of the instance is computed.  The reference's
+                               // own instance box (DTNode.box, merge_sampled_bounds) is the bounding-sphere CUBE of a rotated object -- the walls
+                               // of a Cornell box each "contain" the whole room -- and decides results only where a ray misses it; a ray that
+                               // misses THIS box cannot hit the instance whatever that one says
   double pbounds[6];
   double qorigin[3], qcell[3];
   const void *nodes;           // the node array the scene's walks read: DNodeQ (meshes, scenes without curve sets and motion) or DNode
@@ -139,17 +144,17 @@ struct DInstEntry {
   int32_t primset;
   int32_t xform;
 };
-#define FJ_INST_LDS_ENTRY_WORDS 32      // sizeof(DInstEntry) / 8
+#define FJ_INST_LDS_ENTRY_WORDS 38      // sizeof(DInstEntry) / 8
 // budgets: DTNodes (56 B), DInstEntry records (256 B), DGroups (64 B)
 #define FJ_INST_LDS_NODES 39            // 8 072 bytes next to the 32 KB of stacks of a block: the phased walk still has 4 blocks per CU.  (The curve
                                         // instantiations have a budget of their own below; the motion kernels read global memory.)
-#define FJ_INST_LDS_INSTS 20
+#define FJ_INST_LDS_INSTS 16
 #define FJ_INST_LDS_GROUPS 12
 #define FJ_INST_LDS_NODES_BIG 79        // the walks with 3 blocks per CU (k_trace_closest, k_shadow_trace of mesh scenes): 16 200 bytes
-#define FJ_INST_LDS_INSTS_BIG 40
+#define FJ_INST_LDS_INSTS_BIG 33
 #define FJ_INST_LDS_GROUPS_BIG 24
 #define FJ_INST_LDS_NODES_CURVES 15     // the curve instantiations (3 blocks per CU, 20 KB of stacks + 28 KB of ray space per block): 3 656 bytes
-#define FJ_INST_LDS_INSTS_CURVES 8
+#define FJ_INST_LDS_INSTS_CURVES 6
 #define FJ_INST_LDS_GROUPS_CURVES 12
 #define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
