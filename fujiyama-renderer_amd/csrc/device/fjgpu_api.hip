@@ -97,6 +97,8 @@ struct fjgpu_scene {
   int lrec_bufs = 2;                  // buffers allocated: 2, or FJ_LREC_BUFS once the overlap option is on
   long overlap;                    // option "overlap_shadow": 0 off, 1 on, 2 by the batch size
   bool overlap_now = false;        // ... what this render call does
+  size_t free_cached = 0;          // free HBM + this scene's own work arena, as of the last query
+  hipEvent_t ev_frame[2] = {nullptr, nullptr};   // frame start / end
   long early_shadow = 0;           // with it: level 0's shadow rays are walked as soon as its light loop has run (FJGPU_EARLY_SHADOW)
   hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
   hipEvent_t ev_shadow_done[FJ_LREC_BUFS];    // shadow work reading d_lrecs[k] has finished
@@ -661,6 +663,7 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   if (getenv("FJGPU_PHASE_STATS")) debug_phase_stats();
   if (scene->shadow_stream) (void) hipStreamDestroy(scene->shadow_stream);
   for (hipEvent_t e : scene->ev_shadow_done) if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : scene->ev_frame) if (e) (void) hipEventDestroy(e);
   for (hipEvent_t e : scene->ev_pool) (void) hipEventDestroy(e);
   if (scene->d_frame) (void) hipFree(scene->d_frame);
   if (scene->d_slab) (void) hipFree(scene->d_slab);
@@ -891,9 +894,14 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // queues plus the shadow queue -- bounded by 40 % of the free HBM, unless told otherwise.
   // Measured on C3: 4 M samples per batch 473 ms/frame, 80 M 392 ms, whole frame 390 ms; later,
   // with a 196 ms frame: two batches 195.8 ms, one 192.9 ms.
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
-  const size_t free_now = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
+  // (asked once per arena: the query is a driver round trip, and a rank's share of a frame is 20 ms; an allocation that fails because
+  // somebody else took the memory meanwhile halves the batch below)
+  if (!sc->work || sc->free_cached == 0) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
+    sc->free_cached = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
+  }
+  const size_t free_now = sc->free_cached;
   // recursion levels this scene can reach: one queue per level, level = bounces so far, and a
   // bounce type only occurs if some shader of the scene emits it
   const int deepest = (sc->bounce_diffuse ? std::max(0, r->max_diffuse_depth) : 0) +
@@ -936,7 +944,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     (void) hipGetLastError();
     if (bt == 1) return fail(FJGPU_ENOMEM, "device allocation failed for the wavefront work buffers");
     // another process holds part of the HBM: half the batch (the old arena is released first)
-    sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0;
+    sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; sc->free_cached = 0;
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
     sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
     sc->sort_cap = 0;
@@ -1030,9 +1038,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   bool shadow_pending[FJ_LREC_BUFS] = {false, false, false, false};
   const unsigned lrec_ring = (sst != st && sc->lrec_bufs >= FJ_LREC_BUFS) ? FJ_LREC_BUFS : 2;
   int rc = 0;
-  hipEvent_t ev_all[2];
-  HIP_TRY(hipEventCreate(&ev_all[0]));
-  HIP_TRY(hipEventCreate(&ev_all[1]));
+  hipEvent_t *ev_all = sc->ev_frame;      // (created once per scene: two driver calls less per frame)
+  if (!ev_all[0]) { HIP_TRY(hipEventCreate(&ev_all[0])); HIP_TRY(hipEventCreate(&ev_all[1])); }
   (void) hipEventRecord(ev_all[0], st);
 
   for (size_t b0 = 0; b0 < ids.size() && rc == 0; b0 += (size_t) bt) {
@@ -1282,7 +1289,6 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     acc.closest_ms += acc.sort_ms;       // the sort is part of what the closest-hit side costs
     acc.trace_ms = acc.closest_ms + acc.light_loop_ms + acc.shadow_walk_ms;
   }
-  (void) hipEventDestroy(ev_all[0]); (void) hipEventDestroy(ev_all[1]);
   if (rc > 0 || rc == -1) return fail(FJGPU_ENODEV, std::string("HIP failure in the wavefront loop: ") + hipGetErrorString(hipGetLastError()));
   if (rc) return rc;
   if (se != hipSuccess) return fail(FJGPU_ENODEV, std::string("stream synchronize: ") + hipGetErrorString(se));

@@ -2,7 +2,7 @@
 # usage (GPU box): scripts/round_artifacts.sh r03   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
 # kernel statistics + PMC of the headline bench (dragon) and of the other BASELINE configurations, their bench lines,
 # every workload at full size, the N-rank code path on one GPU, and the whole-frame device-vs-oracle comparison.
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 cd $root
@@ -14,7 +14,7 @@ python bench.py --steps 20 --warmup 5 --rank-costs 8 > $out/${tag}_bench_dragon1
 python bench.py --workload furry --steps 3 --warmup 1 > $out/${tag}_bench_furry1080p.json 2> $out/${tag}_bench_furry.err
 python bench.py --workload cornell --steps 3 --warmup 1 > $out/${tag}_bench_cornell1080p.json 2> $out/${tag}_bench_cornell.err
 python bench.py --workload buddhas --steps 5 --warmup 2 > $out/${tag}_bench_buddhas720p.json 2> $out/${tag}_bench_buddhas.err
-python bench.py --dry-ranks 4 --steps 1 --warmup 1 > $out/${tag}_bench_dry_ranks4.json 2> $out/${tag}_bench_dry.err
+python bench.py --dry-ranks 8 --steps 1 --warmup 1 > $out/${tag}_bench_dry_ranks8.json 2> $out/${tag}_bench_dry.err
 bash scripts/all_workloads.sh > $out/${tag}_all_workloads.txt 2>&1
 for w in buddhas dragon cornell furry ibl; do
   echo "== $w" >> $out/${tag}_full_frame_parity.txt
