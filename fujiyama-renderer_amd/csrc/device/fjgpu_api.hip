@@ -194,6 +194,7 @@ static long g_device_tlas = 1;     // "device_tlas": the instance level of every
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
+static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
 static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
@@ -209,6 +210,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "tlas_verify") { g_tlas_verify = value != 0; return 0; }
   if (std::string(name) == "split_shadow") { g_split_shadow = value != 0; return 0; }
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
+  if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
@@ -428,7 +430,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         E.nodes = quantised ? (const void *) I.pqnodes : (const void *) I.pnodes;
         E.ptype = P.type; E.pad = 0;
         E.proot = I.proot; E.pn_prims = I.pn_prims; E.primset = I.primset; E.xform = I.xform;
-        E.tri_verts = P.tri_verts; E.tri_verts32 = P.tri_verts32; E.tri_vel = P.tri_vel; E.prim_ids = P.prim_ids;
+        E.tri_verts = P.tri_verts; E.tri_verts32 = P.type == FJ_PRIMSET_CURVE ? P.curve_capsule : P.tri_verts32; E.tri_vel = P.tri_vel; E.prim_ids = P.prim_ids;
       }
       e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
     }
@@ -503,6 +505,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     S.n_group_nodes = (int32_t) hs.group_nodes.size();
   }
   static_assert(sizeof(DInstEntry) == 8 * FJ_INST_LDS_ENTRY_WORDS && sizeof(DTNode) == 56 && sizeof(DGroup) == 64, "LDS copy of the instance level");
+  S.curve_anyhit = (g_curve_anyhit && !getenv("FJGPU_NO_CURVE_ANYHIT")) ? 1 : 0;
   S.inst_lds = (g_inst_lds && !getenv("FJGPU_NO_INST_LDS")) ? 1 : 0;         // (each launcher checks the scene against its kernel's budget)
   e |= M.upload(hs.shaders.data(), hs.shaders.size(), &S.shaders);
   e |= M.upload(hs.xforms.data(), hs.xforms.size(), &S.xforms);

@@ -9,6 +9,7 @@
 #include "fjgpu_build.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "fjgpu.h"
 
@@ -159,6 +160,8 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
   for (int s = 0; s < n; s++) {
     float *cap = &ps->curve_capsule[(size_t) s * 8];
     const int i0 = c.indices[ps->prim_ids[s]];
+    // (word 7: the curve's id, the bits of prim_ids[s] -- the walk learns from ONE record whether this piece belongs to the curve it tested last)
+    { const uint32_t cid = ps->prim_ids[s]; std::memcpy(&cap[7], &cid, sizeof(cid)); }
     if (c.velocity) { cap[6] = INFINITY; continue; }
     double b[12];
     for (int k = 0; k < 12; k++) b[k] = c.P[3 * i0 + k];
@@ -196,7 +199,6 @@ int BuildCurveSet(const fj_curve_desc &c, HostPrimSet *ps, std::string *err)
     }
     reach = reach * 1.000001 + slack + 1e-9 * scale + 1e-12;
     cap[6] = std::nextafter((float) reach, INFINITY);
-    cap[7] = 0.f;
   }
   ps->curve_cp.resize((size_t) n * 12);
   ps->curve_width.resize((size_t) n * 2);

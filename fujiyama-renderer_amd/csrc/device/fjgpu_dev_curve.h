@@ -160,6 +160,24 @@ __device__ __forceinline__ bool capsule_may_hit(const FJ_GLOBAL float *cap, V3 o
   return dot(q, q) <= reach * reach * 1.000001;
 }
 
+// the same test on a capsule record already in registers (two 16-byte loads: A xyz, B x | B yz, reach, the curve's id)
+__device__ __forceinline__ bool capsule_may_hit_v(fj_v4f c0, fj_v4f c1, V3 oo, V3 od)
+{
+  const double reach = (double) c1.z;
+  if (!(reach < 1e30)) return true;
+  const V3 A = mk((double) c0.x, (double) c0.y, (double) c0.z);
+  const V3 u = mk((double) c0.w - A.x, (double) c1.x - A.y, (double) c1.y - A.z);
+  const V3 w0 = A - oo;
+  const double a = dot(u, u), b = dot(u, od), c = dot(od, od), d = dot(u, w0), e = dot(od, w0);
+  const double D = a * c - b * b;
+  double sc = 0;
+  if (D > 1e-12 * a * c) { sc = (b * e - c * d) * filter_rcp(D); sc = sc < 0 ? 0 : (sc > 1 ? 1 : sc); }
+  const V3 S = w0 + sc * u;
+  const double tt = dot(S, od) * filter_rcp(c);
+  const V3 q = S - tt * od;
+  return dot(q, q) <= reach * reach * 1.000001;
+}
+
 // first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
 // (exactly the test curve_ray starts with: a curve rejected here is rejected there)
 __device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, const RaySpace &rsp)
@@ -169,6 +187,8 @@ __device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL doubl
   return !bz_misses_ray(root);
 }
 
+// kCache = false: no LDS behind rsp (the any-hit walk of curve scenes, fjgpu_dev_anyhit_curves.h): every leaf walk starts at the root
+template <bool kCache = true>
 __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, int depth, const RaySpace &rsp, double *t_out, double *v_out)
 {
   double ray_scale;
@@ -181,8 +201,8 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   // of from the root.  Same splits, same operands: only the repetition is gone.  (C5, level of
   // the cached node 1 / 2 / 3: 5.19 / 5.26 / 5.46 s per frame, 5.41 s without.)
   const int CL = FJ_CURVE_CACHE_LEVEL;
-  const bool use_cache = CL > 0 && depth > CL;
-  double *cache = rsp.lds + FJ_FRAME_DOUBLES * BLOCK;
+  const bool use_cache = kCache && CL > 0 && depth > CL;
+  double *cache = kCache ? rsp.lds + FJ_FRAME_DOUBLES * BLOCK : nullptr;
   uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
   while (j < nleaf) {

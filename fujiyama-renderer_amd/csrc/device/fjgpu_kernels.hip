@@ -13,6 +13,7 @@
 //                         attribute setup + the shader plugins; light records and child rays)
 //   fjgpu_dev_shadow.h    k_shadow_cull (SlIlluminance light loop), k_shadow_trace
 //   fjgpu_dev_anyhit.h    k_shadow_anyhit (lean any-hit walk: phase-scheduled, f32 slabs)
+//   fjgpu_dev_anyhit_curves.h  k_shadow_anyhit_curves (the same scheduling for scenes with curve sets: + a ribbon phase)
 //   here                  k_resolve (reconstruct_image / apply_pixel_filter), host launchers
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -33,6 +34,7 @@
 #include "fjgpu_dev_shade.h"
 #include "fjgpu_dev_shadow.h"
 #include "fjgpu_dev_anyhit.h"
+#include "fjgpu_dev_anyhit_curves.h"
 #include "fjgpu_dev_adaptive.h"
 
 // ------------------------------------------------------------------ k_resolve
@@ -171,9 +173,16 @@ static int anyhit_blocks_per_cu(bool multi)
   return b;
 }
 
+static int canyhit_blocks_per_cu()
+{
+  int b = FJ_CANYHIT_MINB;
+  if (const char *e = getenv("FJGPU_CANYHIT_BLOCKS")) b = atoi(e);
+  return b < 1 ? 1 : (b > PERSIST_BLOCKS_PER_CU_MAX ? PERSIST_BLOCKS_PER_CU_MAX : b);
+}
+
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -191,6 +200,11 @@ static TravTune trav_tune()
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
     t.min_inner_phased = env("FJGPU_TRAV_MININNER_PHASED", 12);
+    // the any-hit walk of curve scenes (fjgpu_dev_anyhit_curves.h)
+    t.refill_canyhit = env("FJGPU_TRAV_REFILL_CANYHIT", 20);     // (C5 walk, refill / leaf_wait: 32 / 40 1252 ms, 24 / 48 1147, 16 / 48 1140, 20 / 56 1130, 12 / 52 1134)
+    t.steps_canyhit = env("FJGPU_TRAV_STEPS_CANYHIT", 8);
+    t.min_inner_canyhit = env("FJGPU_TRAV_MININNER_CANYHIT", 16);
+    t.leaf_wait_canyhit = env("FJGPU_TRAV_LEAFWAIT_CANYHIT", 56);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
     if (t.refill > 64) t.refill = 64;
@@ -354,7 +368,12 @@ int launch_shadow_trace(hipStream_t st, const DScene &S, const DShadowRay *squeu
 #define FJ_LAUNCH_SHADOW(CURVES, COUNT, MOTION) hipLaunchKernelGGL((k_shadow_trace<CURVES, COUNT, MOTION>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune())
     if (S.has_motion) { if (count_events) FJ_LAUNCH_SHADOW(true, true, true); else FJ_LAUNCH_SHADOW(true, false, true); }
     else if (S.has_curves) {
-      if (InstLdsCurves::fits(S) && S.all_opaque) {      // ... and no hit records: every ray any-hit, an occluded one adds nothing
+      if (InstLdsCurves::fits(S) && S.all_opaque && S.curve_anyhit && FJ_CURVE_QNODES && FJ_CLOSEST_QNODES) {      // the phase-scheduled any-hit walk with a ribbon phase
+        const dim3 cgrid(persistent_grid(1ull << 30, canyhit_blocks_per_cu()));
+        if (count_events) hipLaunchKernelGGL((k_shadow_anyhit_curves<true>), cgrid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+        else hipLaunchKernelGGL((k_shadow_anyhit_curves<false>), cgrid, dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
+      }
+      else if (InstLdsCurves::fits(S) && S.all_opaque) {      // ... and no hit records: every ray any-hit, an occluded one adds nothing
         if (count_events) hipLaunchKernelGGL((k_shadow_trace<true, true, false, true, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
         else hipLaunchKernelGGL((k_shadow_trace<true, false, false, true, true>), dim3(persistent_grid(1ull << 30)), dim3(BLOCK), 0, st, S, squeue, s_accum, cnt, trav_tune());
       }
@@ -408,6 +427,18 @@ void debug_phase_stats()
       fprintf(stderr, "fjgpu phase curves: second-stage execs %llu lanes %llu tests-hit %llu leaf-walks %llu nodes %llu\n", c[2], c[3], c[4], c[0], c[1]);
       unsigned long long z[8] = {0};
       (void) hipMemcpyToSymbol(HIP_SYMBOL(g_curve_stat), z, sizeof(z));
+    }
+  }
+  {
+    unsigned long long c[16];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cphase), sizeof(c)) == hipSuccess && c[12]) {
+      static const char *pn[4] = {"turnover", "inner", "leaf", "ribbon"};
+      const double all = (double) (c[0] + c[1] + c[2] + c[3]);
+      fprintf(stderr, "fjgpu phase curve-anyhit: %llu iterations", c[12]);
+      for (int k = 0; k < 4; k++) fprintf(stderr, " | %s %.1f %% of ticks, %llu execs, %.1f lanes, %.0f ticks each", pn[k], 100. * c[k] / all, c[4 + k], (double) c[8 + k] / (c[4 + k] ? c[4 + k] : 1), (double) c[k] / (c[4 + k] ? c[4 + k] : 1));
+      fprintf(stderr, "\n");
+      unsigned long long z[16] = {0};
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_cphase), z, sizeof(z));
     }
   }
   unsigned long long h[16];

@@ -82,7 +82,7 @@ struct DPrimSet {
   const double *curve_width;   // [n_curves][2]  end widths (BLAS order)
   const float *curve_Cd;       // [n_curves][6]  end colours (BLAS order)
   const int8_t *curve_depth;   // [n_curves]     cached split depth (BLAS order)
-  const float *curve_capsule;  // [n_curves][8]  A xyz, B xyz, reach, pad: the PIECE of the curve a BLAS slot stands for lies
+  const float *curve_capsule;  // [n_curves][8]  A xyz, B xyz, reach, the bits of prim_ids[slot]: the PIECE of the curve a BLAS slot stands for lies
                                //                within `reach` (ribbon radius included) of the segment AB; or null
   const double *curve_vel;     // [n_curves][12] control-point velocities (BLAS order) or null: Curve::ray_intersect
                                //                moves each control point by time * velocity
@@ -134,7 +134,7 @@ struct DInstEntry {
   double qorigin[3], qcell[3];
   const void *nodes;           // the node array the scene's walks read: DNodeQ (meshes, scenes without curve sets and motion) or DNode
   const double *tri_verts;     // the primitive set's leaf-order arrays (DPrimSet): the leaf phase reads them through this record
-  const float *tri_verts32;
+  const float *tri_verts32;    // (curve sets: DPrimSet.curve_capsule -- they have no triangles; k_shadow_anyhit_curves reads the capsules through this record)
   const double *tri_vel;
   const uint32_t *prim_ids;
   int32_t ptype;               // FJ_PRIMSET_*
@@ -255,7 +255,7 @@ struct DScene {
   int32_t has_hair;            // any HairShader: selects the light-loop instantiation with its illuminance term
   int32_t has_curves;          // any curve primset: selects the traversal instantiation with the ribbon test
   int32_t target_group;
-  int32_t pad_wide_;
+  int32_t curve_anyhit;        // option "curve_anyhit": shadow rays of curve scenes whose occluders are all opaque run k_shadow_anyhit_curves (else the general walk)
   int32_t incoherent_rays;     // some shader emits two children per hit or diffuse bounces (glass, pathtracing): the
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
   const double *cam_uv;        // implicit camera rays: the (u, v) table of the batch's samples (sample slot = ray index of

@@ -435,9 +435,13 @@ def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
     # of the ray alone: a lane sets a leaf aside and walks on while its wave runs inner steps (FJ_ANYHIT_POSTPONE), so an
     # occluded ray visits a few nodes more or less depending on which rays the light loop's atomics queued next to it
     # (measured on the box: 75 of 412 663 between two runs) -- same order of magnitude is all that can be asserted.
-    assert st1.insts_tested == st0.insts_tested
-    assert abs(st1.nodes_visited - st0.nodes_visited) <= 0.01 * st0.nodes_visited
-    assert abs(st1.prims_tested - st0.prims_tested) <= 0.01 * st0.prims_tested
+    # (curve scenes: with the instance level in LDS the shadow rays run k_shadow_anyhit_curves, without it the general walk -- other visiting
+    # order (no distance sort), postponed leaves, another moment at which an occluded ray learns it: the same results from other event counts)
+    tol = 0.10 if builder == "furry" else 0.01
+    if builder != "furry":
+        assert st1.insts_tested == st0.insts_tested
+    assert abs(st1.nodes_visited - st0.nodes_visited) <= tol * st0.nodes_visited
+    assert abs(st1.prims_tested - st0.prims_tested) <= tol * st0.prims_tested
     assert float(rel_err(fb1, fb0).max()) <= 1e-5
 
 
