@@ -39,7 +39,7 @@ for spec in sys.argv[2:]:
             m["shade"], m["gen"], m["resolve"], c["nodes"], c["prims"], c["shadow_traversed"])
     except Exception as e:  # noqa: BLE001
         line += "  (no json: %s) %s" % (e, p.stderr.strip().splitlines()[-1:] )
-    ph = [l for l in p.stderr.splitlines() if l.startswith("fjgpu phase")]
+    ph = [l for l in p.stderr.splitlines() if l.startswith(("fjgpu phase", "fjgpu curve"))][-12:]
     if ph:
         line += "\n    " + "\n    ".join(ph)
     print(line, flush=True)
