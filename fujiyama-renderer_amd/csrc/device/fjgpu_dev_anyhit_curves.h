@@ -29,6 +29,11 @@
 #ifndef FJ_CANYHIT_MINB
 #define FJ_CANYHIT_MINB 4
 #endif
+// Measured and dropped (profiles/r04_curve_anyhit_walk.txt): the ribbon tests split off into a kernel of their own (the walk at 6 waves queues
+// (ray, curve) pairs: without the early end of an occluded ray 7.1 G pairs instead of 1.8 G tests, walk + ribbon kernel 2240 ms against 1130);
+// a ray visiting the MESH instances of its group before the curve sets (1074 -> 1161 ms: the rays through the fur are not the ones the body
+// occludes); sweeps cut into parts of <= 4 / 8 / 12 leaf walks per ribbon phase (1465 / 1176 / 1162 ms against 1074: the root is rebuilt per part and
+// the sweeps are not long enough to pay for it); 3 waves without a spill (1417 against 1319 at 4); pieces per curve and SAH costs (no change).
 #ifndef FJ_CANYHIT_POSTPONE
 #define FJ_CANYHIT_POSTPONE 1
 #endif
