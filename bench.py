@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--mesh", default=None, help="mesh class override (smaller = quicker; not a valid headline run)")
     ap.add_argument("--res", type=int, nargs=2, default=None)
     ap.add_argument("--spp", type=int, nargs=2, default=None)
+    ap.add_argument("--lights", type=int, default=0, help="number of point lights (experiments; not a valid headline run)")
     ap.add_argument("--cpu-tiles", type=int, default=-1,
                     help="tiles in the CPU-baseline sample (-1: two per host core so every core stays busy; 0 disables)")
     ap.add_argument("--cpu-port-frame", action="store_true",
@@ -317,6 +318,8 @@ def main():
         kw["res"] = tuple(args.res)
     if args.spp:
         kw["spp"] = tuple(args.spp)
+    if args.lights:
+        kw["nlights"] = args.lights
     builder = workloads.BUILDERS[args.workload]
     asset_dir = workloads.default_asset_dir()
     if world > 1:

@@ -208,7 +208,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   double *cache = kCache ? rsp.lds + FJ_FRAME_DOUBLES * BLOCK : nullptr;
   uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
-  // (kCache = false) levels 0..passed of the walk towards j are known to pass their bounds test: the ancestors a leaf walk shares with the one
+  // levels 0..passed of the walk towards j are known to pass their bounds test: the ancestors a leaf walk shares with the one
   // before it passed THERE -- a failed test skips the whole span below it, so the next walk starts beyond that span.  Same splits, same
   // operands; only the repetition of a test whose outcome is known is gone (FJ_CURVE_SKIP_PASSED: C5 any-hit walk 1130 -> 1074 ms).
   int passed = -1;
@@ -233,7 +233,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
     for (int L = L0;; L++) {
       FJ_CURVE_STAT(1, 1);                  // nodes visited (inner iterations)
       // (a node taken from the cache passed this test when it was stored)
-      if (!(L0 == CL && L == CL && use_cache) && !(!kCache && FJ_CURVE_SKIP_PASSED && L <= passed) && bz_misses_ray(b)) {
+      if (!(L0 == CL && L == CL && use_cache) && !(FJ_CURVE_SKIP_PASSED && L <= passed) && bz_misses_ray(b)) {
         const uint32_t span = 1u << (depth - L);
         j = ((j / span) + 1) * span;
         pruned = true;
@@ -269,7 +269,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
         cached = pre;
       }
     }
-    if (!kCache && FJ_CURVE_SKIP_PASSED) passed = depth - 32 + (int) __clz((int) (j_before ^ (pruned ? j : j + 1u)));     // common leading bits of the two leaf indices
+    if (FJ_CURVE_SKIP_PASSED) passed = depth - 32 + (int) __clz((int) (j_before ^ (pruned ? j : j + 1u)));     // common leading bits of the two leaf indices
     if (pruned) continue;
     j++;
     // depth == 0 block of converge_bezier3

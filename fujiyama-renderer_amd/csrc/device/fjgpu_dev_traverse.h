@@ -21,6 +21,9 @@
 // order (ObjectInstance::RayIntersect, src/fj_object_instance.cc:213-243: the ray
 // goes to object space with M^-1 and dir is NOT renormalised, so t is preserved).
 #define TRAV_DONE 0xffffffffu
+#ifndef FJ_TINY_PRIMS
+#define FJ_TINY_PRIMS 4           // primitive sets of at most this many triangles are tested in the instance loop of the phase-scheduled walk (0: walked like any other)
+#endif
 // tunables (defaults measured on C3; overridable with FJGPU_TRAV_{REFILL,STEPS,GRAB})
 #ifdef FJ_PHASE_STATS
 // debug builds only: wave-level phase executions / tail lengths (printed by debug_phase_stats)
@@ -662,9 +665,30 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
             od = xvector(I->Minv, d);
           }
           if (has_negative_zero(od)) continue;
+          if (I->pn_prims == 0) continue;
+          if (FJ_TINY_PRIMS > 0 && !kMotion && I->pn_prims <= FJ_TINY_PRIMS) {
+            // a handful of triangles (the walls of a box): tested HERE, one after the other, instead of being walked -- the walk of such a set is one
+            // root node whose child boxes cull nothing the instance boxes have not culled, and costs the slab set-up, an inner step, a leaf
+            // execution per triangle and a turnover more.  Same tests in leaf order, same tie rules; node boxes only ever rejected provable misses.
+            bool stop = false;
+            for (int k = 0; k < I->pn_prims; k++) {
+              double t, u = 0, v = 0;
+              if (kCount) lc->prims++;
+              V3 v0, v1, v2;
+              load_tri(I->tri_verts, I->tri_verts32, (uint32_t) k, &v0, &v1, &v2);
+              if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+                const int pid = (int) FJ_G(uint32_t, I->prim_ids)[k];
+                if (t < best.t || (t == best.t && best.inst == ii && pid > best.prim)) {
+                  best.t = t; best.u = u; best.v = v; best.inst = ii; best.prim = pid;
+                  if (anyhit) { stop = true; break; }
+                }
+              }
+            }
+            if (stop) break;               // (an any-hit ray ends here: retired below with its hit)
+            continue;
+          }
           const V3 inv = mk(filter_rcp(od.x), filter_rcp(od.y), filter_rcp(od.z));
           nodes = (const DNode *) I->nodes;
-          if (I->pn_prims == 0) continue;
           if (!slab(I->pbounds, I->pbounds + 3, oo, inv, tmin, tfar, &tn)) continue;
           if (FJ_CLOSEST_QNODES) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
           else s32 = slab32_setup(oo, inv, I->pbounds);
