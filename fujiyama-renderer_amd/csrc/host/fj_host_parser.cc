@@ -285,6 +285,19 @@ int fj_scene_last_stats(fj_render_stats *out)
   return 0;
 }
 
+// SiGetPropertyList for C callers: the table is opaque there, its entries are read through accessors
+const void *fj_SiGetPropertyList(const char *type_name) { return (const void *) SiGetPropertyList(type_name); }
+int fj_property_is_valid(const void *table, int k) { return (table && k >= 0 && ((const Property *) table)[k].IsValid()) ? 1 : 0; }
+const char *fj_property_name(const void *table, int k) { return fj_property_is_valid(table, k) ? ((const Property *) table)[k].GetName() : nullptr; }
+const char *fj_property_type_string(const void *table, int k) { return fj_property_is_valid(table, k) ? ((const Property *) table)[k].GetTypeString() : nullptr; }
+int fj_property_default(const void *table, int k, double out4[4])
+{
+  if (!fj_property_is_valid(table, k) || !out4) return -1;
+  const Vector4 &d = ((const Property *) table)[k].GetDefaultValue();
+  out4[0] = d.x; out4[1] = d.y; out4[2] = d.z; out4[3] = d.w;
+  return 0;
+}
+
 // ---- 1:1 C spellings of the Si* functions
 int  fj_SiGetErrorNo(void) { return SiGetErrorNo(); }
 long fj_SiOpenPlugin(const char *f) { return SiOpenPlugin(f); }

@@ -606,6 +606,8 @@ static const struct KnownPlugin { const char *name; PluginKind kind; int shader;
   {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0},
 };
 
+static std::string table_mismatch(const std::string &plugin_name, const Property *theirs);
+
 ID SiOpenPlugin(const char *filename)
 {
   Scene *sc = get_scene();
@@ -616,6 +618,15 @@ ID SiOpenPlugin(const char *filename)
     const std::string name(lp->info.plugin_name), type(lp->info.plugin_type);
     for (const auto &k : kKnownPlugins)
       if (name == k.name && type == (k.kind == PLUGIN_SHADER ? "Shader" : "Procedure")) {
+        const std::string diff = k.kind == PLUGIN_SHADER ? table_mismatch(name, lp->info.property_list) : std::string();
+        if (!diff.empty()) {
+          ClosePluginDso(lp.get());
+          g_last_error = "plugin '" + name + "' (" + filename + ") is not the shader the device code of that name implements: " + diff +
+              " -- refused (a shader DSO is rendered by the device twin of its plugin_name, never by its own evaluate())";
+          std::fprintf(stderr, "libfjscene: %s\n", g_last_error.c_str());
+          set_errno(SI_ERR_FAILLOAD);
+          return SI_BADID;
+        }
         Plugin *p = new Plugin();
         p->name = k.name; p->kind = k.kind; p->shader_type = k.shader;
         p->loaded = std::move(lp);
@@ -1023,7 +1034,8 @@ const Property *make_table(const PropRow *rows, std::vector<Property> *keep)
 }
 }  // namespace
 
-const Property *SiGetPropertyList(const char *type_name)
+// the table this build carries for a built-in type or a plugin with a device implementation (null: none of that name); *is_plugin: the latter
+static const Property *builtin_table(const std::string &n, bool *is_plugin)
 {
   static const PropRow renderer_props[] = {
     {"sample_jitter", 1, {1}}, {"cast_shadow", 1, {1}}, {"max_diffuse_depth", 1, {3}}, {"max_reflect_depth", 1, {3}},
@@ -1063,23 +1075,51 @@ const Property *SiGetPropertyList(const char *type_name)
     {"PlasticShader", plastic_props}, {"ConstantShader", constant_props}, {"GlassShader", glass_props},
     {"HairShader", hair_props}, {"PathtracingShader", pathtracing_props}};
   static std::vector<Property> tables[sizeof(builtin) / sizeof(builtin[0])];
+  for (size_t i = 0; i < sizeof(builtin) / sizeof(builtin[0]); i++)
+    if (n == builtin[i].type) {
+      if (is_plugin) *is_plugin = i >= 4;
+      if (tables[i].empty()) { tables[i].reserve(32); make_table(builtin[i].rows, &tables[i]); }
+      return tables[i].data();
+    }
+  return nullptr;
+}
+
+// A shader DSO runs as the DEVICE code of its plugin_name, never as its own evaluate(): one whose property table is not the stock
+// shader's (a modified shader that kept the name) would render as the stock one, silently.  "" if the tables agree, else what differs.
+static std::string table_mismatch(const std::string &plugin_name, const Property *theirs)
+{
+  const Property *ours = builtin_table(plugin_name, nullptr);
+  if (!ours) return "";                      // (procedures: no table of ours to compare with)
+  if (!theirs) return "no property table";
+  for (;; ours++, theirs++) {
+    if (!ours->IsValid() || !theirs->IsValid()) {
+      if (ours->IsValid()) return std::string("property '") + ours->GetName() + "' is missing";
+      if (theirs->IsValid()) return std::string("extra property '") + theirs->GetName() + "'";
+      return "";
+    }
+    if (std::strcmp(ours->GetName(), theirs->GetName()) != 0) return std::string("property '") + theirs->GetName() + "' where '" + ours->GetName() + "' is expected";
+    if (ours->GetType() != theirs->GetType()) return std::string("property '") + ours->GetName() + "' has another type";
+    const Vector4 &a = ours->GetDefaultValue(), &b = theirs->GetDefaultValue();
+    if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) return std::string("property '") + ours->GetName() + "' has another default";
+  }
+}
+
+const Property *SiGetPropertyList(const char *type_name)
+{
   if (!type_name) return nullptr;
   const std::string n(type_name);
   // an opened plugin DSO speaks for itself
   if (Scene *sc = get_scene())
     for (const auto &p : sc->plugins)
       if (p->loaded && n == p->loaded->info.plugin_name) return p->loaded->info.property_list;
-  for (size_t i = 0; i < sizeof(builtin) / sizeof(builtin[0]); i++)
-    if (n == builtin[i].type) {
-      if (i >= 4) {      // a plugin's table exists once the plugin is opened (reference: get_property_list)
-        bool opened = false;
-        if (Scene *sc = get_scene()) for (const auto &p : sc->plugins) if (p->name == n) opened = true;
-        if (!opened) return nullptr;
-      }
-      if (tables[i].empty()) { tables[i].reserve(32); make_table(builtin[i].rows, &tables[i]); }
-      return tables[i].data();
-    }
-  return nullptr;
+  bool is_plugin = false;
+  const Property *t = builtin_table(n, &is_plugin);
+  if (t && is_plugin) {      // a plugin's table exists once the plugin is opened (reference: get_property_list)
+    bool opened = false;
+    if (Scene *sc = get_scene()) for (const auto &p : sc->plugins) if (p->name == n) opened = true;
+    if (!opened) return nullptr;
+  }
+  return t;
 }
 
 Status SiSetFrameReportCallback(ID id, void *data, FrameStartCallback frame_start, FrameAbortCallback frame_abort, FrameDoneCallback frame_done)

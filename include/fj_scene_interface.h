@@ -206,6 +206,13 @@ int  fj_SiSetProperty3(long id, const char *name, double v0, double v1, double v
 int  fj_SiSetProperty4(long id, const char *name, double v0, double v1, double v2, double v3);
 int  fj_SiSetStringProperty(long id, const char *name, const char *string);
 int  fj_SiSetSampleProperty3(long id, const char *name, double v0, double v1, double v2, double time);
+/* SiGetPropertyList (reference src/fj_scene_interface.h:116): the table as an opaque pointer, NULL for an unknown name; C has no Property
+ * class, so entry k (0, 1, ... up to the first invalid one, the table's terminator) is read through the accessors */
+const void *fj_SiGetPropertyList(const char *type_name);
+int  fj_property_is_valid(const void *table, int k);             /* 0: the terminator */
+const char *fj_property_name(const void *table, int k);
+const char *fj_property_type_string(const void *table, int k);   /* Property::GetTypeString */
+int  fj_property_default(const void *table, int k, double out4[4]);    /* Property::GetDefaultValue: 0 or -1 */
 /* callbacks: (void *data, const FrameInfo * / const TileInfo *) -> CALLBACK_CONTINUE (0) or
  * CALLBACK_INTERRUPT (-1); layouts of src/fj_callback.h:15-98; NULL = no hook */
 typedef int (*fj_frame_callback)(void *data, const void *frame_info);

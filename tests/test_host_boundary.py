@@ -36,7 +36,7 @@ def test_libfjgpu_exports_every_declared_symbol():
 
 def test_libfjscene_exports_c_and_cxx_api():
     names = _declared("fj_scene_interface.h", "fj_")
-    assert len([n for n in names if n.startswith("fj_Si")]) == 40
+    assert len([n for n in names if n.startswith("fj_Si")]) == 41       # every one of the 41 Si functions has its C twin
     exp = _exported("libfjscene.so")
     assert [n for n in names if n not in exp] == []
     # the C++ spelling (namespace fj, Itanium mangling) of the 41-function interface
@@ -281,6 +281,31 @@ def test_reference_shader_sources_load_as_plugins_through_the_dso_abi(tmp_path):
                     str(tmp_path / "other.cc")], check=True)
     assert L.fj_SiOpenPlugin(other.encode()) == -1
     assert "no device implementation" in host.lib().fj_scene_last_error().decode()
+    # ... and one that KEEPS a known plugin_name but is not that shader (another property table): refused, not rendered as the stock one
+    src = open("%s/constant_shader/constant_shader.cc" % REF_SHADERS).read()
+    assert '"texture"' in src and '"ConstantShader"' in src
+    (tmp_path / "modified.cc").write_text(src.replace('"texture"', '"my_texture"'))
+    modified = str(tmp_path / "modified.so")
+    subprocess.run(["g++", "-std=c++11", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include"), "-o", modified,
+                    str(tmp_path / "modified.cc")], check=True)
+    assert L.fj_SiOpenPlugin(modified.encode()) == -1
+    assert "is not the shader the device code of that name implements" in host.lib().fj_scene_last_error().decode()
+    # the C spelling of SiGetPropertyList: an opaque table read through accessors, the same rows as the text form
+    L.fj_SiGetPropertyList.restype = C.c_void_p
+    L.fj_SiGetPropertyList.argtypes = [C.c_char_p]
+    for fn, rt in (("fj_property_name", C.c_char_p), ("fj_property_type_string", C.c_char_p), ("fj_property_is_valid", C.c_int), ("fj_property_default", C.c_int)):
+        getattr(L, fn).restype = rt
+    L.fj_property_name.argtypes = L.fj_property_type_string.argtypes = L.fj_property_is_valid.argtypes = [C.c_void_p, C.c_int]
+    L.fj_property_default.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    assert L.fj_SiGetPropertyList(b"NoSuchType") is None
+    tab = L.fj_SiGetPropertyList(b"Renderer")
+    rows, k = [], 0
+    while L.fj_property_is_valid(tab, k):
+        d = (C.c_double * 4)()
+        assert L.fj_property_default(tab, k, d) == 0
+        rows.append("%s %s %.17g %.17g %.17g %.17g" % (L.fj_property_type_string(tab, k).decode(), L.fj_property_name(tab, k).decode(), d[0], d[1], d[2], d[3]))
+        k += 1
+    assert rows == table("Renderer") and len(rows) == 16 and L.fj_property_name(tab, k) is None
     L.fj_SiCloseScene()
 
 
