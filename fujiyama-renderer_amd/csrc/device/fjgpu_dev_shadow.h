@@ -203,7 +203,11 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
             const float roughness = .05f;
             const float TI = (float) dot(tangent, Iv);
             float spec = (float) (sqrt((double) (1 - TL * TL)) * sqrt((double) (1 - TI * TI)) + (double) (TL * TI));
-            spec = (float) pow((double) spec, (double) (1 / roughness));
+            // pow(spec, 1 / roughness) with the plugin's constant roughness .05f: 1 / .05f is 20 exactly, and the twentieth power by five
+            // multiplications differs from the C library's pow by a few ulp of a double before the result is rounded to float (the library
+            // routine was most of this instantiation's registers and a hundred instructions per (point, light) pair)
+            static_assert(1 / .05f == 20.f, "the exponent of the hair shader's specular term");
+            { const double s1 = (double) spec, s2 = s1 * s1, s4 = s2 * s2, s5 = s4 * s1, s10 = s5 * s5; spec = (float) (s10 * s10); }
             k[0] = (H.Cd[0] * diff + spec) * Cl[0];
             k[1] = (H.Cd[1] * diff + spec) * Cl[1];
             k[2] = (H.Cd[2] * diff + spec) * Cl[2];
