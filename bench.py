@@ -200,6 +200,8 @@ def kernel_matcher(kname):
     def match(nm):
         if kname == "k_shadow_anyhit":
             return "k_shadow_anyhit<false" in nm
+        if kname == "k_shadow_anyhit_curves":
+            return "k_shadow_anyhit_curves<false" in nm
         if kname == "k_shadow_trace":
             return any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false"))
         if kname == "k_trace_closest_phased":
@@ -339,7 +341,7 @@ def main():
     s_node, s_prim = gs.query("node_record_bytes"), gs.query("tri_record_bytes")
     # the lean any-hit walk reads the quantised 64-byte twin of a node; so does the closest-hit walk of scenes
     # without curve sets / motion (fjgpu_dev_traverse.h)
-    s_node_walk = gs.query("anyhit_node_record_bytes") if gs.query("lean_anyhit") else s_node
+    s_node_walk = gs.query("anyhit_node_record_bytes") if (gs.query("lean_anyhit") or gs.query("curve_anyhit")) else s_node     # (both read the 64-byte quantised nodes)
     s_node_closest = gs.query("closest_node_record_bytes")
     if args.batch_tiles:
         gs.set_option("batch_tiles", args.batch_tiles)
@@ -418,7 +420,7 @@ def main():
         # ---- roofline of the DOMINANT KERNEL on rank 0: the traversal kernel with the largest share of the
         # frame by MEASURED time (HIP events of exactly its launches in the timed frames)
         nf = len(stats)
-        shadow_name = "k_shadow_anyhit" if gs.query("lean_anyhit") else "k_shadow_trace"
+        shadow_name = "k_shadow_anyhit" if gs.query("lean_anyhit") else ("k_shadow_anyhit_curves" if gs.query("curve_anyhit") else "k_shadow_trace")
         closest_name = "k_trace_closest_phased" if int(gs.query("closest_kernel")) == 1 else "k_trace_closest"
         cand = {
             shadow_name: {"ms": float(sum(s.shadow_walk_ms for s in stats)), "launches": float(sum(s.shadow_walk_launches for s in stats)),

@@ -702,6 +702,13 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
   // 1: shadow rays are walked by k_shadow_anyhit (every occluder opaque, no curves, no motion), 0: by k_shadow_trace
+  // 1: shadow rays are walked by k_shadow_anyhit_curves (curve scene, every occluder opaque, no motion, instance level within the curve budget)
+  if (n == "curve_anyhit") {
+    const DScene &S = scene->S;
+    *value = (S.has_curves && !S.has_motion && S.all_opaque && S.curve_anyhit && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES_CURVES &&
+              S.n_instances <= FJ_INST_LDS_INSTS_CURVES && S.n_groups <= FJ_INST_LDS_GROUPS_CURVES && FJ_CURVE_QNODES && FJ_CLOSEST_QNODES) ? 1 : 0;
+    return 0;
+  }
   if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion && scene->S.blas_base) ? 1 : 0; return 0; }
   // which closest-hit kernel walks this scene (launch_trace_closest): 0 k_trace_closest<false, *, false>, 1 k_trace_closest_phased,
   // 2 k_trace_closest<true, *, false> (curve sets), 3 k_trace_closest<true, *, true> (time-sampled transforms / vertex velocities)
