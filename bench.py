@@ -289,6 +289,9 @@ def dry_ranks_parent(args):
     if args.spp:
         cmd += ["--spp"] + [str(v) for v in args.spp]
     env = dict(os.environ, FJ_BENCH_DRY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # N processes share ONE GPU here, each with a scene replica and work buffers of its own: the shadow queue (up to 41 GB per process
+    # when it has a GPU to itself) is held to a share of it, or eight ranks at the headline size do not fit the 288 GB
+    env.setdefault("FJGPU_SQUEUE_M", str(max(8, 256 // max(1, args.dry_ranks))))
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
