@@ -445,6 +445,37 @@ def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
     assert float(rel_err(fb1, fb0).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("kw", [
+    dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4),
+    dict(res=(96, 64), spp=(3, 3), mesh="furball", nlights=9),           # more lights than a wave iteration's worth of pending curves
+])
+def test_curve_anyhit_walk_changes_nothing(kw, asset_dir):
+    """option curve_anyhit: the shadow rays of a curve scene whose occluders are all opaque run k_shadow_anyhit_curves (phase-scheduled,
+    pending curves, ribbon phase); off, the general walk.  Same ray counts per context, same pixels, and the oracle's
+    (Curve::ray_intersect, src/fj_curve.cc:187-232, through SlIlluminance, src/fj_shading.cc:296-359)."""
+    text = workloads.furry(asset_dir, **kw)
+    out = []
+    _last["adaptive"] = False
+    for on in (1, 0):
+        gpu.global_option("curve_anyhit", on)
+        try:
+            sp, rd = prepare(text)
+            gs = gpu.Scene(sp)
+            assert int(gs.query("curve_anyhit")) == on
+            fb, st = gs.render_frame(rd)
+            gs.close()
+        finally:
+            gpu.global_option("curve_anyhit", 1)
+        out.append((fb, st))
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    for fb, st in out:
+        assert_parity(fb, st, ref, rc)
+    assert out[0][1].rays.as_dict() == out[1][1].rays.as_dict()
+    assert float(rel_err(out[0][0], out[1][0]).max()) <= 1e-5
+
+
 def test_hair_shader_declared_in_an_all_opaque_mesh_scene_with_split_shadow_rays(asset_dir):
     """a HairShader in a scene WITHOUT curves whose shadow groups hold several instances: the light loop runs its
     hair instantiation, and that one must queue rays per candidate instance exactly like the plain one does (the
