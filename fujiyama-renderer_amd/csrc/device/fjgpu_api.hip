@@ -118,6 +118,7 @@ struct fjgpu_scene {
   double tri_record_bytes;         // 36 when every mesh is stored as f32 triangles, else 72
   size_t blas_nodes;
   size_t squeue_max;               // shadow-queue entries allowed by the memory budget
+  size_t batch_fit_samples = 0;    // 0, or the samples per batch the work buffers were cut down to when an allocation failed (not tried beyond again)
   // ray-queue sort (fjgpu_raysort.hip): levels >= 1 of scenes with incoherent secondary rays
   int ray_sort_bits = 0;           // grid bits per axis; 0 = rays are walked in queue order
   double scene_box[6];             // union of the instances' world boxes (the sort's grid)
@@ -930,6 +931,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   }
   bt = std::min<long>(bt, (long) ids.size());
   bt = std::min<long>(bt, (long) (((size_t) 1 << 31) / full_tile_samples));   // sample slots are 32-bit
+  // (a batch that did not fit last time -- a batch_tiles option beyond the memory -- is not tried again frame after frame: each failed attempt
+  // allocates and releases tens of GB, 15-20 s per frame measured with batch_tiles = 1020 on C4)
+  if (sc->batch_fit_samples && full_tile_samples * (size_t) bt > sc->batch_fit_samples) bt = std::max<long>(1, (long) (sc->batch_fit_samples / full_tile_samples));
   if (bt < 1) bt = 1;
   // light loops beside the next levels' closest-hit walks (option overlap_shadow): on, or by the size of the batch
   sc->overlap_now = !adaptive && sc->n_light_samples > 0 && (sc->overlap == 1 || (sc->overlap == 2 && deepest >= 1 && full_tile_samples * (size_t) bt <= FJ_OVERLAP_MAX_SAMPLES));
@@ -959,6 +963,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     sc->a_owner = nullptr; sc->a_samples = 0; sc->a_cell_bytes = 0;
     sc->sort_cap = 0;
     bt = std::max<long>(1, bt / 2);
+    sc->batch_fit_samples = full_tile_samples * (size_t) bt;      // (at most this from now on; a smaller one that fails lowers it again)
   }
   // adaptive grid: split / leaf byte per lattice cell of every level (4/3 of the finest level)
   const size_t a_cells0_cap = adaptive ? (size_t) bt * (size_t) (r->tile_w + 2 * margin[0]) * (size_t) (r->tile_h + 2 * margin[1]) : 0;
