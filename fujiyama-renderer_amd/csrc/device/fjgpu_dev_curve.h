@@ -37,26 +37,18 @@ __device__ __forceinline__ double dmin(double x, double y) { return x < y ? x : 
 __device__ __forceinline__ double dot_xy(V3 a, V3 b) { return a.x * b.x + a.y * b.y; }
 
 // Ray space of one (ray, instance): origin at the ray origin, +z along the ray
-// (compute_world_to_ray_matrix, src/fj_curve.cc:268-295: dst = rotate * translate).  The
-// reference rebuilds it in every Curve::ray_intersect call; it depends on the ray only, so the
-// walk builds it ONCE when the ray enters a curve set and keeps its 12 numbers in LDS
-// ([k][thread], lane consecutive) -- two square roots and two divisions less per curve tested,
-// more than half of the first-stage test.
+// (compute_world_to_ray_matrix, src/fj_curve.cc:268-295: dst = rotate * translate), rebuilt in every
+// Curve::ray_intersect call like the reference does.
 #ifndef FJ_CURVE_CACHE_LEVEL
 #define FJ_CURVE_CACHE_LEVEL 1            // 0: no cached node of the subdivision
-#endif
-#ifndef FJ_CURVE_FIRST_STAGE
-#define FJ_CURVE_FIRST_STAGE 0             // 1: the whole curve's ray-space box is tested in the leaf phase before the lane takes the curve along (the second stage begins with the same test: with it C5 2.07 s, without 1.95 s)
 #endif
 #ifndef FJ_CURVE_SKIP_PASSED
 #define FJ_CURVE_SKIP_PASSED 1
 #endif
-#ifndef FJ_CURVE_FRAME_LDS
-#define FJ_CURVE_FRAME_LDS 0              // 1: the frame is built once per (ray, instance) and kept in 12 doubles of LDS per lane
-#endif
-#define FJ_FRAME_DOUBLES (FJ_CURVE_FRAME_LDS ? 12 : 0)
-#define FJ_RAYSPACE_DOUBLES_ (FJ_FRAME_DOUBLES + (FJ_CURVE_CACHE_LEVEL > 0 ? 14 : 0))
-#define FJ_RAYSPACE_DOUBLES (FJ_RAYSPACE_DOUBLES_ > 0 ? FJ_RAYSPACE_DOUBLES_ : 1)
+// (measured and dropped in rounds 1-3, kept as profiles/r04_curve_dropped_experiments.patch: the frame kept in 12 doubles of LDS per lane instead of
+// rebuilt per test; the whole curve's ray-space box tested in the leaf phase before the lane takes the curve along; the second stage shared by
+// the wave, curve_ray_coop)
+#define FJ_RAYSPACE_DOUBLES (FJ_CURVE_CACHE_LEVEL > 0 ? 14 : 1)
 struct RayFrame { V3 r0, r1, r2; double m03, m13, m23, ray_scale; };
 __device__ __forceinline__ RayFrame make_ray_frame(V3 oo, V3 od)
 {
@@ -78,32 +70,9 @@ __device__ __forceinline__ RayFrame make_ray_frame(V3 oo, V3 od)
   return f;
 }
 struct RaySpace {
-  double *lds;          // s_rayspace + threadIdx.x
-  V3 oo, od;            // the ray in the instance's space (FJ_CURVE_FRAME_LDS == 0: the frame is rebuilt from it)
-  __device__ __forceinline__ void set(V3 oo_, V3 od_) const
-  {
-    if (!FJ_CURVE_FRAME_LDS) return;
-    const RayFrame f = make_ray_frame(oo_, od_);
-    lds[0 * BLOCK] = f.r0.x; lds[1 * BLOCK] = f.r0.z;                          // r0.y = 0
-    lds[2 * BLOCK] = f.r1.x; lds[3 * BLOCK] = f.r1.y; lds[4 * BLOCK] = f.r1.z;
-    lds[5 * BLOCK] = f.r2.x; lds[6 * BLOCK] = f.r2.y; lds[7 * BLOCK] = f.r2.z;
-    lds[8 * BLOCK] = f.m03;
-    lds[9 * BLOCK] = f.m13;
-    lds[10 * BLOCK] = f.m23;
-    lds[11 * BLOCK] = f.ray_scale;
-  }
-  __device__ __forceinline__ RayFrame frame() const
-  {
-    if (!FJ_CURVE_FRAME_LDS) return make_ray_frame(oo, od);
-    const double *m = lds;
-    RayFrame f;
-    f.r0 = mk(m[0 * BLOCK], 0, m[1 * BLOCK]);
-    f.r1 = mk(m[2 * BLOCK], m[3 * BLOCK], m[4 * BLOCK]);
-    f.r2 = mk(m[5 * BLOCK], m[6 * BLOCK], m[7 * BLOCK]);
-    f.m03 = m[8 * BLOCK]; f.m13 = m[9 * BLOCK]; f.m23 = m[10 * BLOCK];
-    f.ray_scale = m[11 * BLOCK];
-    return f;
-  }
+  double *lds;          // s_rayspace + threadIdx.x: the cached node of the subdivision (curve_ray<true>), or null
+  V3 oo, od;            // the ray in the instance's space: the frame is rebuilt from it per test (cheaper than 12 doubles of LDS per lane)
+  __device__ __forceinline__ RayFrame frame() const { return make_ray_frame(oo, od); }
 };
 
 // The curve (moved to the ray's time) in that space
@@ -181,15 +150,6 @@ __device__ __forceinline__ bool capsule_may_hit_v(fj_v4f c0, fj_v4f c1, V3 oo, V
   return dot(q, q) <= reach * reach * 1.000001;
 }
 
-// first stage of the ribbon test: does the whole curve's ray-space box reach the ray at all?
-// (exactly the test curve_ray starts with: a curve rejected here is rejected there)
-__device__ bool curve_may_hit(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, const RaySpace &rsp)
-{
-  double rs;
-  const Bz root = curve_to_ray_space(cpw, velw, time, w0, w1, rsp, &rs);
-  return !bz_misses_ray(root);
-}
-
 // kCache = false: no LDS behind rsp (the any-hit walk of curve scenes, fjgpu_dev_anyhit_curves.h): every leaf walk starts at the root
 template <bool kCache = true>
 __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *velw, double time, double w0, double w1, int depth, const RaySpace &rsp, double *t_out, double *v_out)
@@ -205,7 +165,7 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   // the cached node 1 / 2 / 3: 5.19 / 5.26 / 5.46 s per frame, 5.41 s without.)
   const int CL = FJ_CURVE_CACHE_LEVEL;
   const bool use_cache = kCache && CL > 0 && depth > CL;
-  double *cache = kCache ? rsp.lds + FJ_FRAME_DOUBLES * BLOCK : nullptr;
+  double *cache = kCache ? rsp.lds : nullptr;
   uint32_t cached = 0xffffffffu;           // which level-CL node the cache holds
   uint32_t j = 0;
   // levels 0..passed of the walk towards j are known to pass their bounds test: the ancestors a leaf walk shares with the one
@@ -295,198 +255,6 @@ __device__ bool curve_ray(const FJ_GLOBAL double *cpw, const FJ_GLOBAL double *v
   *t_out = best_z / ray_scale;
   *v_out = best_v;
   return true;
-}
-
-// ---------------------------------------------------- the second stage, shared by the wave
-// curve_ray above is one lane's sweep over the 2^depth leaves of ITS curve: 1 node when the root misses, a hundred when the
-// ray runs along the ribbon.  Run by the lanes of a wave side by side, the longest sweep sets the time: of the 64 lanes 44
-// carry a curve when the stage runs, and those average 17 nodes where the slowest takes ~60 -- a fifth of the issued lanes
-// work (C5: lane efficiency 0.34 over the whole kernel).  The leaf walks of a sweep are INDEPENDENT of each other (each is
-// derived from the root by its own sequence of splits; the result is the smallest z, the rightmost leaf among equals), so
-// here the wave shares them: a lane's item is (test, [j, jend)); a lane without work takes the upper half of the range of
-// one that has at least two leaves left (the thief rebuilds the root from the owner's ray, fetched across lanes, and the
-// curve's record), and the partial results meet in LDS -- an atomic minimum on the bits of z (z > 0), then among the entries
-// that attain it the largest leaf index.  Same splits, same operands, same winner as the sweep of one lane.
-#ifndef FJ_CURVE_COOP
-#define FJ_CURVE_COOP 0                   // measured SLOWER (C5 shadow walk 1737 -> 2030 ms whatever the hand-over thresholds): off; see below
-#endif
-#ifndef FJ_COOP_STEAL_MIN
-#define FJ_COOP_STEAL_MIN 8                 // idle lanes it takes to run a round of hand-overs
-#endif
-#ifndef FJ_COOP_MIN_WALKS
-#define FJ_COOP_MIN_WALKS 4                 // a range is split only after its lane has made this many leaf walks in it: most sweeps
-                                            // end within a few walks (a high ancestor fails its bounds test and the range is gone)
-#endif
-#define FJ_COOP_HITS 160
-struct CoopHit { unsigned long long z; double v; uint32_t test, j; };
-struct CoopWave {                           // LDS of ONE wave (carved from s_rayspace: 14 * 64 doubles = 7168 bytes per wave)
-  unsigned long long zmin[64];              // per test (= owner lane): smallest z so far, as bits
-  double vres[64];                          // ... and the winner's curve parameter
-  unsigned long long desc_P[64];            // the test: primitive set and BLAS slot of the curve
-  uint32_t jmax[64];                        // 1 + the largest leaf index among the entries with z == zmin
-  uint32_t desc_sl[64];
-  uint32_t st_test[64], st_j[64], st_end[64];   // hand-over slots of one round
-  uint32_t hit_n, pad_[3];
-  CoopHit hits[FJ_COOP_HITS];               // one entry per finished item that found a hit
-};
-static_assert(sizeof(CoopWave) <= 14 * 64 * 8, "CoopWave must fit a wave's share of s_rayspace");
-
-// one step of curve_ray's sweep: from the root towards leaf *jp -- to the leaf's own test, or to the first ancestor whose
-// bounds the ray misses (then *jp skips that ancestor's span)
-__device__ __forceinline__ void curve_leaf_walk(const Bz &root, int depth, uint32_t *jp, double *best_z, double *best_v, uint32_t *best_j, bool *any)
-{
-  const uint32_t j = *jp;
-  Bz b = root;
-  double v0 = 0, vn = 1;
-  for (int L = 0;; L++) {
-    if (bz_misses_ray(b)) {
-      const uint32_t span = 1u << (depth - L);
-      *jp = ((j / span) + 1) * span;
-      return;
-    }
-    if (L == depth) break;
-    const V3 midP = bez_eval(b, .5);              // split_bezier3, src/fj_curve.cc:488-508
-    const V3 midCP = mid_point(b.c1, b.c2);
-    const double vm = (v0 + vn) * .5;
-    const double wm = (b.w0 + b.w1) * .5;
-    if (((j >> (depth - L - 1)) & 1u) == 0) {
-      const V3 l1 = mid_point(b.c0, b.c1);
-      const V3 l2 = mid_point(l1, midCP);
-      b.c1 = l1; b.c2 = l2; b.c3 = midP;
-      b.w1 = wm;
-      vn = vm;
-    } else {
-      const V3 q2 = mid_point(b.c3, b.c2);
-      const V3 q1 = mid_point(q2, midCP);
-      b.c0 = midP; b.c1 = q1; b.c2 = q2;
-      b.w0 = wm;
-      v0 = vm;
-    }
-  }
-  *jp = j + 1;
-  // depth == 0 block of converge_bezier3 (as in curve_ray)
-  const V3 dir = b.c3 - b.c0;
-  V3 dP0 = b.c1 - b.c0;
-  if (dot_xy(dir, dP0) < 0) dP0 = dP0 * -1;
-  if (-1 * dot_xy(dP0, b.c0) < 0) return;
-  V3 dPn = b.c3 - b.c2;
-  if (dot_xy(dir, dPn) < 0) dPn = dPn * -1;
-  if (dot_xy(dPn, b.c3) < 0) return;
-  double w = dir.x * dir.x + dir.y * dir.y;
-  if (fabs(w) < 1e-6) return;
-  w = -(b.c0.x * dir.x + b.c0.y * dir.y) / w;
-  w = clampd(w, 0, 1);
-  const double v = v0 * (1 - w) + vn * w;
-  const double radius_w = .5 * ((1 - w) * b.w0 + w * b.w1);
-  const V3 vP = bez_eval(b, w);
-  if (vP.x * vP.x + vP.y * vP.y >= radius_w * radius_w) return;
-  if (vP.z <= 1e-6) return;
-  if (vP.z <= *best_z) { *best_z = vP.z; *best_v = v; *best_j = j; *any = true; }
-}
-
-#define FJ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-
-// ALL lanes of the wave call this (wave-uniform control flow around it); `carrying` lanes bring a test -- the curve in BLAS
-// slot sl of primitive set P against the ray (oo, od) at time rtime -- and get its result: true + t, v as curve_ray.
-template <bool kMotion>
-__device__ bool curve_ray_coop(bool carrying, const DPrimSet *P, uint32_t sl, double rtime, V3 oo, V3 od, CoopWave *cw, double *t_out, double *v_out)
-{
-  const unsigned lane = __lane_id();
-  Bz root;
-  root.c0 = root.c1 = root.c2 = root.c3 = mk(0, 0, 0); root.w0 = root.w1 = 0;
-  double ray_scale = 1;
-  int depth = 0;
-  uint32_t test = lane, j = 0, jend = 0;
-  if (carrying) {
-    const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + (size_t) sl * 12 : nullptr;
-    const RaySpace rsp = {nullptr, oo, od};
-    root = curve_to_ray_space(FJ_G(double, P->curve_cp) + (size_t) sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * (size_t) sl],
-        FJ_G(double, P->curve_width)[2 * (size_t) sl + 1], rsp, &ray_scale);
-    depth = (int) FJ_G(int8_t, P->curve_depth)[sl];
-    jend = 1u << depth;
-    cw->desc_P[lane] = (unsigned long long) (uintptr_t) P;
-    cw->desc_sl[lane] = sl;
-  }
-  cw->zmin[lane] = ~0ull;
-  cw->jmax[lane] = 0u;
-  if (lane == 0) cw->hit_n = 0u;
-  uint32_t items_total = (uint32_t) __popcll(__ballot(carrying));       // wave-uniform
-  double best_z = DBL_MAX, best_v = 0;
-  uint32_t best_j = 0;
-  bool any = false, open = carrying;
-  uint32_t walks = 0;
-  FJ_WAVE_SYNC();
-  for (;;) {
-    if (__ballot(j < jend) == 0ull) break;
-    if (j < jend) { curve_leaf_walk(root, depth, &j, &best_z, &best_v, &best_j, &any); walks++; }
-    if (open && j >= jend) {               // the item is finished: its result joins the test's
-      if (any) {
-        atomicMin(&cw->zmin[test], (unsigned long long) __double_as_longlong(best_z));
-        const uint32_t at = atomicAdd(&cw->hit_n, 1u);
-        if (at < FJ_COOP_HITS) { CoopHit h; h.z = (unsigned long long) __double_as_longlong(best_z); h.v = best_v; h.test = test; h.j = best_j; cw->hits[at] = h; }
-      }
-      open = false;
-    }
-    // ---- hand-overs: the k-th idle lane takes the upper half of the k-th splittable range
-    const bool idle = !(j < jend);
-    const bool splittable = !idle && jend - j >= 2u && walks >= FJ_COOP_MIN_WALKS;
-    const unsigned long long m_idle = __ballot(idle), m_split = __ballot(splittable);
-    const uint32_t n_idle = (uint32_t) __popcll(m_idle), n_split = (uint32_t) __popcll(m_split);
-    if (n_idle >= FJ_COOP_STEAL_MIN && n_split > 0u && items_total < FJ_COOP_HITS) {
-      uint32_t n_pairs = n_idle < n_split ? n_idle : n_split;
-      if (n_pairs > FJ_COOP_HITS - items_total) n_pairs = FJ_COOP_HITS - items_total;
-      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t) (m_split >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_split, 0u));
-      const uint32_t q = __builtin_amdgcn_mbcnt_hi((uint32_t) (m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_idle, 0u));
-      const bool victim = splittable && r < n_pairs, thief = idle && q < n_pairs;
-      if (victim) { cw->st_test[r] = test; cw->st_j[r] = j; cw->st_end[r] = jend; }
-      FJ_WAVE_SYNC();
-      if (thief) {
-        const uint32_t a = cw->st_j[q], e = cw->st_end[q];
-        const uint32_t mid = a + (e - a + 1u) / 2u;
-        test = cw->st_test[q];
-        cw->st_end[q] = mid;
-        j = mid; jend = e;
-      }
-      FJ_WAVE_SYNC();
-      if (victim) jend = cw->st_end[r];
-      items_total += n_pairs;
-      // the ray of a test lives in the registers of its owner lane (lane index = test index)
-      const int src = thief ? (int) test : (int) lane;
-      const V3 o2 = mk(__shfl(oo.x, src), __shfl(oo.y, src), __shfl(oo.z, src));
-      const V3 d2 = mk(__shfl(od.x, src), __shfl(od.y, src), __shfl(od.z, src));
-      const double tm2 = kMotion ? __shfl(rtime, src) : 0.;
-      if (thief) {
-        const DPrimSet *P2 = (const DPrimSet *) (uintptr_t) cw->desc_P[test];
-        const uint32_t sl2 = cw->desc_sl[test];
-        const FJ_GLOBAL double *cvel = (kMotion && P2->curve_vel) ? FJ_G(double, P2->curve_vel) + (size_t) sl2 * 12 : nullptr;
-        const RaySpace rsp = {nullptr, o2, d2};
-        double rs2;
-        root = curve_to_ray_space(FJ_G(double, P2->curve_cp) + (size_t) sl2 * 12, cvel, tm2, FJ_G(double, P2->curve_width)[2 * (size_t) sl2],
-            FJ_G(double, P2->curve_width)[2 * (size_t) sl2 + 1], rsp, &rs2);
-        depth = (int) FJ_G(int8_t, P2->curve_depth)[sl2];
-        best_z = DBL_MAX; best_v = 0; best_j = 0; any = false; open = true; walks = FJ_COOP_MIN_WALKS;    // (a stolen range has proven long)
-      }
-    }
-  }
-  FJ_WAVE_SYNC();
-  // ---- the winner of every test: smallest z (atomic minimum above), among equals the rightmost leaf
-  const uint32_t H = cw->hit_n < FJ_COOP_HITS ? cw->hit_n : FJ_COOP_HITS;
-  for (uint32_t h = lane; h < H; h += 64u) {
-    const CoopHit e = cw->hits[h];
-    if (e.z == cw->zmin[e.test]) atomicMax(&cw->jmax[e.test], e.j + 1u);
-  }
-  FJ_WAVE_SYNC();
-  for (uint32_t h = lane; h < H; h += 64u) {
-    const CoopHit e = cw->hits[h];
-    if (e.z == cw->zmin[e.test] && e.j + 1u == cw->jmax[e.test]) cw->vres[e.test] = e.v;
-  }
-  FJ_WAVE_SYNC();
-  if (carrying && cw->zmin[lane] != ~0ull) {
-    *t_out = __longlong_as_double((long long) cw->zmin[lane]) / ray_scale;
-    *v_out = cw->vres[lane];
-    return true;
-  }
-  return false;
 }
 
 // The reference's GridAccelerator accepts a primitive hit only when the hit point

@@ -329,7 +329,6 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
         plain = plain_dir(d);
       }
-      bool into_curves = false;
       while (!dead_ray && ti < tend) {
         const DTNode *tn_ = &gnodes[ti];
         if (tn_->inst < 0) {             // inner node of the instance BVH: conservative box, skip link
@@ -366,13 +365,11 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
         if (FJ_CLOSEST_QNODES && (!kCurves || (FJ_CURVE_QNODES && !kMotion))) s32 = slab32q_setup(oo, inv, I->qorigin, I->qcell);
         else s32 = slab32_setup(oo, inv, I->pbounds);
         root = I->proot;
-        into_curves = kCurves && I->ptype == FJ_PRIMSET_CURVE;
         found = true;
         break;
       }
       if (found) {
         cur = root; sp = 0; last_curve = 0xffffffffu;
-        if (into_curves) { RaySpace rsp = {stk.rayspace, oo, od}; rsp.set(oo, od); }
       }
       else { pol.finish(idx, best); have = false; }
     }
@@ -446,9 +443,8 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           last_curve = cid;
           if (kCount) lc->prims++;
           const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
-          // (FJ_CURVE_FIRST_STAGE 0: a slot that passes its capsule goes to the second stage at once; that stage starts with the same test)
-          deep = !FJ_CURVE_FIRST_STAGE ? true :
-                 curve_may_hit(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1], RaySpace{stk.rayspace, oo, od});
+          // (a slot that passes its capsule goes to the second stage at once: that stage starts with the whole curve's ray-space box)
+          deep = true;
           // the second stage is deferred: the lane remembers the curve and walks on (its result
           // only shortens the ray or ends it -- the walk stays correct without it); a lane that
           // already carries a deferred curve waits here instead
@@ -492,21 +488,14 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
           if (lane == (unsigned) __ffsll((long long) pendm) - 1u) { FJ_CURVE_STAT(2, 1); FJ_CURVE_STAT(3, __popcll(pendm)); }   // second-stage execs / lanes
           double t = 0, u = 0;
           bool hitc = false;
-#if FJ_CURVE_COOP
-          // (every lane of the wave: the lanes share the leaf walks of the carried curves, curve_ray_coop)
-          hitc = curve_ray_coop<kMotion>(carrying, P, pend, rtime, oo, od,
-              (CoopWave *) ((char *) (stk.rayspace - threadIdx.x) + (threadIdx.x >> 6) * (14 * 64 * 8)), &t, &u);
-#endif
-                if (carrying) {
+          if (carrying) {
             bool stop = false;
             const size_t sl = pend;
             pend = 0xffffffffu;
             const FJ_GLOBAL double *cvel = (kMotion && P->curve_vel) ? FJ_G(double, P->curve_vel) + sl * 12 : nullptr;
             // hit record of a curve: u = curve parameter v_hit, v = BLAS slot (attribute fetch)
-#if !FJ_CURVE_COOP
             hitc = curve_ray(FJ_G(double, P->curve_cp) + sl * 12, cvel, rtime, FJ_G(double, P->curve_width)[2 * sl], FJ_G(double, P->curve_width)[2 * sl + 1],
                           (int) FJ_G(int8_t, P->curve_depth)[sl], RaySpace{stk.rayspace, oo, od}, &t, &u);
-#endif
             if (hitc &&
                 (cvel ? curve_listed_in_cell_of_moving(P, FJ_G(double, P->curve_cp) + sl * 12, cvel, oo + t * od)
                       : curve_listed_in_cell_of(P, FJ_G(double, P->curve_cp) + sl * 12, oo + t * od)) &&
