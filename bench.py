@@ -206,6 +206,8 @@ def kernel_matcher(kname):
             return any(("k_shadow_trace<%s, false" % c) in nm for c in ("true", "false"))
         if kname == "k_trace_closest_phased":
             return "k_trace_closest_phased<false" in nm
+        if kname == "k_trace_closest_flat":
+            return "k_trace_closest_flat<false" in nm
         if kname == "k_trace_closest":
             return any(("k_trace_closest<%s, false" % c) in nm for c in ("true", "false"))
         return kname in nm
@@ -424,7 +426,7 @@ def main():
         # frame by MEASURED time (HIP events of exactly its launches in the timed frames)
         nf = len(stats)
         shadow_name = "k_shadow_anyhit" if gs.query("lean_anyhit") else ("k_shadow_anyhit_curves" if gs.query("curve_anyhit") else "k_shadow_trace")
-        closest_name = "k_trace_closest_phased" if int(gs.query("closest_kernel")) == 1 else "k_trace_closest"
+        closest_name = {1: "k_trace_closest_phased", 4: "k_trace_closest_flat"}.get(int(gs.query("closest_kernel")), "k_trace_closest")
         cand = {
             shadow_name: {"ms": float(sum(s.shadow_walk_ms for s in stats)), "launches": float(sum(s.shadow_walk_launches for s in stats)),
                           "alg": float(counted.shadow_nodes * s_node_walk + counted.shadow_prims * s_prim + counted.shadow_insts * S_INST +

@@ -189,12 +189,96 @@ static const char *bad_render(const fj_render_desc *r)
   return nullptr;
 }
 
+// FLAT groups (DFlat, fjgpu_dev_flat.h): when EVERY group of a scene with incoherent closest-hit rays holds only small static meshes built on
+// the host, each group gets one world-space culling tree over the triangles of all its instances.  Returns the flats (empty: not applicable)
+// and the deepest stack any of the trees needs.
+#ifndef FJ_FLAT_MAX_TRIS
+#define FJ_FLAT_MAX_TRIS (1 << 21)
+#endif
+struct HostFlat { fjgpu::HostPrimSet tree; std::vector<DFlatRef> refs; std::vector<double> refbox; double grid[6]; };
+static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> *out)
+{
+  out->clear();
+  if (hs.groups.empty() || !hs.xforms.empty()) return false;
+  std::vector<HostFlat> flats(hs.groups.size());
+  for (size_t g = 0; g < hs.groups.size(); g++) {
+    const DGroup &G = hs.groups[g];
+    // the instances in the order the walks (and the reference's BVH) visit them: the leaves of the threaded instance level
+    std::vector<int> order;
+    for (int k = G.first; k < G.first + G.count; k++) if (hs.group_nodes[k].inst >= 0) order.push_back(hs.group_nodes[k].inst);
+    if (order.empty() || order.size() > 32 || (int) order.size() != G.n_instances) return false;
+    size_t total = 0;
+    for (int inst : order) {
+      const DInstance &I = hs.instances[inst];
+      const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
+      if (ps.type != FJ_PRIMSET_MESH || ps.device_build || I.xform >= 0 || !ps.tri_vel.empty() || inst >= (1 << 24)) return false;
+      if (ps.n_prims > 0 && ps.tri_verts.empty() && ps.tri_verts32.empty()) return false;
+      total += (size_t) ps.n_prims;
+    }
+    if (total > (size_t) FJ_FLAT_MAX_TRIS) return false;
+    HostFlat &F = flats[g];
+    std::vector<fjgpu::PrimRef> prs;
+    prs.reserve(total);
+    double gmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, gmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    std::vector<DFlatRef> src;
+    src.reserve(total);
+    for (size_t pos = 0; pos < order.size(); pos++) {
+      const int inst = order[pos];
+      const DInstance &I = hs.instances[inst];
+      const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
+      const double *rb = order.size() == 1 ? G.sbounds : I.wbounds;
+      for (int k = 0; k < 6; k++) F.refbox.push_back(rb[k]);
+      for (int k = 0; k < ps.n_prims; k++) {
+        double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (int v = 0; v < 3; v++) {
+          double p[3];
+          for (int a = 0; a < 3; a++) p[a] = ps.tri_verts32.empty() ? ps.tri_verts[(size_t) k * 9 + 3 * v + a] : (double) ps.tri_verts32[(size_t) k * 9 + 3 * v + a];
+          for (int a = 0; a < 3; a++) {
+            const double w = I.M[4 * a] * p[0] + I.M[4 * a + 1] * p[1] + I.M[4 * a + 2] * p[2] + I.M[4 * a + 3];
+            mn[a] = std::min(mn[a], w); mx[a] = std::max(mx[a], w);
+          }
+        }
+        fjgpu::PrimRef r;
+        for (int a = 0; a < 3; a++) {
+          // the exact test runs in object space: its hit point, carried to the world by o + t d, lies on the image of the triangle up to the
+          // roundings of M v and M^-1 (o, d) -- a relative 1e-9 (and 1e-12 absolute) covers them many times over
+          if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return false;
+          const double pad = 1e-9 * (std::fabs(mn[a]) + std::fabs(mx[a])) + 1e-12;
+          r.bmin[a] = fjgpu::RoundDown2(mn[a] - pad);
+          r.bmax[a] = fjgpu::RoundUp2(mx[a] + pad);
+          r.c[a] = (float) (.5 * (mn[a] + mx[a]));
+          gmn[a] = std::min(gmn[a], (double) r.bmin[a]); gmx[a] = std::max(gmx[a], (double) r.bmax[a]);
+        }
+        r.id = (uint32_t) src.size();
+        prs.push_back(r);
+        DFlatRef fr;
+        fr.inst_ord = ((uint32_t) inst << 8) | (uint32_t) pos;
+        fr.slot = (uint32_t) k;
+        src.push_back(fr);
+      }
+    }
+    F.tree.type = FJ_PRIMSET_MESH; F.tree.device_build = false; F.tree.f32_exact = false; F.tree.mesh = nullptr; F.tree.curve = nullptr;
+    fjgpu::BuildBlas(&F.tree, prs, FJ_MAX_LEAF_PRIMS, 1.2f);
+    F.refs.resize(src.size());
+    for (size_t sl = 0; sl < src.size(); sl++) F.refs[sl] = src[F.tree.prim_ids[sl]];
+    for (int a = 0; a < 3; a++) {
+      if (total == 0) { gmn[a] = 0; gmx[a] = 1; }
+      const double pad = 1e-4 * std::max(1., gmx[a] - gmn[a]);
+      F.grid[a] = gmn[a] - pad;
+      F.grid[3 + a] = std::max(1e-300, (gmx[a] - gmn[a] + 2 * pad) / 65535. * (1 + 1e-9));
+    }
+  }
+  out->swap(flats);
+  return true;
+}
+
 static long g_ray_sort = -1;       // "ray_sort": grid bits per axis of the ray-queue sort (fjgpu_raysort.hip); 0 = off, -1 = by scene
 static long g_ray_sort_min = FJ_RAY_SORT_MIN;   // "ray_sort_min": smaller launches keep queue order
 static long g_device_tlas = 1;     // "device_tlas": the instance level of every group is built on the device (fjgpu_tlas.hip)
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
+static long g_flat_groups = 1;     // "flat_groups": scenes with incoherent closest-hit rays whose groups hold only small static meshes walk ONE world-space tree per group
 static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
@@ -212,6 +296,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "split_shadow") { g_split_shadow = value != 0; return 0; }
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
   if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
+  if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
@@ -535,10 +620,46 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   S.n_instances = (int) hs.instances.size();
   S.n_groups = (int) hs.groups.size();
   S.n_primsets = (int) hs.primsets.size();
+  // FLAT groups: one world-space culling tree per group for the closest-hit walk of scenes with incoherent rays (fjgpu_dev_flat.h)
+  int flat_stack_need = 0;
+  S.flats = nullptr;
+  {
+    bool incoherent = false;         // (the rule of DScene.incoherent_rays below: two children per hit, or diffuse bounces)
+    for (int i = 0; i < desc->n_shaders; i++) {
+      const fj_shader_desc &sh = desc->shaders[i];
+      auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
+      if (sh.type == FJ_SHADER_GLASS) incoherent = true;
+      if (sh.type == FJ_SHADER_PATHTRACING && (lum(sh.diffuse) || (int) lum(sh.reflect) + (int) lum(sh.refract) >= 2)) incoherent = true;
+    }
+    std::vector<HostFlat> hf;
+    if (incoherent && g_flat_groups && !getenv("FJGPU_NO_FLAT") && FJ_CLOSEST_QNODES && build_flat_groups(hs, &hf)) {
+      std::vector<DFlat> df(hf.size());
+      for (size_t g = 0; g < hf.size() && !e; g++) {
+        HostFlat &F = hf[g];
+        DFlat &D = df[g];
+        std::memset(&D, 0, sizeof(D));
+        const DNode *d_nodes = nullptr;
+        const size_t n_nodes = std::max<size_t>(1, F.tree.nodes.size());
+        e |= M.upload(F.tree.nodes.data(), n_nodes, &d_nodes);
+        DNodeQ *q = nullptr;
+        if (!e && M.alloc(n_nodes, &q)) e = 1;
+        if (!e && launch_quantize_nodes(nullptr, d_nodes, (uint32_t) n_nodes, &F.grid[0], &F.grid[3], q)) e = 1;
+        D.nodes = q;
+        e |= M.upload(F.refs.data(), F.refs.size(), &D.refs);
+        e |= M.upload(F.refbox.data(), F.refbox.size(), &D.refbox);
+        for (int a = 0; a < 3; a++) { D.qorigin[a] = F.grid[a]; D.qcell[a] = F.grid[3 + a]; }
+        D.root = F.tree.root; D.n_inst = (int32_t) (F.refbox.size() / 6); D.n_prims = F.tree.n_prims;
+        flat_stack_need = std::max(flat_stack_need, F.tree.stack_need);
+      }
+      if (!e) e |= M.upload(df.data(), df.size(), &S.flats);
+      if (e) S.flats = nullptr;
+      lap("flat groups");
+    }
+  }
   // traversal stack: entries beyond the LDS part live in a global overflow area sized for
   // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
   {
-    int need = 0;
+    int need = S.flats ? flat_stack_need : 0;
     for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;
@@ -713,7 +834,14 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "lean_anyhit") { *value = (scene->S.all_opaque && !scene->S.has_curves && !scene->S.has_motion && scene->S.blas_base) ? 1 : 0; return 0; }
   // which closest-hit kernel walks this scene (launch_trace_closest): 0 k_trace_closest<false, *, false>, 1 k_trace_closest_phased,
   // 2 k_trace_closest<true, *, false> (curve sets), 3 k_trace_closest<true, *, true> (time-sampled transforms / vertex velocities)
-  if (n == "closest_kernel") { *value = scene->S.has_motion ? 3 : (scene->S.has_curves ? 2 : (scene->S.incoherent_rays ? 1 : 0)); return 0; }
+  // 4 k_trace_closest_flat (incoherent rays, every group flat, instance level within the phased walk's LDS budget)
+  if (n == "closest_kernel") {
+    const DScene &S = scene->S;
+    const bool flat = !S.has_motion && !S.has_curves && S.incoherent_rays && S.flats && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES &&
+        S.n_instances <= FJ_INST_LDS_INSTS && S.n_groups <= FJ_INST_LDS_GROUPS;
+    *value = S.has_motion ? 3 : (S.has_curves ? 2 : (flat ? 4 : (S.incoherent_rays ? 1 : 0)));
+    return 0;
+  }
   // ... and the node record it reads: the 64-byte quantised twin unless the ribbon test / motion instantiation runs
   if (n == "closest_node_record_bytes") { *value = (double) ((scene->S.has_motion || (scene->S.has_curves && !FJ_CURVE_QNODES) || !FJ_CLOSEST_QNODES) ? sizeof(DNode) : sizeof(DNodeQ)); return 0; }
   if (n == "has_curves") { *value = scene->S.has_curves; return 0; }

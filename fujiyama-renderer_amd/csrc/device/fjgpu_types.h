@@ -197,6 +197,20 @@ struct DGroup {
   double sbounds[6];           // single-instance group: its instance's bounds + 1e-4 (the group accelerator's box)
 };
 
+// ---- FLAT groups (scenes whose closest-hit rays are incoherent: glass, pathtracing; fjgpu_dev_flat.h).  A group whose instances are all small
+// static meshes (the walls and objects of a Cornell box) gets ONE world-space culling tree over the triangles of all of them: a ray walks that
+// tree once instead of looping over the instances, and a leaf names (instance, triangle) -- the exact tests stay what they are, in the
+// instance's object space with its M^-1, after the reference's own instance box has been passed (once per ray and instance).
+struct DFlatRef { uint32_t inst_ord; uint32_t slot; };     // (instance << 8) | position of the instance in the group's visiting order; leaf-order slot in ITS set
+struct DFlat {
+  const DNodeQ *nodes;         // quantised 4-wide tree over the world-space boxes of the triangles
+  const DFlatRef *refs;        // [n_prims], leaf order of that tree
+  const double *refbox;        // [n_inst][6]: the REFERENCE's box of the instance at each position (DInstance.wbounds; a single-instance group: DGroup.sbounds)
+  double qorigin[3], qcell[3]; // grid of the quantised nodes
+  uint32_t root;
+  int32_t n_inst, n_prims, pad;
+};
+
 struct DTexture {
   const float *tiles;
   int32_t width, height, nchannels, tilesize;
@@ -242,6 +256,7 @@ struct DScene {
                                // instance, and all k entries name one slot here (DShadowRay.tindex = slot + 1; 0 = a
                                // single entry): (k << 16) | number of entries that reached the light so far.  The
                                // entry that completes the count adds the light; an occluded entry adds nothing.
+  const DFlat *flats;              // [n_groups] when EVERY group of the scene is flat (k_trace_closest_flat walks them), else null
   const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
   const DAnyInst *any_insts;       // [n_instances] (static mesh instances; the lean any-hit walk)
   const char *blas_base;           // lowest address of any BLAS node / triangle array (DAnyInst offsets); null: the

@@ -162,6 +162,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * queue order (default 65536).  "split_shadow" 1/0 (default 1): in scenes served by the lean any-hit walk, a shadow
  * ray into a group of several instances is queued once per instance whose box it passes (joined by a counter)
  * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).
+ * "flat_groups" 1/0 (default 1): scenes created from now on whose closest-hit rays are incoherent (glass, pathtracing shaders) and whose groups hold only
+ * small static meshes built on the host (at most 2 M triangles and 32 instances per group) get ONE world-space culling tree per group over the
+ * triangles of all its instances; the exact tests stay in object space (k_trace_closest_flat).  0: the instance loop of k_trace_closest_phased.
  * "curve_anyhit" 1/0 (default 1): scenes created from now on that hold curve sets, no time-sampled motion and only opaque occluders walk their
  * shadow rays with k_shadow_anyhit_curves (phase-scheduled, ribbon tests as a phase of their own); 0: with the general k_shadow_trace.
  * "inst_lds" 1/0 (default 1): scenes created from now on whose instance level is small (79 threaded nodes / 40 instances /
@@ -185,7 +188,7 @@ int fjgpu_host_instance_level(const fj_scene_desc *desc, int group, int32_t *out
  * triangles, else 72), "blas_nodes", "stack_need", "lean_anyhit" (1: shadow rays are walked by
  * k_shadow_anyhit, 0: not), "curve_anyhit" (1: by k_shadow_anyhit_curves -- curve scene, every occluder opaque, no motion; both 0: by the
  * general k_shadow_trace), "closest_kernel" (0 k_trace_closest, 1 k_trace_closest_phased,
- * 2 its curve instantiation, 3 its motion instantiation), "closest_node_record_bytes" (64: the closest-hit walk reads the
+ * 2 its curve instantiation, 3 its motion instantiation, 4 k_trace_closest_flat: one world-space tree per group), "closest_node_record_bytes" (64: the closest-hit walk reads the
  * quantised nodes too; 128 in scenes with curve sets or motion), "has_curves", "has_motion".  Returns 0 or FJGPU_EINVAL. */
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);
 

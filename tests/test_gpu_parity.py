@@ -437,8 +437,11 @@ def test_instance_level_in_lds_changes_nothing(builder, kw, asset_dir):
     # (measured on the box: 75 of 412 663 between two runs) -- same order of magnitude is all that can be asserted.
     # (curve scenes: with the instance level in LDS the shadow rays run k_shadow_anyhit_curves, without it the general walk -- other visiting
     # order (no distance sort), postponed leaves, another moment at which an occluded ray learns it: the same results from other event counts)
-    tol = 0.10 if builder == "furry" else 0.01
-    if builder != "furry":
+    # (cornell: its groups are FLAT -- with the instance level in LDS the closest-hit rays run k_trace_closest_flat, one world-space tree per group,
+    # without it the phase-scheduled walk with its instance loop: other trees, other event counts, the same hits)
+    other_kernel = builder in ("furry", "cornell")
+    tol = 0.5 if builder == "cornell" else (0.10 if builder == "furry" else 0.01)
+    if not other_kernel:
         assert st1.insts_tested == st0.insts_tested
     assert abs(st1.nodes_visited - st0.nodes_visited) <= tol * st0.nodes_visited
     assert abs(st1.prims_tested - st0.prims_tested) <= tol * st0.prims_tested
