@@ -53,7 +53,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
     const bool can_fetch = head_live || next < range_end;
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
 
-    if ((unsigned) __popcll(m_turn) >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
+    if ((unsigned) __popcll(m_turn) >= tune.refill_flat || (n_inner == 0 && n_leaf == 0)) {
       if (m_turn == 0ull) break;
       // ---- turnover: retire, fetch, set up the walk
       if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
@@ -94,7 +94,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
       // ---- inner nodes; further steps without a new vote while enough lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
-        if (step > 0 && (step >= tune.steps_phased || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner_phased)) break;
+        if (step > 0 && (step >= tune.steps_flat || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner_flat)) break;
         if (in_now) {
           if (kCount) lc->nodes++;
           const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
@@ -168,17 +168,21 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
 #ifndef FJ_FLAT_MINB
 #define FJ_FLAT_MINB 4
 #endif
+#ifndef FJ_STACK_LDS_FLAT
+#define FJ_STACK_LDS_FLAT FJ_STACK_LDS
+#endif
+static_assert(FJ_STACK_LDS_FLAT >= FJ_STACK_LDS_MIN, "the overflow area is sized for FJ_STACK_LDS_MIN entries in LDS");
 template <bool kCount>
 __global__ void __launch_bounds__(BLOCK, FJ_FLAT_MINB) k_trace_closest_flat(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
-  __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
+  __shared__ uint32_t s_stack[FJ_STACK_LDS_FLAT * BLOCK];
   __shared__ double s_inst[InstLds::WORDS];
   InstLds::fill(S, s_inst);         // (the launcher picked this kernel because the scene fits)
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_flat<kCount>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS), &lc, s_inst);
+  traverse_flat<kCount>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS_FLAT), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

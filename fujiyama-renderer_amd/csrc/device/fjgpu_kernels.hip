@@ -183,7 +183,7 @@ static int canyhit_blocks_per_cu()
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -205,6 +205,10 @@ static TravTune trav_tune()
     t.refill_canyhit = env("FJGPU_TRAV_REFILL_CANYHIT", 20);     // (C5 walk, refill / leaf_wait: 32 / 40 1252 ms, 24 / 48 1147, 16 / 48 1140, 20 / 56 1130, 12 / 52 1134)
     t.steps_canyhit = env("FJGPU_TRAV_STEPS_CANYHIT", 8);
     t.min_inner_canyhit = env("FJGPU_TRAV_MININNER_CANYHIT", 16);
+    // the walk of flat groups (fjgpu_dev_flat.h); C4 frame, refill / steps / min: 40 / 5 / 12 672 ms, 32 / 8 / 12 and no ray sort 638
+    t.refill_flat = env("FJGPU_TRAV_REFILL_FLAT", 32);
+    t.steps_flat = env("FJGPU_TRAV_STEPS_FLAT", 8);
+    t.min_inner_flat = env("FJGPU_TRAV_MININNER_FLAT", 8);
     t.leaf_wait_canyhit = env("FJGPU_TRAV_LEAFWAIT_CANYHIT", 56);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;
