@@ -80,6 +80,7 @@ struct fjgpu_scene {
   std::unique_ptr<DeviceBuffers> work;
   size_t work_samples, work_rays;
   double *d_suv;
+  uint32_t *d_stk = nullptr;       // (tile id, index in the tile) per sample slot: DScene.cam_tk (scenes with uid-keyed random streams), or null
   float *d_accum;
   // adaptive grid sampler (allocated on first use, in the `work` arena)
   double *d_aseen = nullptr, *d_afinal = nullptr;
@@ -716,7 +717,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   S.incoherent_rays = (sc->max_children >= 2 || sc->bounce_diffuse) ? 1 : 0;
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
   S.ray_perm = nullptr;
-  S.cam_uv = nullptr; S.cam_slot0 = 0;
+  S.cam_uv = nullptr; S.cam_slot0 = 0; S.cam_tk = nullptr;
   S.shadow_join = nullptr;
   sc->split_shadow = S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base && g_split_shadow;
   if (const char *e = getenv("FJGPU_SPLIT_SHADOW"))
@@ -891,6 +892,8 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     DeviceBuffers &W = *sc->work;
     int e = 0;
     e |= W.alloc(samples * 2, &sc->d_suv);
+    sc->d_stk = nullptr;
+    if (sc->uses_sample_uid && !sc->S.has_motion && !sc->S.cam_xform) e |= W.alloc(samples * 2, &sc->d_stk);      // (tile, index) per sample: implicit camera rays
     e |= W.alloc(samples * 4, &sc->d_accum);
     for (auto &L : sc->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
     e |= W.alloc(rays, &sc->d_hits);
@@ -1215,11 +1218,14 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     (void) hipMemsetAsync(sc->d_cnt, 0, sizeof(DCounters), st);
 
     // implicit camera rays (fjgpu_dev_shade.h): level 0 is rebuilt from the (u, v) table where it is needed
-    const bool implicit_cam = !adaptive && S.cam_xform == nullptr && !sc->uses_sample_uid && !getenv("FJGPU_EXPLICIT_CAMERA_RAYS");
+    // (scenes whose random streams are keyed by the sample's uid -- pathtracing shader, area lights -- get a (tile, index) table of 8 bytes per
+    // sample beside it; time-sampled motion keeps explicit rays: the walks read the sample's time from the path record)
+    const bool tk_cam = sc->uses_sample_uid && !S.has_motion && sc->d_stk != nullptr;
+    const bool implicit_cam = !adaptive && S.cam_xform == nullptr && (!sc->uses_sample_uid || tk_cam) && !getenv("FJGPU_EXPLICIT_CAMERA_RAYS");
     if (!adaptive) {
       rc = timed(st, &acc.gen_ms, [&]() {
         return launch_gen_camera(st, S, gp, sc->d_tiles, nb, max_ts, sc->d_jit, sc->d_tim, sc->d_suv,
-            implicit_cam ? nullptr : sc->levels[0].rays, implicit_cam ? nullptr : sc->levels[0].paths);
+            implicit_cam ? nullptr : sc->levels[0].rays, implicit_cam ? nullptr : sc->levels[0].paths, (implicit_cam && tk_cam) ? sc->d_stk : nullptr);
       });
       if (rc) break;
       acc.rays.camera += n_samples;
@@ -1265,7 +1271,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         (void) hipMemsetAsync(&sc->d_cnt->next_count, 0, sizeof(uint32_t) * 2, st);   // next_count + light_count
         // secondary rays leave the shading kernel in emission order: walk them in (octant, cell) order
         DScene St = S;
-        if (implicit) { St.cam_uv = sc->d_suv + 2 * (size_t) off; St.cam_slot0 = off; }
+        if (implicit) { St.cam_uv = sc->d_suv + 2 * (size_t) off; St.cam_slot0 = off; St.cam_tk = tk_cam ? sc->d_stk + 2 * (size_t) off : nullptr; }
         int e = 0;
         if (sc->ray_sort_bits > 0 && level >= 1 && (long) n >= g_ray_sort_min) {
           if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");   // (sized with the queues: cannot fail here)
@@ -1287,7 +1293,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
         shadow_pending[lb] = false;
         DScene Sl = S;
-        if (implicit) { Sl.cam_uv = St.cam_uv; Sl.cam_slot0 = off; }
+        if (implicit) { Sl.cam_uv = St.cam_uv; Sl.cam_slot0 = off; Sl.cam_tk = St.cam_tk; }
         Sl.lrec_hair = sc->d_lhair[lb];
         ShadeParams shl = shp;
         shl.next_keys = (can_emit && sc->ray_sort_bits > 0) ? sc->levels[level + 1].keys : nullptr;

@@ -82,7 +82,7 @@ __device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, 
 // Camera::GetRay (src/fj_camera.cc:79-110) with the host-built camera matrix.
 template <bool kMovingCamera>
 __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, const TileDesc *tiles,
-    const double *jitter_tab, const double *time_tab, double *s_uv, DRay *rays, DPath *paths)
+    const double *jitter_tab, const double *time_tab, double *s_uv, DRay *rays, DPath *paths, uint32_t *s_tk)
 {
   const TileDesc T = tiles[blockIdx.y];
   const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(BLOCK) k_gen_camera(DScene S, GenParams gp, co
   s_uv[2 * (size_t) slot + 1] = v;
   (void) time_tab;   // (the same table as S.time_tab)
 
-  if (!kMovingCamera && rays == nullptr) return;      // implicit camera rays: the (u, v) table is all that is needed
+  if (!kMovingCamera && rays == nullptr) {            // implicit camera rays: the (u, v) table is all that is needed ...
+    if (s_tk) { s_tk[2 * (size_t) slot] = (uint32_t) T.id; s_tk[2 * (size_t) slot + 1] = k; }      // ... and who the sample is, where a random stream asks
+    return;
+  }
   camera_ray<kMovingCamera>(S, u, v, T.id, k, slot, rays + slot, paths + slot);
 }
 
@@ -396,7 +399,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
   if (hit) {
     // (level 0 with implicit camera rays: nothing was written, ray and path state follow from the sample slot)
     const DRay r = rays ? rays[i] : implicit_camera_ray(S, i);
-    p = rays ? paths[i] : camera_path(S, S.cam_slot0 + i, 0u, 0u);
+    if (rays) p = paths[i];
+    else if (S.cam_tk) { const uint32_t tid_ = S.cam_tk[2 * (size_t) i], k_ = S.cam_tk[2 * (size_t) i + 1]; p = camera_path(S, S.cam_slot0 + i, k_, sample_uid((int32_t) tid_, k_)); }
+    else p = camera_path(S, S.cam_slot0 + i, 0u, 0u);
     sample = p.sample;
     rng = p.rng;
     uid = p.uid;

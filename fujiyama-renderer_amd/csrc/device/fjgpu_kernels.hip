@@ -262,11 +262,11 @@ static void timeline_dump(hipStream_t st, const char *kernel, unsigned waves)
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
 
 int launch_gen_camera(hipStream_t st, const DScene &S, const GenParams &gp, const TileDesc *d_tiles, int n_tiles,
-    uint32_t max_tile_samples, const double *jit, const double *tim, double *s_uv, DRay *rays, DPath *paths)
+    uint32_t max_tile_samples, const double *jit, const double *tim, double *s_uv, DRay *rays, DPath *paths, uint32_t *s_tk)
 {
   dim3 grid((max_tile_samples + BLOCK - 1) / BLOCK, n_tiles);
-  if (S.cam_xform) hipLaunchKernelGGL(k_gen_camera<true>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
-  else hipLaunchKernelGGL(k_gen_camera<false>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths);
+  if (S.cam_xform) hipLaunchKernelGGL(k_gen_camera<true>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths, s_tk);
+  else hipLaunchKernelGGL(k_gen_camera<false>, grid, dim3(BLOCK), 0, st, S, gp, d_tiles, jit, tim, s_uv, rays, paths, s_tk);
   LAUNCH_CHECK();
   return 0;
 }

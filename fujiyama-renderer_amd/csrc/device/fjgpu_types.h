@@ -275,6 +275,8 @@ struct DScene {
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
   const double *cam_uv;        // implicit camera rays: the (u, v) table of the batch's samples (sample slot = ray index of
                                // level 0; fjgpu_dev_shade.h) while level 0 is walked and shaded, else null
+  const uint32_t *cam_tk;      // ... in scenes whose random streams are keyed by the sample's uid (pathtracing shader, area lights): (tile id, index of
+                               // the sample in its tile), two words per sample slot of the batch: 8 bytes instead of the 48-byte path record; else null
   const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
                                // (hits are written to the ray's own slot); null = queue order
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
