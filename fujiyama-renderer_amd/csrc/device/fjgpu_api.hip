@@ -213,7 +213,7 @@ static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> 
       const DInstance &I = hs.instances[inst];
       const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
       if (ps.type != FJ_PRIMSET_MESH || ps.device_build || I.xform >= 0 || !ps.tri_vel.empty() || inst >= (1 << 24)) return false;
-      if (ps.n_prims > 0 && ps.tri_verts.empty() && ps.tri_verts32.empty()) return false;
+      if (ps.n_prims > 0 && ps.tri_verts32.empty()) return false;          // (the leaf records hold f32 triangles: exact only for such sets)
       total += (size_t) ps.n_prims;
     }
     if (total > (size_t) FJ_FLAT_MAX_TRIS) return false;
@@ -233,7 +233,7 @@ static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> 
         double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
         for (int v = 0; v < 3; v++) {
           double p[3];
-          for (int a = 0; a < 3; a++) p[a] = ps.tri_verts32.empty() ? ps.tri_verts[(size_t) k * 9 + 3 * v + a] : (double) ps.tri_verts32[(size_t) k * 9 + 3 * v + a];
+          for (int a = 0; a < 3; a++) p[a] = (double) ps.tri_verts32[(size_t) k * 9 + 3 * v + a];
           for (int a = 0; a < 3; a++) {
             const double w = I.M[4 * a] * p[0] + I.M[4 * a + 1] * p[1] + I.M[4 * a + 2] * p[2] + I.M[4 * a + 3];
             mn[a] = std::min(mn[a], w); mx[a] = std::max(mx[a], w);
@@ -253,8 +253,10 @@ static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> 
         r.id = (uint32_t) src.size();
         prs.push_back(r);
         DFlatRef fr;
+        for (int q = 0; q < 9; q++) fr.v[q] = ps.tri_verts32[(size_t) k * 9 + q];
         fr.inst_ord = ((uint32_t) inst << 8) | (uint32_t) pos;
-        fr.slot = (uint32_t) k;
+        fr.pid = ps.prim_ids[k];
+        fr.pad = 0;
         src.push_back(fr);
       }
     }

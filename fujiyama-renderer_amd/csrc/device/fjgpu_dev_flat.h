@@ -39,11 +39,18 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
   uint32_t best_ord = 0;
   bool anyhit = false;
   const FJ_GLOBAL char *nodes = nullptr;
-  const FJ_GLOBAL uint2 *refs = nullptr;       // DFlatRef as two words
+  const FJ_GLOBAL fj_v4u *refs = nullptr;      // DFlatRef records: three 16-byte words each
   const double *refbox = nullptr;
   uint32_t fl_pass = 0, fl_fail = 0;       // instances (by position in the group) whose own box and -0.0 rule this ray passed / failed
   uint32_t cur = TRAV_DONE;
   int sp = 0;
+#ifdef FJ_PHASE_STATS
+  // wave-level clock ticks, executions and lanes per phase (the slots of traverse_phased: debug_phase_stats prints them)
+  unsigned long long pcyc[3] = {0, 0, 0}, pex[3] = {0, 0, 0}, pln[3] = {0, 0, 0}, pc_prev = __builtin_readcyclecounter();
+#define FJ_FCYC(k, mask) do { const unsigned long long c_now = __builtin_readcyclecounter(); pcyc[k] += c_now - pc_prev; pc_prev = c_now; pex[k]++; pln[k] += __popcll(mask); } while (0)
+#else
+#define FJ_FCYC(k, mask) do { } while (0)
+#endif
 
   for (;;) {
     const bool fin = cur == TRAV_DONE;
@@ -54,7 +61,15 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
 
     if ((unsigned) __popcll(m_turn) >= tune.refill_flat || (n_inner == 0 && n_leaf == 0)) {
-      if (m_turn == 0ull) break;
+      if (m_turn == 0ull) {
+#ifdef FJ_PHASE_STATS
+        if (lane == 0) {
+          for (int k = 0; k < 3; k++) { atomicAdd(&g_phase[1 + 2 * k], pcyc[k]); atomicAdd(&g_phase[2 + 2 * k], pln[k]); atomicAdd(&g_phase[7 + k], pex[k]); }
+          atomicAdd(&g_phase[10], pex[0]); atomicAdd(&g_phase[11], pex[0]);
+        }
+#endif
+        break;
+      }
       // ---- turnover: retire, fetch, set up the walk
       if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
       if (fin && have) { pol.finish(idx, best); have = false; }
@@ -75,7 +90,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
           fresh = have;
           if (fresh) {
             const DFlat *F = &S.flats[r.group];
-            nodes = (const FJ_GLOBAL char *) F->nodes; refs = (const FJ_GLOBAL uint2 *) F->refs; refbox = F->refbox;
+            nodes = (const FJ_GLOBAL char *) F->nodes; refs = (const FJ_GLOBAL fj_v4u *) F->refs; refbox = F->refbox;
             // BoxRayIntersect's -0.0 quirk: every box test of the reference fails for such a ray -- it hits nothing
             if (!has_negative_zero(d) && F->n_prims > 0) {
               const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
@@ -87,6 +102,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
       }
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
+      FJ_FCYC(0, m_turn);
       continue;
     }
 
@@ -123,6 +139,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
             if (nh > 1) stk.push(sp, r1);
           }
         }
+        FJ_FCYC(1, __ballot(in_now));
       }
     } else {
       // ---- leaves: ONE candidate (instance, triangle) per lane
@@ -130,7 +147,8 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
         const uint32_t first = (cur & 0x7fffffffu) >> 3;
         const uint32_t more = cur & 7u;
         bool stop = false;
-        const uint32_t ref_io = refs[first].x, ref_slot = refs[first].y;
+        const fj_v4u q0 = refs[3 * (size_t) first], q1 = refs[3 * (size_t) first + 1], q2 = refs[3 * (size_t) first + 2];
+        const uint32_t ref_io = q2.y;
         const uint32_t inst = ref_io >> 8, ord = ref_io & 255u, bit = 1u << ord;
         if (!(fl_fail & bit)) {
           const DInstEntry *E = &gents[inst];
@@ -146,10 +164,11 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
           if (ok) {
             double t, u = 0, v = 0;
             if (kCount) lc->prims++;
-            V3 v0, v1, v2;
-            load_tri(E->tri_verts, E->tri_verts32, ref_slot, &v0, &v1, &v2);
-            if (tri_ray(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
-              const int pid = (int) FJ_G(uint32_t, E->prim_ids)[ref_slot];
+            const V3 v0 = mk((double) __uint_as_float(q0.x), (double) __uint_as_float(q0.y), (double) __uint_as_float(q0.z));
+            const V3 v1 = mk((double) __uint_as_float(q0.w), (double) __uint_as_float(q1.x), (double) __uint_as_float(q1.y));
+            const V3 v2 = mk((double) __uint_as_float(q1.z), (double) __uint_as_float(q1.w), (double) __uint_as_float(q2.x));
+            if (tri_ray_early(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
+              const int pid = (int) q2.z;
               if (t < best.t || (t == best.t && best.inst >= 0 && (ord < best_ord || (ord == best_ord && pid > best.prim)))) {
                 best.t = t; best.u = u; best.v = v; best.inst = (int) inst; best.prim = pid; best_ord = ord;
                 stop = anyhit;
@@ -161,8 +180,10 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (sp == 0) ? TRAV_DONE : stk.pop(sp);
       }
+      FJ_FCYC(2, __ballot(at_leaf));
     }
   }
+#undef FJ_FCYC
 }
 
 #ifndef FJ_FLAT_MINB

@@ -371,6 +371,36 @@ __device__ __forceinline__ bool tri_ray(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, do
   return true;
 }
 
+// The same decision and the same t, u, v with the misses settled before the division where the reference's own arithmetic provably rejects
+// (the rules of tri_ray_anyhit, fjgpu_dev_anyhit.h): u = U * fl(1 / det) < 0 when U and det differ in sign and the product cannot underflow
+// (|U| > 1e-100 |det|); u > 1 when |U| > |det| (1 + 1e-10); the same for v.  Whatever is left takes tri_ray's statements as they are.
+__device__ __forceinline__ bool tri_ray_early(V3 v0, V3 v1, V3 v2, V3 orig, V3 dir, double *t, double *u, double *v)
+{
+  const V3 edge1 = v1 - v0;
+  const V3 edge2 = v2 - v0;
+  const V3 pvec = cross(dir, edge2);
+  const double det = dot(edge1, pvec);
+  if (det > -1e-6 && det < 1e-6) return false;
+  const double adet = fabs(det);
+  const V3 tvec = orig - v0;
+  const double U = dot(tvec, pvec);
+  const double aU = fabs(U);
+  if (((U < 0.0) != (det < 0.0)) ? aU > 1e-100 * adet : aU > adet * (1.0 + 1e-10)) return false;
+  const V3 qvec = cross(tvec, edge1);
+  const double V = dot(dir, qvec);
+  const double aV = fabs(V);
+  if (((V < 0.0) != (det < 0.0)) ? aV > 1e-100 * adet : aV > adet * (1.0 + 1e-10)) return false;
+  const double inv_det = 1.0 / det;
+  const double uu = U * inv_det;
+  if (uu < 0.0 || uu > 1.0) return false;
+  const double vv = V * inv_det;
+  if (vv < 0.0 || uu + vv > 1.0) return false;
+  *t = dot(edge2, qvec) * inv_det;
+  *u = uu;
+  *v = vv;
+  return true;
+}
+
 // ----------------------------------------------------------------- traversal
 struct Best { double t, u, v; int inst, prim; };
 

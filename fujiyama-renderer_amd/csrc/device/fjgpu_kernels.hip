@@ -207,8 +207,8 @@ static TravTune trav_tune()
     t.min_inner_canyhit = env("FJGPU_TRAV_MININNER_CANYHIT", 16);
     // the walk of flat groups (fjgpu_dev_flat.h); C4 frame, refill / steps / min: 40 / 5 / 12 672 ms, 32 / 8 / 12 and no ray sort 638
     t.refill_flat = env("FJGPU_TRAV_REFILL_FLAT", 32);
-    t.steps_flat = env("FJGPU_TRAV_STEPS_FLAT", 8);
-    t.min_inner_flat = env("FJGPU_TRAV_MININNER_FLAT", 8);
+    t.steps_flat = env("FJGPU_TRAV_STEPS_FLAT", 12);
+    t.min_inner_flat = env("FJGPU_TRAV_MININNER_FLAT", 12);
     t.leaf_wait_canyhit = env("FJGPU_TRAV_LEAFWAIT_CANYHIT", 56);
     t.leaf_wait = env("FJGPU_TRAV_LEAFWAIT", 40);   // curve scenes: lanes awaiting the second stage of the ribbon test before it runs
     if (t.refill < 1) t.refill = 1;

@@ -201,7 +201,10 @@ struct DGroup {
 // static meshes (the walls and objects of a Cornell box) gets ONE world-space culling tree over the triangles of all of them: a ray walks that
 // tree once instead of looping over the instances, and a leaf names (instance, triangle) -- the exact tests stay what they are, in the
 // instance's object space with its M^-1, after the reference's own instance box has been passed (once per ray and instance).
-struct DFlatRef { uint32_t inst_ord; uint32_t slot; };     // (instance << 8) | position of the instance in the group's visiting order; leaf-order slot in ITS set
+// one leaf slot of the flat tree, 48 bytes = three 16-byte loads: the triangle in its instance's OBJECT space (f32, exact: only sets whose
+// coordinates are all representable in f32 are flattened), (instance << 8) | position of the instance in the group's visiting order, primitive id
+struct DFlatRef { float v[9]; uint32_t inst_ord; uint32_t pid; uint32_t pad; };
+static_assert(sizeof(DFlatRef) == 48, "DFlatRef must be 48 bytes");
 struct DFlat {
   const DNodeQ *nodes;         // quantised 4-wide tree over the world-space boxes of the triangles
   const DFlatRef *refs;        // [n_prims], leaf order of that tree
