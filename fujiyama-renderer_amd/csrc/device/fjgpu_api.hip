@@ -196,40 +196,50 @@ static const char *bad_render(const fj_render_desc *r)
 #ifndef FJ_FLAT_MAX_TRIS
 #define FJ_FLAT_MAX_TRIS (1 << 21)
 #endif
+#ifndef FJ_FLAT_SHADOW_MAX_TRIS
+#define FJ_FLAT_SHADOW_MAX_TRIS (48 << 20)       // (C2: 17.4 M triangles: 0.8 GB of leaf records + 0.4 GB of nodes)
+#endif
 struct HostFlat { fjgpu::HostPrimSet tree; std::vector<DFlatRef> refs; std::vector<double> refbox; double grid[6]; };
-static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> *out)
+// one group: false if it cannot be flattened (an instance that is not a static, host-built, f32-exact mesh; more than 32 instances or max_tris triangles)
+static bool build_flat_group(const fjgpu::HostScene &hs, size_t g, size_t max_tris, HostFlat *Fp)
 {
-  out->clear();
-  if (hs.groups.empty() || !hs.xforms.empty()) return false;
-  std::vector<HostFlat> flats(hs.groups.size());
-  for (size_t g = 0; g < hs.groups.size(); g++) {
-    const DGroup &G = hs.groups[g];
-    // the instances in the order the walks (and the reference's BVH) visit them: the leaves of the threaded instance level
-    std::vector<int> order;
-    for (int k = G.first; k < G.first + G.count; k++) if (hs.group_nodes[k].inst >= 0) order.push_back(hs.group_nodes[k].inst);
-    if (order.empty() || order.size() > 32 || (int) order.size() != G.n_instances) return false;
-    size_t total = 0;
-    for (int inst : order) {
-      const DInstance &I = hs.instances[inst];
-      const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
-      if (ps.type != FJ_PRIMSET_MESH || ps.device_build || I.xform >= 0 || !ps.tri_vel.empty() || inst >= (1 << 24)) return false;
-      if (ps.n_prims > 0 && ps.tri_verts32.empty()) return false;          // (the leaf records hold f32 triangles: exact only for such sets)
-      total += (size_t) ps.n_prims;
-    }
-    if (total > (size_t) FJ_FLAT_MAX_TRIS) return false;
-    HostFlat &F = flats[g];
-    std::vector<fjgpu::PrimRef> prs;
-    prs.reserve(total);
-    double gmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, gmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    std::vector<DFlatRef> src;
-    src.reserve(total);
-    for (size_t pos = 0; pos < order.size(); pos++) {
-      const int inst = order[pos];
-      const DInstance &I = hs.instances[inst];
-      const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
-      const double *rb = order.size() == 1 ? G.sbounds : I.wbounds;
-      for (int k = 0; k < 6; k++) F.refbox.push_back(rb[k]);
-      for (int k = 0; k < ps.n_prims; k++) {
+  const DGroup &G = hs.groups[g];
+  // the instances in the order the walks (and the reference's BVH) visit them: the leaves of the threaded instance level
+  std::vector<int> order;
+  for (int k = G.first; k < G.first + G.count; k++) if (hs.group_nodes[k].inst >= 0) order.push_back(hs.group_nodes[k].inst);
+  if (order.empty() || order.size() > 32 || (int) order.size() != G.n_instances) return false;
+  size_t total = 0;
+  std::vector<size_t> first_ref(order.size() + 1, 0);
+  for (size_t pos = 0; pos < order.size(); pos++) {
+    const int inst = order[pos];
+    const DInstance &I = hs.instances[inst];
+    const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
+    if (ps.type != FJ_PRIMSET_MESH || ps.device_build || I.xform >= 0 || !ps.tri_vel.empty() || inst >= (1 << 24)) return false;
+    if (ps.n_prims > 0 && ps.tri_verts32.empty()) return false;          // (the leaf records hold f32 triangles: exact only for such sets)
+    first_ref[pos] = total;
+    total += (size_t) ps.n_prims;
+  }
+  first_ref[order.size()] = total;
+  if (total > max_tris || total >= ((size_t) 1 << 28)) return false;
+  HostFlat &F = *Fp;
+  std::vector<fjgpu::PrimRef> prs(total);
+  std::vector<DFlatRef> src(total);
+  double gmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, gmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  bool finite = true;
+  for (size_t pos = 0; pos < order.size(); pos++) {
+    const int inst = order[pos];
+    const DInstance &I = hs.instances[inst];
+    const fjgpu::HostPrimSet &ps = hs.primsets[I.primset];
+    const double *rb = order.size() == 1 ? G.sbounds : I.wbounds;
+    for (int k = 0; k < 6; k++) F.refbox.push_back(rb[k]);
+    const size_t base = first_ref[pos];
+    const int n = ps.n_prims;
+    // (threads over the triangles of the instance: C2's group is 17.4 M of them)
+    const unsigned hc = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    std::vector<char> bad(hc, 0);
+    for (unsigned t = 0; t < hc; t++) th.emplace_back([&, t]() {
+      for (int k = (int) ((size_t) n * t / hc); k < (int) ((size_t) n * (t + 1) / hc); k++) {
         double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
         for (int v = 0; v < 3; v++) {
           double p[3];
@@ -243,34 +253,48 @@ static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> 
         for (int a = 0; a < 3; a++) {
           // the exact test runs in object space: its hit point, carried to the world by o + t d, lies on the image of the triangle up to the
           // roundings of M v and M^-1 (o, d) -- a relative 1e-9 (and 1e-12 absolute) covers them many times over
-          if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return false;
+          if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { bad[t] = 1; mn[a] = mx[a] = 0; }
           const double pad = 1e-9 * (std::fabs(mn[a]) + std::fabs(mx[a])) + 1e-12;
           r.bmin[a] = fjgpu::RoundDown2(mn[a] - pad);
           r.bmax[a] = fjgpu::RoundUp2(mx[a] + pad);
           r.c[a] = (float) (.5 * (mn[a] + mx[a]));
-          gmn[a] = std::min(gmn[a], (double) r.bmin[a]); gmx[a] = std::max(gmx[a], (double) r.bmax[a]);
         }
-        r.id = (uint32_t) src.size();
-        prs.push_back(r);
+        r.id = (uint32_t) (base + (size_t) k);
+        prs[base + (size_t) k] = r;
         DFlatRef fr;
         for (int q = 0; q < 9; q++) fr.v[q] = ps.tri_verts32[(size_t) k * 9 + q];
         fr.inst_ord = ((uint32_t) inst << 8) | (uint32_t) pos;
         fr.pid = ps.prim_ids[k];
         fr.pad = 0;
-        src.push_back(fr);
+        src[base + (size_t) k] = fr;
       }
-    }
-    F.tree.type = FJ_PRIMSET_MESH; F.tree.device_build = false; F.tree.f32_exact = false; F.tree.mesh = nullptr; F.tree.curve = nullptr;
-    fjgpu::BuildBlas(&F.tree, prs, FJ_MAX_LEAF_PRIMS, 1.2f);
-    F.refs.resize(src.size());
-    for (size_t sl = 0; sl < src.size(); sl++) F.refs[sl] = src[F.tree.prim_ids[sl]];
-    for (int a = 0; a < 3; a++) {
-      if (total == 0) { gmn[a] = 0; gmx[a] = 1; }
-      const double pad = 1e-4 * std::max(1., gmx[a] - gmn[a]);
-      F.grid[a] = gmn[a] - pad;
-      F.grid[3 + a] = std::max(1e-300, (gmx[a] - gmn[a] + 2 * pad) / 65535. * (1 + 1e-9));
-    }
+    });
+    for (auto &t : th) t.join();
+    for (char b : bad) if (b) finite = false;
   }
+  if (!finite) return false;
+  for (const fjgpu::PrimRef &r : prs)
+    for (int a = 0; a < 3; a++) { gmn[a] = std::min(gmn[a], (double) r.bmin[a]); gmx[a] = std::max(gmx[a], (double) r.bmax[a]); }
+  F.tree.type = FJ_PRIMSET_MESH; F.tree.device_build = false; F.tree.f32_exact = false; F.tree.mesh = nullptr; F.tree.curve = nullptr;
+  fjgpu::BuildBlas(&F.tree, prs, FJ_MAX_LEAF_PRIMS, 1.2f);
+  F.refs.resize(src.size());
+  for (size_t sl = 0; sl < src.size(); sl++) F.refs[sl] = src[F.tree.prim_ids[sl]];
+  for (int a = 0; a < 3; a++) {
+    if (total == 0) { gmn[a] = 0; gmx[a] = 1; }
+    const double pad = 1e-4 * std::max(1., gmx[a] - gmn[a]);
+    F.grid[a] = gmn[a] - pad;
+    F.grid[3 + a] = std::max(1e-300, (gmx[a] - gmn[a] + 2 * pad) / 65535. * (1 + 1e-9));
+    F.tree.bounds[a] = gmn[a] - pad; F.tree.bounds[3 + a] = gmx[a] + pad;
+  }
+  return true;
+}
+// every group of the scene, or none
+static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> *out)
+{
+  out->clear();
+  if (hs.groups.empty() || !hs.xforms.empty()) return false;
+  std::vector<HostFlat> flats(hs.groups.size());
+  for (size_t g = 0; g < hs.groups.size(); g++) if (!build_flat_group(hs, g, (size_t) FJ_FLAT_MAX_TRIS, &flats[g])) return false;
   out->swap(flats);
   return true;
 }
@@ -281,6 +305,7 @@ static long g_device_tlas = 1;     // "device_tlas": the instance level of every
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
+static long g_flat_shadow = 1;     // "flat_shadow": ... and shadow target groups of several small static meshes, in scenes the lean any-hit walk serves, one for their shadow rays
 static long g_flat_groups = 1;     // "flat_groups": scenes with incoherent closest-hit rays whose groups hold only small static meshes walk ONE world-space tree per group
 static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
@@ -300,6 +325,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
   if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
   if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
+  if (std::string(name) == "flat_shadow") { g_flat_shadow = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
@@ -433,6 +459,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   }
   DScene &S = sc->S;
   std::memset(&S, 0, sizeof(S));
+  int flat_shadow_stack_need = 0, flat_shadow_groups = 0;
+  std::vector<char> flat_group_is_shadow_flat;
   {
     // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
     // grid = 65536^3 cells over the primitive set's padded bounds
@@ -523,9 +551,48 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       }
       e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
     }
+    // FLAT SHADOW groups (DScene.flat_shadow): shadow target groups of several small static meshes that can receive shadow rays, in scenes the
+    // lean any-hit walk serves, get one world-space culling tree each
+    struct FlatDev { const DNodeQ *q; const DFlatRef *refs; double grid[6]; double bounds[6]; uint32_t root; int n_prims; int group; int stack_need; };
+    std::vector<FlatDev> fdev;
+    {
+      bool lean = true;
+      for (const auto &g : hs.groups) if (!g.all_opaque) lean = false;
+      for (const auto &ps : hs.primsets) if ((ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) || !ps.tri_vel.empty() || !ps.curve_vel.empty()) lean = false;
+      if (!hs.xforms.empty()) lean = false;
+      std::vector<char> target(hs.groups.size(), 0);
+      for (const DInstance &I : hs.instances) {
+        bool gathers = false;
+        for (int k = 0; k < I.n_shaders; k++)
+          if (I.shaders[k] >= 0 && (hs.shaders[I.shaders[k]].type == FJ_SHADER_PLASTIC || hs.shaders[I.shaders[k]].type == FJ_SHADER_HAIR)) gathers = true;
+        if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1) target[I.shadow_target] = 1;
+      }
+      for (size_t g = 0; lean && g_flat_shadow && !getenv("FJGPU_NO_FLAT_SHADOW") && !e && g < hs.groups.size(); g++) {
+        if (!target[g]) continue;
+        HostFlat F;
+        if (!build_flat_group(hs, g, (size_t) FJ_FLAT_SHADOW_MAX_TRIS, &F)) continue;
+        FlatDev D;
+        std::memset(&D, 0, sizeof(D));
+        const DNode *d_nodes = nullptr;
+        const size_t n_nodes = std::max<size_t>(1, F.tree.nodes.size());
+        e |= M.upload(F.tree.nodes.data(), n_nodes, &d_nodes);
+        DNodeQ *q = nullptr;
+        if (!e && M.alloc(n_nodes, &q)) e = 1;
+        if (!e && launch_quantize_nodes(nullptr, d_nodes, (uint32_t) n_nodes, &F.grid[0], &F.grid[3], q)) e = 1;
+        D.q = q;
+        e |= M.upload(F.refs.data(), F.refs.size(), &D.refs);
+        for (int k = 0; k < 6; k++) { D.grid[k] = F.grid[k]; D.bounds[k] = F.tree.bounds[k]; }
+        D.root = F.tree.root; D.n_prims = F.tree.n_prims; D.group = (int) g; D.stack_need = F.tree.stack_need;
+        if (!e) fdev.push_back(D);
+      }
+      if (!fdev.empty()) lap("flat shadow groups");
+    }
     // flat per-instance records of that walk (static mesh instances): node and triangle arrays
     // as 32-bit offsets from the lowest of their addresses
     uintptr_t lo = UINTPTR_MAX, hi = 0;
+    for (const FlatDev &D : fdev) {
+      lo = std::min(lo, std::min((uintptr_t) D.q, (uintptr_t) D.refs)); hi = std::max(hi, std::max((uintptr_t) D.q, (uintptr_t) D.refs));
+    }
     auto tris_of = [](const DPrimSet &P) { return (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts); };
     for (size_t i = 0; i < dps.size(); i++) {
       const DPrimSet &P = dps[i];
@@ -545,7 +612,32 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     S.blas_base = fits ? (const char *) lo : nullptr;
     if (!fits && lo != UINTPTR_MAX && getenv("FJGPU_VERBOSE"))
       fprintf(stderr, "fjgpu: BLAS arrays span %zu bytes from %p: no 32-bit offsets, the general shadow walk is used\n", (size_t) (hi - lo), (void *) lo);
-    std::vector<DAnyInst> ai(hs.instances.size());
+    for (const FlatDev &D : fdev) if (((uintptr_t) D.q - lo) % 128 != 0 || ((uintptr_t) D.refs - lo) % 128 != 0) fits = false;
+    if (!fits) { S.blas_base = nullptr; fdev.clear(); }
+    std::vector<DAnyInst> ai(hs.instances.size() + fdev.size());
+    // (the pseudo records of the flat shadow groups follow the instances': identity transform -- the walk keeps the WORLD ray as the "object-space" one --,
+    // the tree, the leaf records; tris_f32 = 2 marks them)
+    std::vector<DFlatShadow> fsh(hs.groups.size());
+    for (auto &f : fsh) { std::memset(&f, 0, sizeof(f)); f.pseudo_inst = -1; }
+    for (size_t k = 0; k < fdev.size(); k++) {
+      const FlatDev &D = fdev[k];
+      DAnyInst &a = ai[hs.instances.size() + k];
+      std::memset(&a, 0, sizeof(a));
+      a.Minv[0] = a.Minv[5] = a.Minv[10] = 1.;
+      std::memcpy(a.bounds, D.bounds, sizeof(a.bounds));
+      for (int q = 0; q < 3; q++) { a.qorigin[q] = D.grid[q]; a.qcell[q] = D.grid[3 + q]; }
+      a.node_base = (uint32_t) (((uintptr_t) D.q - lo) / 128);
+      a.tri_base = (uint32_t) (((uintptr_t) D.refs - lo) / 128);
+      a.root = D.root; a.tris_f32 = 2; a.n_prims = D.n_prims;
+      std::memcpy(fsh[D.group].bounds, D.bounds, sizeof(D.bounds));
+      fsh[D.group].pseudo_inst = (int32_t) (hs.instances.size() + k);
+      flat_shadow_stack_need = std::max(flat_shadow_stack_need, D.stack_need);
+    }
+    S.flat_shadow = nullptr;
+    if (!fdev.empty()) e |= M.upload(fsh.data(), fsh.size(), &S.flat_shadow);
+    flat_shadow_groups = (int) fdev.size();
+    flat_group_is_shadow_flat.assign(hs.groups.size(), 0);
+    for (const FlatDev &D : fdev) flat_group_is_shadow_flat[D.group] = 1;
     for (size_t i = 0; i < hs.instances.size(); i++) {
       const DInstance &I = hs.instances[i];
       const DPrimSet &P = dps[I.primset];
@@ -609,7 +701,8 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     bool gathers = false;
     for (int k = 0; k < I.n_shaders; k++)
       if (I.shaders[k] >= 0 && (hs.shaders[I.shaders[k]].type == FJ_SHADER_PLASTIC || hs.shaders[I.shaders[k]].type == FJ_SHADER_HAIR)) gathers = true;
-    if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1)
+    if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1 &&
+        !(flat_shadow_groups && flat_group_is_shadow_flat[I.shadow_target]))
       S.multi_shadow_groups = 1;
   }
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
@@ -662,7 +755,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   // traversal stack: entries beyond the LDS part live in a global overflow area sized for
   // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
   {
-    int need = S.flats ? flat_stack_need : 0;
+    int need = std::max(S.flats ? flat_stack_need : 0, flat_shadow_stack_need);
     for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;

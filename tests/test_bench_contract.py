@@ -40,7 +40,7 @@ def test_bench_line_has_the_contract_fields():
     else:
         assert r["uncalibrated"] is True and "UNCALIBRATED" in r["frac_source"]
     # the dominant kernel by measured time, named; the SURVEY 8(d) bytes are kept apart
-    assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_trace", "k_trace_closest", "k_trace_closest_phased")
+    assert r["kernel"] in ("k_shadow_anyhit", "k_shadow_anyhit_curves", "k_shadow_trace", "k_trace_closest", "k_trace_closest_phased", "k_trace_closest_flat")
     assert r["launches"] >= 1 and r["avg_launch_ms"] > 0 and r["algorithmic"]["bytes_per_launch"] > 0
     assert max(r["kernel_ms_per_frame_rank0"], key=lambda k: r["kernel_ms_per_frame_rank0"][k] if k.startswith("k_trace") or k.startswith("k_shadow_a") or k.startswith("k_shadow_t") else -1) == r["kernel"]
     c = d["cpu_baseline"]
