@@ -196,9 +196,7 @@ static const char *bad_render(const fj_render_desc *r)
 #ifndef FJ_FLAT_MAX_TRIS
 #define FJ_FLAT_MAX_TRIS (1 << 21)
 #endif
-#ifndef FJ_FLAT_SHADOW_MAX_TRIS
-#define FJ_FLAT_SHADOW_MAX_TRIS (48 << 20)       // (C2: 17.4 M triangles: 0.8 GB of leaf records + 0.4 GB of nodes)
-#endif
+
 struct HostFlat { fjgpu::HostPrimSet tree; std::vector<DFlatRef> refs; std::vector<double> refbox; double grid[6]; };
 // one group: false if it cannot be flattened (an instance that is not a static, host-built, f32-exact mesh; more than 32 instances or max_tris triangles)
 static bool build_flat_group(const fjgpu::HostScene &hs, size_t g, size_t max_tris, HostFlat *Fp)
@@ -305,7 +303,6 @@ static long g_device_tlas = 1;     // "device_tlas": the instance level of every
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
-static long g_flat_shadow = 1;     // "flat_shadow": ... and shadow target groups of several small static meshes, in scenes the lean any-hit walk serves, one for their shadow rays
 static long g_flat_groups = 1;     // "flat_groups": scenes with incoherent closest-hit rays whose groups hold only small static meshes walk ONE world-space tree per group
 static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
@@ -325,7 +322,6 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
   if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
   if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
-  if (std::string(name) == "flat_shadow") { g_flat_shadow = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
@@ -459,8 +455,6 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   }
   DScene &S = sc->S;
   std::memset(&S, 0, sizeof(S));
-  int flat_shadow_stack_need = 0, flat_shadow_groups = 0;
-  std::vector<char> flat_group_is_shadow_flat;
   {
     // quantised node arrays of the lean any-hit walk (DNodeQ): one per mesh, same node indices;
     // grid = 65536^3 cells over the primitive set's padded bounds
@@ -551,48 +545,9 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       }
       e |= M.upload(ie.data(), ie.size(), &S.inst_entries);
     }
-    // FLAT SHADOW groups (DScene.flat_shadow): shadow target groups of several small static meshes that can receive shadow rays, in scenes the
-    // lean any-hit walk serves, get one world-space culling tree each
-    struct FlatDev { const DNodeQ *q; const DFlatRef *refs; double grid[6]; double bounds[6]; uint32_t root; int n_prims; int group; int stack_need; };
-    std::vector<FlatDev> fdev;
-    {
-      bool lean = true;
-      for (const auto &g : hs.groups) if (!g.all_opaque) lean = false;
-      for (const auto &ps : hs.primsets) if ((ps.type == FJ_PRIMSET_CURVE && ps.n_prims > 0) || !ps.tri_vel.empty() || !ps.curve_vel.empty()) lean = false;
-      if (!hs.xforms.empty()) lean = false;
-      std::vector<char> target(hs.groups.size(), 0);
-      for (const DInstance &I : hs.instances) {
-        bool gathers = false;
-        for (int k = 0; k < I.n_shaders; k++)
-          if (I.shaders[k] >= 0 && (hs.shaders[I.shaders[k]].type == FJ_SHADER_PLASTIC || hs.shaders[I.shaders[k]].type == FJ_SHADER_HAIR)) gathers = true;
-        if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1) target[I.shadow_target] = 1;
-      }
-      for (size_t g = 0; lean && g_flat_shadow && !getenv("FJGPU_NO_FLAT_SHADOW") && !e && g < hs.groups.size(); g++) {
-        if (!target[g]) continue;
-        HostFlat F;
-        if (!build_flat_group(hs, g, (size_t) FJ_FLAT_SHADOW_MAX_TRIS, &F)) continue;
-        FlatDev D;
-        std::memset(&D, 0, sizeof(D));
-        const DNode *d_nodes = nullptr;
-        const size_t n_nodes = std::max<size_t>(1, F.tree.nodes.size());
-        e |= M.upload(F.tree.nodes.data(), n_nodes, &d_nodes);
-        DNodeQ *q = nullptr;
-        if (!e && M.alloc(n_nodes, &q)) e = 1;
-        if (!e && launch_quantize_nodes(nullptr, d_nodes, (uint32_t) n_nodes, &F.grid[0], &F.grid[3], q)) e = 1;
-        D.q = q;
-        e |= M.upload(F.refs.data(), F.refs.size(), &D.refs);
-        for (int k = 0; k < 6; k++) { D.grid[k] = F.grid[k]; D.bounds[k] = F.tree.bounds[k]; }
-        D.root = F.tree.root; D.n_prims = F.tree.n_prims; D.group = (int) g; D.stack_need = F.tree.stack_need;
-        if (!e) fdev.push_back(D);
-      }
-      if (!fdev.empty()) lap("flat shadow groups");
-    }
     // flat per-instance records of that walk (static mesh instances): node and triangle arrays
     // as 32-bit offsets from the lowest of their addresses
     uintptr_t lo = UINTPTR_MAX, hi = 0;
-    for (const FlatDev &D : fdev) {
-      lo = std::min(lo, std::min((uintptr_t) D.q, (uintptr_t) D.refs)); hi = std::max(hi, std::max((uintptr_t) D.q, (uintptr_t) D.refs));
-    }
     auto tris_of = [](const DPrimSet &P) { return (uintptr_t) (P.tri_verts32 ? (const void *) P.tri_verts32 : (const void *) P.tri_verts); };
     for (size_t i = 0; i < dps.size(); i++) {
       const DPrimSet &P = dps[i];
@@ -612,32 +567,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     S.blas_base = fits ? (const char *) lo : nullptr;
     if (!fits && lo != UINTPTR_MAX && getenv("FJGPU_VERBOSE"))
       fprintf(stderr, "fjgpu: BLAS arrays span %zu bytes from %p: no 32-bit offsets, the general shadow walk is used\n", (size_t) (hi - lo), (void *) lo);
-    for (const FlatDev &D : fdev) if (((uintptr_t) D.q - lo) % 128 != 0 || ((uintptr_t) D.refs - lo) % 128 != 0) fits = false;
-    if (!fits) { S.blas_base = nullptr; fdev.clear(); }
-    std::vector<DAnyInst> ai(hs.instances.size() + fdev.size());
-    // (the pseudo records of the flat shadow groups follow the instances': identity transform -- the walk keeps the WORLD ray as the "object-space" one --,
-    // the tree, the leaf records; tris_f32 = 2 marks them)
-    std::vector<DFlatShadow> fsh(hs.groups.size());
-    for (auto &f : fsh) { std::memset(&f, 0, sizeof(f)); f.pseudo_inst = -1; }
-    for (size_t k = 0; k < fdev.size(); k++) {
-      const FlatDev &D = fdev[k];
-      DAnyInst &a = ai[hs.instances.size() + k];
-      std::memset(&a, 0, sizeof(a));
-      a.Minv[0] = a.Minv[5] = a.Minv[10] = 1.;
-      std::memcpy(a.bounds, D.bounds, sizeof(a.bounds));
-      for (int q = 0; q < 3; q++) { a.qorigin[q] = D.grid[q]; a.qcell[q] = D.grid[3 + q]; }
-      a.node_base = (uint32_t) (((uintptr_t) D.q - lo) / 128);
-      a.tri_base = (uint32_t) (((uintptr_t) D.refs - lo) / 128);
-      a.root = D.root; a.tris_f32 = 2; a.n_prims = D.n_prims;
-      std::memcpy(fsh[D.group].bounds, D.bounds, sizeof(D.bounds));
-      fsh[D.group].pseudo_inst = (int32_t) (hs.instances.size() + k);
-      flat_shadow_stack_need = std::max(flat_shadow_stack_need, D.stack_need);
-    }
-    S.flat_shadow = nullptr;
-    if (!fdev.empty()) e |= M.upload(fsh.data(), fsh.size(), &S.flat_shadow);
-    flat_shadow_groups = (int) fdev.size();
-    flat_group_is_shadow_flat.assign(hs.groups.size(), 0);
-    for (const FlatDev &D : fdev) flat_group_is_shadow_flat[D.group] = 1;
+    std::vector<DAnyInst> ai(hs.instances.size());
     for (size_t i = 0; i < hs.instances.size(); i++) {
       const DInstance &I = hs.instances[i];
       const DPrimSet &P = dps[I.primset];
@@ -701,8 +631,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
     bool gathers = false;
     for (int k = 0; k < I.n_shaders; k++)
       if (I.shaders[k] >= 0 && (hs.shaders[I.shaders[k]].type == FJ_SHADER_PLASTIC || hs.shaders[I.shaders[k]].type == FJ_SHADER_HAIR)) gathers = true;
-    if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1 &&
-        !(flat_shadow_groups && flat_group_is_shadow_flat[I.shadow_target]))
+    if (gathers && I.shadow_target >= 0 && I.shadow_target < (int) hs.groups.size() && hs.groups[I.shadow_target].n_instances > 1)
       S.multi_shadow_groups = 1;
   }
   S.time_tab = nullptr; S.time_start = 0; S.time_end = 0;     // set per render call
@@ -755,7 +684,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   // traversal stack: entries beyond the LDS part live in a global overflow area sized for
   // the worst tree of the scene (usually none: stack_need <= FJ_STACK_LDS)
   {
-    int need = std::max(S.flats ? flat_stack_need : 0, flat_shadow_stack_need);
+    int need = S.flats ? flat_stack_need : 0;
     for (const auto &ps : hs.primsets) need = std::max(need, ps.stack_need);
     S.stack_overflow = nullptr;
     S.stack_overflow_shadow = nullptr;

@@ -214,8 +214,6 @@ struct DFlat {
   int32_t n_inst, n_prims, pad;
 };
 
-struct DFlatShadow { double bounds[6]; int32_t pseudo_inst; int32_t pad; };
-
 struct DTexture {
   const float *tiles;
   int32_t width, height, nchannels, tilesize;
@@ -262,11 +260,6 @@ struct DScene {
                                // single entry): (k << 16) | number of entries that reached the light so far.  The
                                // entry that completes the count adds the light; an occluded entry adds nothing.
   const DFlat *flats;              // [n_groups] when EVERY group of the scene is flat (k_trace_closest_flat walks them), else null
-  // FLAT SHADOW groups (scenes served by the lean any-hit walk): a shadow target group of several small static meshes gets one world-space
-  // culling tree too; the light loop treats it like a single-instance group (ONE box test, ONE queue entry: ~pseudo instance) and the walk
-  // tests its leaf records (DFlatRef) in object space, the instance's own box once per ray and instance.  [n_groups] or null; entry: the
-  // tree's padded bounds and the index of its pseudo record in any_insts (>= n_instances), -1 for a group that is not flat
-  const struct DFlatShadow *flat_shadow;
   const DAreaLight *area_lights;   // [n_lights] (entries of other light types unused) or null
   const DAnyInst *any_insts;       // [n_instances] (static mesh instances; the lean any-hit walk)
   const char *blas_base;           // lowest address of any BLAS node / triangle array (DAnyInst offsets); null: the
