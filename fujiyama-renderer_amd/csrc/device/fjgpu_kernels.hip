@@ -14,6 +14,7 @@
 //   fjgpu_dev_shadow.h    k_shadow_cull (SlIlluminance light loop), k_shadow_trace
 //   fjgpu_dev_anyhit.h    k_shadow_anyhit (lean any-hit walk: phase-scheduled, f32 slabs)
 //   fjgpu_dev_anyhit_curves.h  k_shadow_anyhit_curves (the same scheduling for scenes with curve sets: + a ribbon phase)
+//   fjgpu_dev_flat.h      k_trace_closest_flat (closest-hit walk of FLAT groups: one world-space culling tree per group, exact tests in object space)
 //   here                  k_resolve (reconstruct_image / apply_pixel_filter), host launchers
 #include <hip/hip_runtime.h>
 #include <float.h>
