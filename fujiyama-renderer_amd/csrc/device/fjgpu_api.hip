@@ -303,6 +303,7 @@ static long g_device_tlas = 1;     // "device_tlas": the instance level of every
 static long g_tlas_verify = 0;     // "tlas_verify": ... and compared node for node with the host's build (scene creation fails on a difference)
 static long g_split_shadow = 1;    // "split_shadow": shadow rays into groups of several instances are queued once per candidate instance
                                    // (C2: any-hit walk 91 -> 54 ms, the light loop that now lists every candidate 18 -> 41 ms, frame 134 -> 121)
+static long g_compact_squeue = 1;  // "compact_squeue": 56-byte shadow-queue records (DShadowRayC) where the walks can rebuild direction and distance
 static long g_flat_groups = 1;     // "flat_groups": scenes with incoherent closest-hit rays whose groups hold only small static meshes walk ONE world-space tree per group
 static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
@@ -322,6 +323,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
   if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
   if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
+  if (std::string(name) == "compact_squeue") { g_compact_squeue = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
@@ -1154,6 +1156,15 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   swp.cos_pi = std::cos(3.14159265358979323846);
   swp.pre_resolve = (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) ? 1 : 0;   // the lean any-hit walk consumes the queue
   swp.cast_shadow = r->cast_shadow;
+  // compact queue records (DShadowRayC) where the consumers rebuild direction and distance: the lean and the curve any-hit walk, point / dome lights, no motion
+  {
+    const bool lean = S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base;
+    const bool curve_walk = S.has_curves && !S.has_motion && S.all_opaque && S.curve_anyhit && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES_CURVES &&
+        S.n_instances <= FJ_INST_LDS_INSTS_CURVES && S.n_groups <= FJ_INST_LDS_GROUPS_CURVES && FJ_CURVE_QNODES && FJ_CLOSEST_QNODES;
+    S.compact_squeue = ((lean || curve_walk) && !S.has_area && g_compact_squeue && !getenv("FJGPU_NO_COMPACT_SQUEUE")) ? 1 : 0;
+    S.pad_cs_ = 0;
+  }
+  swp.compact = S.compact_squeue; swp.pad_ = 0;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
   swp.join_capacity = (swp.pre_resolve && sc->split_shadow && sc->d_join) ? (uint32_t) sc->join_cap : 0u;
   S.shadow_join = swp.join_capacity ? sc->d_join : nullptr;

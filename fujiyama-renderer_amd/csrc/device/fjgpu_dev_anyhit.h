@@ -176,17 +176,17 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (kMulti && gi < gend) fetch = false;    // the group has more instances: the same ray goes on
           else {
             // reached the light: add c (an opaque occluder would have added c * (1 - Os) = 0)
-            const DShadowRay *q = &squeue[idx];
             // one of k entries of a ray with k candidate instances: the light is added by the entry that completes
             // the count of those that reached it (DScene.shadow_join)
             bool add = true;
             if (!kMulti && S.shadow_join) {
-              const uint32_t slot1 = q->tindex;
+              const uint32_t slot1 = SQ_FIELD(S, squeue, idx, tindex);
               if (slot1) { const uint32_t old = atomicAdd(&S.shadow_join[slot1 - 1u], 1u); add = ((old & 0xffffu) + 1u) == (old >> 16); }
             }
             if (add) {
-              float *acc = s_accum + 4 * (size_t) q->sample;
-              const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
+              float *acc = s_accum + 4 * (size_t) SQ_FIELD(S, squeue, idx, sample);
+              const float *qc_ = sq_colour(S, squeue, idx);
+              const float r0 = qc_[0], r1 = qc_[1], r2 = qc_[2];
               if (r0 != 0.f) atomicAdd(acc + 0, r0);
               if (r1 != 0.f) atomicAdd(acc + 1, r1);
               if (r2 != 0.f) atomicAdd(acc + 2, r2);
@@ -202,8 +202,8 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       if (fetch) {
         const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t) (m_fetch >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_fetch, 0u));   // set bits below this lane
         if (my < range_end) {
-          const int g = squeue[my].group;
-          if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
+          const int g = SQ_FIELD(S, squeue, my, group);
+          if (SQ_FIELD(S, squeue, my, sample) != SQ_INVALID) {         // (padding slot of a partially filled chunk)
 #ifdef FJ_WAVE_TIMELINE
             ray_steps = 0;
 #endif
@@ -217,9 +217,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
       if (fin && have) {
-        const DShadowRay *q = &squeue[idx];
-        const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
-        const double tmax = q->tmax;
+        V3 o, d;
+        double tmax;
+        sq_ray(S, squeue, idx, &o, &d, &tmax);
         V3 winv = o;
         bool plain = false, single = false, dead = false;
         if (kMulti && gi >= 0) {
@@ -227,7 +227,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           dead = has_negative_zero(d);
           winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
           plain = plain_dir(d);
-          single = S.groups[q->group].n_instances == 1;
+          single = S.groups[SQ_FIELD(S, squeue, idx, group)].n_instances == 1;
           if (dead) gi = gend;
         }
         for (;;) {

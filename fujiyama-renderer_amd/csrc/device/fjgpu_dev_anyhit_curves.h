@@ -128,9 +128,9 @@ __device__ void traverse_anyhit_curves(const DScene &S, const DShadowRay *squeue
           if (ti < tend) fetch = false;    // the group has more instances: the same ray goes on
           else {
             // ran out of instances: the ray reaches the light (an opaque occluder would have added c * (1 - Os) = 0)
-            const DShadowRay *q = &squeue[idx];
-            float *acc = s_accum + 4 * (size_t) q->sample;
-            const float r0 = q->c[0], r1 = q->c[1], r2 = q->c[2];
+            float *acc = s_accum + 4 * (size_t) SQ_FIELD(S, squeue, idx, sample);
+            const float *qc_ = sq_colour(S, squeue, idx);
+            const float r0 = qc_[0], r1 = qc_[1], r2 = qc_[2];
             if (r0 != 0.f) atomicAdd(acc + 0, r0);
             if (r1 != 0.f) atomicAdd(acc + 1, r1);
             if (r2 != 0.f) atomicAdd(acc + 2, r2);
@@ -142,8 +142,8 @@ __device__ void traverse_anyhit_curves(const DScene &S, const DShadowRay *squeue
       if (fetch) {
         const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t) (m_fetch >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m_fetch, 0u));
         if (my < range_end) {
-          const int g = squeue[my].group;
-          if (squeue[my].sample != SQ_INVALID) {         // (padding slot of a partially filled chunk)
+          const int g = SQ_FIELD(S, squeue, my, group);
+          if (SQ_FIELD(S, squeue, my, sample) != SQ_INVALID) {         // (padding slot of a partially filled chunk)
             have = true;
             idx = my;
             ti = ggroups[g].first; tend = ti + ggroups[g].count;
@@ -153,10 +153,10 @@ __device__ void traverse_anyhit_curves(const DScene &S, const DShadowRay *squeue
       next += (uint32_t) __popcll(m_fetch);
       if (next > range_end) next = range_end;
       if (turn && have) {
-        const DShadowRay *q = &squeue[idx];
-        const V3 o = mk(q->o[0], q->o[1], q->o[2]), d = mk(q->d[0], q->d[1], q->d[2]);
-        const double tmax = q->tmax;
-        const DGroup *G = &ggroups[q->group];
+        V3 o, d;
+        double tmax;
+        sq_ray(S, squeue, idx, &o, &d, &tmax);
+        const DGroup *G = &ggroups[SQ_FIELD(S, squeue, idx, group)];
         const bool single = G->n_instances == 1;
         // BoxRayIntersect's -0.0 quirk: such a ray fails every box test in the reference
         if (has_negative_zero(d)) ti = tend;

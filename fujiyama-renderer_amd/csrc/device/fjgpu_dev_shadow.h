@@ -24,6 +24,30 @@
 #define JQ_CHUNK 64u           // join slots a wave reserves per global atomic (split shadow rays; >= 64: one round may need a slot per lane); fjgpu_api.hip sizes the slack
 #endif
 #define SQ_INVALID 0xffffffffu // DShadowRay.sample of a padding slot
+// queue entry i in either record format (DScene.compact_squeue is wave-uniform: a scalar branch)
+__device__ __forceinline__ const DShadowRayC *sq_c(const DShadowRay *squeue, uint32_t i) { return (const DShadowRayC *) squeue + i; }
+#define SQ_FIELD(S, squeue, i, f) ((S).compact_squeue ? sq_c(squeue, i)->f : (squeue)[i].f)
+__device__ __forceinline__ const float *sq_colour(const DScene &S, const DShadowRay *squeue, uint32_t i) { return S.compact_squeue ? sq_c(squeue, i)->c : squeue[i].c; }
+// the ray of entry i: stored, or rebuilt with the light loop's statements (k_shadow_cull: Ln, distance)
+__device__ __forceinline__ void sq_ray(const DScene &S, const DShadowRay *squeue, uint32_t i, V3 *o, V3 *d, double *tmax)
+{
+  if (!S.compact_squeue) {
+    const DShadowRay *q = &squeue[i];
+    *o = mk(q->o[0], q->o[1], q->o[2]); *d = mk(q->d[0], q->d[1], q->d[2]); *tmax = q->tmax;
+    return;
+  }
+  const DShadowRayC *q = sq_c(squeue, i);
+  const V3 Ps = mk(q->o[0], q->o[1], q->o[2]);
+  const DLightSample *LS = &S.light_samples[q->light];
+  const V3 Pl = mk(LS->P[0], LS->P[1], LS->P[2]);
+  V3 Ln = mk(Pl.x - Ps.x, Pl.y - Ps.y, Pl.z - Ps.z);
+  const double distance = sqrt(dot(Ln, Ln));
+  if (distance > 0) {
+    const double inv = 1. / distance;
+    Ln = mk(Ln.x * inv, Ln.y * inv, Ln.z * inv);
+  }
+  *o = Ps; *d = Ln; *tmax = distance;
+}
 
 #ifndef FJ_CULL_MINB
 #define FJ_CULL_MINB 1
@@ -319,7 +343,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
           // retire the chunk: mark its unused tail as padding, reserve a new one
           if (chunk_used < SQ_CHUNK)
             for (uint32_t k = chunk_used + lane; k < SQ_CHUNK; k += 64)
-              if (chunk_base + k < sp.queue_capacity) squeue[chunk_base + k].sample = SQ_INVALID;
+              if (chunk_base + k < sp.queue_capacity) { if (sp.compact) ((DShadowRayC *) squeue)[chunk_base + k].sample = SQ_INVALID; else squeue[chunk_base + k].sample = SQ_INVALID; }
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(&cnt->shadow_count, SQ_CHUNK);
           chunk_base = __shfl(base, 0);
@@ -327,8 +351,15 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
         }
         if (emit) {
           const uint32_t slot = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-          if (slot < sp.queue_capacity) squeue[slot] = q;
-          else cnt->overflow = 1;
+          if (slot >= sp.queue_capacity) cnt->overflow = 1;
+          else if (sp.compact) {
+            DShadowRayC qc;
+            qc.o[0] = q.o[0]; qc.o[1] = q.o[1]; qc.o[2] = q.o[2];
+            qc.c[0] = q.c[0]; qc.c[1] = q.c[1]; qc.c[2] = q.c[2];
+            qc.sample = q.sample; qc.group = q.group; qc.tindex = q.tindex; qc.light = l; qc.pad = 0;
+            ((DShadowRayC *) squeue)[slot] = qc;
+          }
+          else squeue[slot] = q;
         }
         chunk_used += need;
       }
@@ -348,7 +379,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
   // pad the tail of the last chunk
   if (chunk_used < SQ_CHUNK)
     for (uint32_t k = chunk_used + lane; k < SQ_CHUNK; k += 64)
-      if (chunk_base + k < sp.queue_capacity) squeue[chunk_base + k].sample = SQ_INVALID;
+      if (chunk_base + k < sp.queue_capacity) { if (sp.compact) ((DShadowRayC *) squeue)[chunk_base + k].sample = SQ_INVALID; else squeue[chunk_base + k].sample = SQ_INVALID; }
   flush_counters(cnt, 0, 0, count_events ? c_insts : 0, count_events ? c_shadow : 0, c_shadow);
 }
 

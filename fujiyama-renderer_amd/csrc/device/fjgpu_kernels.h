@@ -46,6 +46,8 @@ struct ShadowParams {
   uint32_t queue_capacity;     // entries of the shadow-ray queue
   uint32_t join_capacity;      // slots of DScene.shadow_join (0: shadow rays into groups of several instances stay whole)
   int32_t cast_shadow;
+  int32_t compact;             // 1: the queue holds DShadowRayC records (DScene.compact_squeue)
+  int32_t pad_;
 };
 
 struct ResolveParams {

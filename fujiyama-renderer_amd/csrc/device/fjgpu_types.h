@@ -278,6 +278,8 @@ struct DScene {
                                // closest-hit walk of such mesh scenes is the phase-scheduled one
   const double *cam_uv;        // implicit camera rays: the (u, v) table of the batch's samples (sample slot = ray index of
                                // level 0; fjgpu_dev_shade.h) while level 0 is walked and shaded, else null
+  int32_t compact_squeue;      // 1: the shadow-ray queue holds DShadowRayC records (set per render call)
+  int32_t pad_cs_;
   const uint32_t *cam_tk;      // ... in scenes whose random streams are keyed by the sample's uid (pathtracing shader, area lights): (tile id, index of
                                // the sample in its tile), two words per sample slot of the batch: 8 bytes instead of the 48-byte path record; else null
   const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
@@ -347,6 +349,21 @@ struct DShadowRay {            // 80 B: a shadow ray that survived the instance-
                                // one instance is the only candidate (single-instance group, lean any-hit walk)
   uint32_t tindex;             // sample index in its tile: the ray's time is time_tab[tindex] (motion blur)
 };
+
+// The COMPACT form of the same record, 56 B (DScene.compact_squeue: scenes whose shadow rays run the lean or the curve any-hit walk and whose lights are
+// point / dome lights without motion): direction and distance are not stored -- the walk rebuilds them from the origin and the light sample's position with the
+// light loop's own statements (Ln = Pl - Ps; distance = sqrt(dot(Ln, Ln)); Ln *= 1 / distance: the same bits).  The origin stays: the light records are
+// recycled (ring of two or three buffers per batch) before the walk runs.
+struct DShadowRayC {
+  double o[3];
+  float c[3];
+  uint32_t sample;
+  int32_t group;
+  uint32_t tindex;
+  uint32_t light;              // index into DScene.light_samples
+  uint32_t pad;
+};
+static_assert(sizeof(DShadowRayC) == 56, "DShadowRayC must be 56 bytes");
 
 struct DCounters {
   // Counters that many waves add to at the same time sit on their own 128-byte lines:

@@ -162,6 +162,8 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * queue order (default 65536).  "split_shadow" 1/0 (default 1): in scenes served by the lean any-hit walk, a shadow
  * ray into a group of several instances is queued once per instance whose box it passes (joined by a counter)
  * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).
+ * "compact_squeue" 1/0 (default 1): shadow-queue records of 56 instead of 80 bytes (no direction / distance: the walk rebuilds them from the origin and
+ * the light sample, same statements, same bits) where the lean or the curve any-hit walk consumes the queue and the lights are point / dome lights.
  * "flat_groups" 1/0 (default 1): scenes created from now on whose closest-hit rays are incoherent (glass, pathtracing shaders) and whose groups hold only
  * small static meshes built on the host (at most 2 M triangles and 32 instances per group) get ONE world-space culling tree per group over the
  * triangles of all its instances; the exact tests stay in object space (k_trace_closest_flat).  0: the instance loop of k_trace_closest_phased.
