@@ -519,6 +519,38 @@ def test_flat_groups_change_nothing(builder, kw, asset_dir):
     assert float(rel_err(out[0][0], out[1][0]).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("builder,kw", [
+    ("dragon", dict(res=(96, 54), spp=(2, 2), mesh="tiny", nlights=5)),                    # lean any-hit walk, one instance per entry
+    ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="tiny", nlights=4)),                   # rays split per candidate instance (join slots in tindex)
+    ("furry", dict(res=(64, 48), spp=(2, 2), mesh="furball", nlights=4)),                  # the curve scenes' any-hit walk
+    ("ibl", dict(res=(64, 36), spp=(2, 2), mesh="tiny", sample_count=16)),                 # dome light samples
+])
+def test_compact_shadow_queue_changes_nothing(builder, kw, asset_dir):
+    """option compact_squeue: 56-byte shadow-queue records without direction and distance -- the any-hit walks rebuild them from the origin and the
+    light sample's position with the light loop's own statements (SlIlluminance, src/fj_shading.cc:296-359) -- against the 80-byte records:
+    the same rays per context, the same pixels, and the oracle's"""
+    text = getattr(workloads, builder)(asset_dir, **kw)
+    out = []
+    _last["adaptive"] = False
+    for on in (1, 0):
+        gpu.global_option("compact_squeue", on)
+        try:
+            sp, rd = prepare(text)
+            gs = gpu.Scene(sp)
+            fb, st = gs.render_frame(rd)
+            gs.close()
+        finally:
+            gpu.global_option("compact_squeue", 1)
+        out.append((fb, st))
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    for fb, st in out:
+        assert_parity(fb, st, ref, rc)
+    assert out[0][1].rays.as_dict() == out[1][1].rays.as_dict()
+    assert float(rel_err(out[0][0], out[1][0]).max()) <= 1e-6
+
+
 def test_hair_shader_declared_in_an_all_opaque_mesh_scene_with_split_shadow_rays(asset_dir):
     """a HairShader in a scene WITHOUT curves whose shadow groups hold several instances: the light loop runs its
     hair instantiation, and that one must queue rays per candidate instance exactly like the plain one does (the
