@@ -274,7 +274,14 @@ static bool build_flat_group(const fjgpu::HostScene &hs, size_t g, size_t max_tr
   for (const fjgpu::PrimRef &r : prs)
     for (int a = 0; a < 3; a++) { gmn[a] = std::min(gmn[a], (double) r.bmin[a]); gmx[a] = std::max(gmx[a], (double) r.bmax[a]); }
   F.tree.type = FJ_PRIMSET_MESH; F.tree.device_build = false; F.tree.f32_exact = false; F.tree.mesh = nullptr; F.tree.curve = nullptr;
-  fjgpu::BuildBlas(&F.tree, prs, FJ_MAX_LEAF_PRIMS, 1.2f);
+  {
+    // (experiment knobs like the mesh builder's: leaf size / SAH cost of a node step in candidate tests)
+    int max_leaf = FJ_MAX_LEAF_PRIMS;
+    float trav_cost = .7f;           // (a candidate costs three node steps here -- record, M^-1, transform, test: C4 frame 611 / 606 / 605 / 690 ms at 1.2 / .4 / .7 / 2.5)
+    if (const char *e = getenv("FJGPU_FLAT_MAX_LEAF")) max_leaf = atoi(e);
+    if (const char *e = getenv("FJGPU_FLAT_TRAV_COST")) trav_cost = (float) atof(e);
+    fjgpu::BuildBlas(&F.tree, prs, max_leaf, trav_cost);
+  }
   F.refs.resize(src.size());
   for (size_t sl = 0; sl < src.size(); sl++) F.refs[sl] = src[F.tree.prim_ids[sl]];
   for (int a = 0; a < 3; a++) {
