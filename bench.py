@@ -73,6 +73,13 @@ def parse_args():
     ap.add_argument("--rank-costs", type=int, default=0,
                     help="diagnostic: on ONE GPU time the tile share of EVERY rank of an N-GPU job (max over ranks = the N-GPU frame "
                          "time before the gather)")
+    ap.add_argument("--deal", default=os.environ.get("FJ_TILE_DEAL", "auto"), choices=("auto", "lattice", "interleave"),
+                    help="static tile deal of an N-GPU job: tile id %% N, the (tx + s ty) %% N lattice, or (auto) the first unless the "
+                         "frame's row length makes it stripes (fujiyama_renderer_amd/distributed.py)")
+    ap.add_argument("--balance-frames", type=int, default=int(os.environ.get("FJ_BALANCE_FRAMES", "8")),
+                    help="N-GPU job: the first this-many frames (warm-up frames included) end with an exchange of the ranks' frame "
+                         "times, and every second one with a re-deal of tiles from the slowest ranks to the fastest; 0: the static "
+                         "deal throughout")
     ap.add_argument("--dry-ranks", type=int, default=0,
                     help="self-check of the N > 1 code path on ONE GPU: re-runs this script as N torch.distributed ranks (gloo, all on "
                          "cuda:0, rendering one after the other), gathers their tiles exactly like an N-GPU job and compares the "
@@ -355,15 +362,40 @@ def main():
     prep_seconds = time.perf_counter() - t_prep
 
     n_tiles = gpu.tile_count(render)
-    my_tiles = fjdist.tiles_of_rank(n_tiles, rank, world)
+    tiles_per_row = -(-render.xres // render.tile_w)
+    capacity = fjdist.slab_capacity(n_tiles, world) if args.balance_frames > 0 else None
+    balance = fjdist.TileBalance(fjdist.deal_tiles(n_tiles, world, tiles_per_row, args.deal), capacity,
+                                 frames=args.balance_frames if world > 1 else 0)
+    my_tiles = balance.lists[rank]
     if args.as_rank_of > 1 and world == 1:
-        my_tiles = fjdist.tiles_of_rank(n_tiles, 0, args.as_rank_of)
+        my_tiles = fjdist.deal_tiles(n_tiles, args.as_rank_of, tiles_per_row, args.deal)[0]
     tile_rects = [gpu.tile_rect(render, t) for t in range(n_tiles)]
     fb = torch.zeros((render.yres, render.xres, 4), dtype=torch.float32, device=device)
     host_fb = torch.empty((render.yres, render.xres, 4), dtype=torch.float32).pin_memory()
     stream = torch.cuda.current_stream(device).cuda_stream
 
+    def measure_tail(G, deal):
+        """what an N-GPU frame adds after its slowest rank is done, less the exchange itself: packing a rank's tiles into
+        the slab, scattering the N slabs into the frame, the frame's copy to the host -- measured on this GPU"""
+        slabs = fjdist._DeviceSlabs(fb, tile_rects, n_tiles, render.tile_w, render.tile_h, 0, G, deal, fjdist.slab_capacity(n_tiles, G))
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            gpu.pack_tiles(fb.data_ptr(), render.xres, slabs.mine.data_ptr(), slabs.per_rank, slabs.tile_px, slabs.slab.data_ptr(), stream)
+            gpu.unpack_tiles(fb.data_ptr(), render.xres, slabs.all.data_ptr(), G * slabs.per_rank, slabs.tile_px, slabs.recv.data_ptr(), stream)
+            host_fb.copy_(fb, non_blocking=False)
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t1) / 5 * 1e3, slabs.slab.numel() * 4
+
+    if world > 1 and balance.adapting:
+        # the work buffers follow the longest tile list a call has seen, and growing them costs seconds: one untimed frame
+        # of as many tiles as the balance may ever hand to this rank
+        spare = [t for t in range(n_tiles) if t not in set(my_tiles)]
+        gs.render_tiles(render, (my_tiles + spare)[:capacity], fb.data_ptr(), stream)
+        torch.cuda.synchronize(device)
+
     def step():
+        nonlocal my_tiles
         if dry:
             # ranks share ONE device here: they render one after the other
             st = None
@@ -374,9 +406,16 @@ def main():
                 dist.barrier()
         else:
             st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
-        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world, rects=tile_rects)
+        adapting = balance.adapting
+        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world, rects=tile_rects,
+                                    lists=balance.lists, capacity=capacity)
         if rank == 0:
             host_fb.copy_(frame, non_blocking=False)       # framebuffer resident in host memory
+        if adapting:
+            # the ranks' render times -> the next frame's deal (the same arithmetic on every rank; what follows the renders --
+            # exchange, scatter, the frame's copy to the host -- waits for the slowest rank whoever that is)
+            balance.update(fjdist.share_times(st.total_ms, rank, world, device))
+            my_tiles = balance.lists[rank]
         return st
 
     def sync():
@@ -559,7 +598,9 @@ def main():
                                       render.tile_w, render.tile_h, n_tiles),
                        "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot",
                                              "furry": "furbunny"}.get(args.workload, args.workload),
-                       "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world,
+                       "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world, "tile_deal": args.deal,
+                       "tile_balance": {"frames": args.balance_frames, "tiles_per_rank": [len(l) for l in balance.lists],
+                                        "slowest_rank_ms_by_deal": balance.history} if world > 1 else None,
                        "blas_build": ("host binned SAH", "device clustering (PLOC)", "device radix tree (LBVH)")[args.device_build],
                        "prepare_seconds": prep_seconds,
                        "counters_counting_frame_rank0": {"nodes": int(counted.nodes_visited), "prims": int(counted.prims_tested),
@@ -583,8 +624,10 @@ def main():
             # per-rank cost of an N-GPU job, every rank's tile share timed on this one GPU
             # (tile t -> rank t % N): the slowest share bounds the N-GPU frame before the gather
             costs, parts = [], []
-            for rk in range(args.rank_costs):
-                tiles_r = fjdist.tiles_of_rank(n_tiles, rk, args.rank_costs)
+            G = args.rank_costs
+            deal = fjdist.deal_tiles(n_tiles, G, tiles_per_row, args.deal)
+            for rk in range(G):
+                tiles_r = deal[rk]
                 gs.render_tiles(render, tiles_r, fb.data_ptr(), stream)      # warm
                 torch.cuda.synchronize(device)
                 each = []
@@ -601,19 +644,38 @@ def main():
             # what an N-GPU frame adds to its slowest rank: packing the rank's tiles into a slab, the exchange, the
             # scatter into the frame, the frame's D2H -- all but the exchange itself measured on this GPU (the 7 slabs
             # of <= 4.1 MB each arrive over separate xGMI links: priced at 50 GB/s per link, a third of the link rate)
-            G = args.rank_costs
-            slabs = fjdist._DeviceSlabs(fb, tile_rects, n_tiles, render.tile_w, render.tile_h, 0, G)
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                gpu.pack_tiles(fb.data_ptr(), render.xres, slabs.mine.data_ptr(), slabs.per_rank, slabs.tile_px, slabs.slab.data_ptr(), stream)
-                gpu.unpack_tiles(fb.data_ptr(), render.xres, slabs.all.data_ptr(), G * slabs.per_rank, slabs.tile_px, slabs.recv.data_ptr(), stream)
-                host_fb.copy_(fb, non_blocking=False)
-            torch.cuda.synchronize(device)
-            tail_ms = (time.perf_counter() - t1) / 5 * 1e3
-            slab = slabs.slab
-            xgmi_ms = slab.numel() * 4 / 50e9 * 1e3
-            out["config"]["rank_costs_ms"] = {"ranks": G, "per_rank": costs, "max": max(costs),
+            tail_ms, slab_bytes = measure_tail(G, deal)
+            xgmi_ms = slab_bytes / 50e9 * 1e3
+            # ... and the feedback deal (TileBalance) played through on this GPU: every frame of an N-GPU job is one round of
+            # timing each rank's current share (one frame each, as the job would see it)
+            bal = None
+            if args.balance_frames > 0:
+                tb = fjdist.TileBalance(deal, fjdist.slab_capacity(n_tiles, G), frames=args.balance_frames)
+
+                gs.render_tiles(render, list(range(tb.capacity)), fb.data_ptr(), stream)      # (buffers for the longest list, as the job does)
+                torch.cuda.synchronize(device)
+
+                def share_ms(tiles_r, reps):
+                    each = []
+                    for _ in range(reps):
+                        each.append(gs.render_tiles(render, tiles_r, fb.data_ptr(), stream).total_ms)     # (what the job's ranks report)
+                    return sorted(each)[len(each) // 2]
+                while tb.adapting:
+                    tb.update([share_ms(tb.lists[rk], 1) for rk in range(G)])
+                final = []
+                for rk in range(G):
+                    each = []
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        gs.render_tiles(render, tb.lists[rk], fb.data_ptr(), stream)
+                        torch.cuda.synchronize(device)
+                        each.append((time.perf_counter() - t1) * 1e3)
+                    final.append(sorted(each)[2])
+                frame_ms = max(final) + tail_ms + xgmi_ms
+                bal = {"frames": args.balance_frames, "slowest_rank_ms_by_frame": tb.history, "per_rank": final,
+                       "tiles_per_rank": [len(l) for l in tb.lists], "projected_frame_ms": frame_ms,
+                       "projected_speedup": out["ms_per_step"] / frame_ms}
+            out["config"]["rank_costs_ms"] = {"ranks": G, "deal": args.deal, "balanced": bal, "per_rank": costs, "max": max(costs),
                                               "speedup_before_gather": out["ms_per_step"] / max(costs),
                                               "pack_unpack_d2h_ms_measured": tail_ms, "xgmi_exchange_ms_estimated": xgmi_ms,
                                               "projected_frame_ms": max(costs) + tail_ms + xgmi_ms,

@@ -20,6 +20,58 @@ def test_tile_deal_partitions_every_tile_once():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_lattice_deal_partitions_every_tile_once_and_spreads_in_both_directions():
+    assert [fjdist.lattice_step(g) for g in (2, 4, 8)] == [1, 2, 3]
+    for n, w, nx in ((510, 8, 30), (512, 8, 32), (2040, 3, 60), (64, 2, 8), (5, 8, 5), (7, 1, 7)):
+        lists = fjdist.deal_tiles(n, w, nx, how="lattice")
+        assert sorted(t for l in lists for t in l) == list(range(n))
+        if n >= 8 * w:
+            assert max(len(l) for l in lists) - min(len(l) for l in lists) <= max(2, w // 2)
+    # a row length that is a multiple of the rank count: the interleave is vertical stripes, the lattice is not
+    stripes = fjdist.deal_tiles(512, 8, 32, how="interleave")
+    assert len({t % 32 for t in stripes[0]}) == 4
+    assert len({t % 32 for t in fjdist.deal_tiles(512, 8, 32)[0]}) == 32                # auto: the lattice here ...
+    assert fjdist.deal_tiles(2040, 8, 60) == fjdist.deal_tiles(2040, 8, 60, how="interleave")     # ... the interleave where it is good enough
+    assert fjdist.deal_tiles(12, 2, None) == [fjdist.tiles_of_rank(12, 0, 2), fjdist.tiles_of_rank(12, 1, 2)]
+
+
+def test_feedback_deal_evens_the_ranks_and_keeps_every_tile():
+    import random
+    rnd = random.Random(7)
+    n, w, nx = 510, 8, 30
+    cost = [0.05 + 0.5 * rnd.random() ** 3 + (0.4 if (t % nx) in range(10, 20) else 0.0) for t in range(n)]
+
+    def times(lists):
+        return [3.0 + sum(cost[t] for t in l) for l in lists]
+    cap = fjdist.slab_capacity(n, w)
+    tb = fjdist.TileBalance(fjdist.deal_tiles(n, w, nx, how="interleave"), cap, frames=12)
+    first = max(times(tb.lists))
+    frames = 0
+    while tb.adapting:
+        before = [list(l) for l in tb.lists]
+        # (two frames per deal; one of them with a rank that ran long for no reason of its tiles: the shorter time counts)
+        late = times(tb.lists)
+        late[frames % w] += 2.5
+        tb.update(late if frames % 2 == 0 else times(tb.lists))
+        frames += 1
+        assert sorted(t for l in tb.lists for t in l) == list(range(n))
+        assert max(len(l) for l in tb.lists) <= cap
+        assert fjdist.rebalance(before, times(before), cap) == fjdist.rebalance(before, times(before), cap)      # deterministic
+    assert frames == 12 and len(tb.history) == 6
+    t = times(tb.lists)
+    assert max(t) == pytest.approx(min(tb.history))               # the best deal seen is the one kept
+    assert max(t) - sum(t) / w < 0.35 * (first - sum(t) / w)      # most of the spread is gone
+    kept = [list(l) for l in tb.lists]
+    tb.update(t)
+    assert tb.lists == kept                                       # frozen
+    # nothing to move: equal times leave the deal alone; a full receiver is skipped
+    even = fjdist.deal_tiles(64, 2, 8)
+    assert fjdist.rebalance(even, [10.0, 10.0], 40) == [sorted(l) for l in even]
+    assert fjdist.rebalance(even, [20.0, 10.0], 32) == [sorted(l) for l in even]
+    moved = fjdist.rebalance(even, [20.0, 10.0], 40)
+    assert len(moved[0]) < 32 and len(moved[0]) + len(moved[1]) == 64
+
+
 def test_pack_unpack_roundtrip_with_ragged_edge_tiles():
     H, W, tw, th = 70, 100, 32, 32            # 4 x 3 tiles, last column 4 px, last row 6 px
     fb = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)
@@ -30,7 +82,7 @@ def test_pack_unpack_roundtrip_with_ragged_edge_tiles():
     assert torch.equal(back, fb)
 
 
-def _worker(rank, world, port, H, W, out_path, mode=None):
+def _worker(rank, world, port, H, W, out_path, mode=None, uneven=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,10 +93,19 @@ def _worker(rank, world, port, H, W, out_path, mode=None):
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     full = torch.stack([yy * 1000.0 + xx, yy * 1.0, xx * 1.0, torch.ones_like(yy) * 1.0], dim=-1).float()
     fb = torch.zeros_like(full)
-    for t in fjdist.tiles_of_rank(n_tiles, rank, world):
+    lists = capacity = None
+    if uneven:
+        # a re-dealt frame: lists of different lengths in slabs with room to spare, and the ranks' times shared as the bench does
+        lists = fjdist.deal_tiles(n_tiles, world, nx)
+        capacity = fjdist.slab_capacity(n_tiles, world)
+        times = fjdist.share_times(10.0 + 5.0 * rank, rank, world)
+        assert times == [10.0 + 5.0 * r for r in range(world)]
+        lists = fjdist.rebalance(lists, times, capacity, threshold=0.1, noise=0.0)
+        assert len(lists[world - 1]) < len(lists[0])
+    for t in (lists[rank] if lists else fjdist.tiles_of_rank(n_tiles, rank, world)):
         x0, y0 = (t % nx) * tw, (t // nx) * th
         fb[y0:y0 + th, x0:x0 + tw] = full[y0:y0 + th, x0:x0 + tw]
-    frame = fjdist.gather_frame(fb, n_tiles, tw, th, rank, world, mode=mode)
+    frame = fjdist.gather_frame(fb, n_tiles, tw, th, rank, world, mode=mode, lists=lists, capacity=capacity)
     if rank == 0:
         assert torch.equal(frame, full)
         np.save(out_path, frame.numpy())
@@ -65,3 +126,13 @@ def test_gather_frame_gloo(tmp_path, mode, world):
     mp.spawn(_worker, args=(world, port, 54, 100, out, mode), nprocs=world, join=True)
     f = np.load(out)
     assert f.shape == (54, 100, 4) and f[53, 99, 0] == 53 * 1000.0 + 99
+
+
+def test_gather_frame_gloo_with_a_rebalanced_deal(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, port, 200, 300, out, "gather", True), nprocs=2, join=True)
+    assert np.load(out).shape == (200, 300, 4)
