@@ -390,7 +390,8 @@ def main():
     if world > 1 and balance.adapting:
         # the work buffers follow the longest tile list a call has seen, and growing them costs seconds: one untimed frame
         # of as many tiles as the balance may ever hand to this rank
-        spare = [t for t in range(n_tiles) if t not in set(my_tiles)]
+        own = set(my_tiles)
+        spare = [t for t in range(n_tiles) if t not in own]
         gs.render_tiles(render, (my_tiles + spare)[:capacity], fb.data_ptr(), stream)
         torch.cuda.synchronize(device)
 

@@ -51,10 +51,10 @@ def test_bench_line_has_the_contract_fields():
 
 @pytest.mark.gpu
 def test_bench_multi_rank_code_path_on_one_gpu():
-    """bench.py --dry-ranks 3: the N > 1 path of the driver's contract (process group, tile deal t % N, per-rank
+    """bench.py --dry-ranks 3: the N > 1 path of the driver's contract (process group, tile deal and its feedback, per-rank
     render, the one gather, scatter, D2H) run as three torch.distributed ranks that share cuda:0 over gloo; the
     assembled frame equals a single render and the line keeps its contract fields with n_gpus = 3"""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--dry-ranks", "3", "--steps", "1", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--dry-ranks", "3", "--steps", "2", "--warmup", "1"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
@@ -63,3 +63,6 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert d["dry_ranks"]["ok"] and d["dry_ranks"]["ranks"] == 3, d["dry_ranks"]
     assert d["config"]["parallelism"] == "tiles%3"
+    # the feedback deal ran (a re-deal after every second frame; the last frames are re-dealt ones) and kept every tile
+    tb = d["config"]["tile_balance"]
+    assert tb["frames"] == 8 and len(tb["slowest_rank_ms_by_deal"]) >= 1 and len(tb["tiles_per_rank"]) == 3
