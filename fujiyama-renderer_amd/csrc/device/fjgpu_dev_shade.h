@@ -639,7 +639,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
           const double r1 = 2. * 3.14159265358979323846 * x1;
           const double r2 = x2;
           const double r2sqrt = sqrt(r2);
-          const V3 D = normalize(u * cos(r1) * r2sqrt + v * sin(r1) * r2sqrt + w * sqrt(1. - r2));
+          double sin_r1, cos_r1;
+          sincos(r1, &sin_r1, &cos_r1);       // (one argument reduction for the two; the same values as sin() and cos())
+          const V3 D = normalize(u * cos_r1 * r2sqrt + v * sin_r1 * r2sqrt + w * sqrt(1. - r2));
           const float kd = (float) dot(Np, D);
           c2.want = true;
           c2.d = D; c2.tmin = .001f;
