@@ -4,6 +4,7 @@
 // compiled with -ffp-contract=off; see the header of that file).
 #ifndef FJGPU_DEV_FLAT_H
 #define FJGPU_DEV_FLAT_H
+#define FJ_FLAT_NO_HIT 0xffffffffu     // "no candidate has won yet" in the walk's best_ord
 
 // What the reference does for a ray into a group (BVHAccelerator over ObjectInstances, src/fj_bvh_accelerator.cc:164-241; ObjectInstance::
 // RayIntersect, src/fj_object_instance.cc:213-243): visit the instances whose box the ray passes, in the BVH's order; in each, transform the ray
@@ -19,7 +20,7 @@
 //   * nearer wins; at exactly equal t the instance EARLIER in the group's order wins (the reference visits it first and later ones need a strictly
 //     smaller t), within an instance the larger primitive id (the grid's LIFO cell lists).
 // A turnover is retire + fetch + slab set-up: one per ray.  Same phases and votes as traverse_phased otherwise.
-template <bool kCount, class Policy>
+template <bool kCount, bool kOne, class Policy>
 __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
   const DInstEntry *gents = (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT);
@@ -34,13 +35,17 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
   V3 o = mk(0, 0, 0), d = o;
   Slab32 s32 = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double tmin = 0, tmax = 0;
-  Best best;
-  best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1;
-  uint32_t best_ord = 0;
+  // the nearest hit so far: t, the position of its instance in the group and its primitive id are what later candidates are compared with; the
+  // record itself (u, v, instance) goes to the ray's hit slot whenever a candidate wins (the walk is near to far: 1.4 winners per C4 ray, and
+  // the line is still in L2 when the second one comes) instead of riding along in five registers -- the loop spilled sixteen
+  double best_t = DBL_MAX;
+  int best_prim = -1;
+  uint32_t best_ord = FJ_FLAT_NO_HIT;
   bool anyhit = false;
-  const FJ_GLOBAL char *nodes = nullptr;
-  const FJ_GLOBAL fj_v4u *refs = nullptr;      // DFlatRef records: three 16-byte words each
-  const double *refbox = nullptr;
+  // (kOne: the scene has ONE group -- node and leaf arrays are the same for every ray: scalar registers)
+  const FJ_GLOBAL char *nodes = kOne ? (const FJ_GLOBAL char *) S.flats[0].nodes : nullptr;
+  const FJ_GLOBAL fj_v4u *refs = kOne ? (const FJ_GLOBAL fj_v4u *) S.flats[0].refs : nullptr;      // DFlatRef records: three 16-byte words each
+  const double *refbox = kOne ? S.flats[0].refbox : nullptr;
   uint32_t fl_pass = 0, fl_fail = 0;       // instances (by position in the group) whose own box and -0.0 rule this ray passed / failed
   uint32_t cur = TRAV_DONE;
   int sp = 0;
@@ -72,7 +77,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
       }
       // ---- turnover: retire, fetch, set up the walk
       if (next >= range_end && head_live) head_live = qc.claim(lane, &next, &range_end);
-      if (fin && have) { pol.finish(idx, best); have = false; }
+      if (fin && have) { if (best_ord == FJ_FLAT_NO_HIT) pol.finish_miss(idx); have = false; }
       const bool fetch = fin;
       const unsigned long long m_fetch = __ballot(fetch);
       bool fresh = false;
@@ -84,13 +89,13 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
           have = pol.fetch(my, &r);
           idx = my;
           o = r.o; d = r.d; tmin = r.tmin; tmax = r.tmax; anyhit = r.anyhit;
-          best.t = DBL_MAX; best.u = best.v = 0; best.inst = -1; best.prim = -1; best_ord = 0;
+          best_t = DBL_MAX; best_prim = -1; best_ord = FJ_FLAT_NO_HIT;
           fl_pass = fl_fail = 0;
           sp = 0;
           fresh = have;
           if (fresh) {
-            const DFlat *F = &S.flats[r.group];
-            nodes = (const FJ_GLOBAL char *) F->nodes; refs = (const FJ_GLOBAL fj_v4u *) F->refs; refbox = F->refbox;
+            const DFlat *F = &S.flats[kOne ? 0 : r.group];
+            if (!kOne) { nodes = (const FJ_GLOBAL char *) F->nodes; refs = (const FJ_GLOBAL fj_v4u *) F->refs; refbox = F->refbox; }
             // BoxRayIntersect's -0.0 quirk: every box test of the reference fails for such a ray -- it hits nothing
             if (!has_negative_zero(d) && F->n_prims > 0) {
               const V3 winv = mk(filter_rcp(d.x), filter_rcp(d.y), filter_rcp(d.z));
@@ -113,7 +118,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
         if (step > 0 && (step >= tune.steps_flat || (unsigned) __popcll(__ballot(in_now)) < tune.min_inner_flat)) break;
         if (in_now) {
           if (kCount) lc->nodes++;
-          const double tf2 = anyhit ? tmax : fmin(tmax, best.t);
+          const double tf2 = anyhit ? tmax : fmin(tmax, best_t);
           const float tmin32 = f32_below(tmin), tmax32 = f32_above(tf2);
           float t0, t1, t2, t3;
           const FJ_GLOBAL fj_v4u *nq = (const FJ_GLOBAL fj_v4u *) (nodes + ((size_t) cur << 6));
@@ -169,8 +174,11 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
             const V3 v2 = mk((double) __uint_as_float(q1.z), (double) __uint_as_float(q1.w), (double) __uint_as_float(q2.x));
             if (tri_ray_early(v0, v1, v2, oo, od, &t, &u, &v) && tmin <= t && t <= tmax) {
               const int pid = (int) q2.z;
-              if (t < best.t || (t == best.t && best.inst >= 0 && (ord < best_ord || (ord == best_ord && pid > best.prim)))) {
-                best.t = t; best.u = u; best.v = v; best.inst = (int) inst; best.prim = pid; best_ord = ord;
+              if (t < best_t || (t == best_t && best_ord != FJ_FLAT_NO_HIT && (ord < best_ord || (ord == best_ord && pid > best_prim)))) {
+                best_t = t; best_prim = pid; best_ord = ord;
+                Best b;
+                b.t = t; b.u = u; b.v = v; b.inst = (int) inst; b.prim = pid;
+                pol.finish(idx, b);
                 stop = anyhit;
               }
             }
@@ -193,7 +201,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
 #define FJ_STACK_LDS_FLAT FJ_STACK_LDS
 #endif
 static_assert(FJ_STACK_LDS_FLAT >= FJ_STACK_LDS_MIN, "the overflow area is sized for FJ_STACK_LDS_MIN entries in LDS");
-template <bool kCount>
+template <bool kCount, bool kOne>
 __global__ void __launch_bounds__(BLOCK, FJ_FLAT_MINB) k_trace_closest_flat(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
@@ -203,7 +211,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_FLAT_MINB) k_trace_closest_flat(DSce
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};
-  traverse_flat<kCount>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS_FLAT), &lc, s_inst);
+  traverse_flat<kCount, kOne>(S, pol, tune, n, &cnt->trace_xcd_head[0][0], make_stack(s_stack, S.stack_overflow, nullptr, FJ_STACK_LDS_FLAT), &lc, s_inst);
   if (kCount) {
     flush_counters(cnt, lc.nodes, lc.prims, lc.insts, 0, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->traced, (unsigned long long) n);

@@ -809,6 +809,12 @@ struct ClosestPolicy {
     h.t = b.t; h.u = b.u; h.v = b.v; h.inst = b.inst; h.prim = b.prim;
     hits[slot(k)] = h;
   }
+  __device__ void finish_miss(uint32_t k) const      // (walks that write a ray's record whenever a candidate wins: nothing won)
+  {
+    DHit h;
+    h.t = DBL_MAX; h.u = h.v = 0; h.inst = -1; h.prim = -1;
+    hits[slot(k)] = h;
+  }
 };
 
 #ifndef FJ_CURVE_MINB
