@@ -33,6 +33,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (read by the HSA runtime when the first HIP call initialises it -- long before the process group: RCCL's buffers cross
+# processes through dmabuf IPC only on this host driver)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
