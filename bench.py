@@ -87,6 +87,11 @@ def parse_args():
                     help="self-check of the N > 1 code path on ONE GPU: re-runs this script as N torch.distributed ranks (gloo, all on "
                          "cuda:0, rendering one after the other), gathers their tiles exactly like an N-GPU job and compares the "
                          "assembled frame with rank 0's own full render; timings of such a run mean nothing")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the ranks through torch.distributed.run (nccl) even for --gpus 1: the RCCL bring-up on one GPU; "
+                         "--gpus N > 1 without a launcher around the script always does")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end leg (the product's bin/scene run as a process of its own on this workload: one cold frame, .fb written)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (HBM traffic, VALU issue) that feed the roofline object")
     return ap.parse_args()
@@ -134,7 +139,7 @@ def cpu_baseline(args, scene_text_fn, render, scene_ptr, sample_ids, sample_rays
     (oracle/liboracle.so) on the same tiles.  Rays = the rays the device counted
     for exactly these tiles (per-context counts are identical at parity).
     """
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(os.cpu_count() or 1, 64) if args.workload in ("cornell",) else (os.cpu_count() or 1)
     rects = [gpu.tile_rect(render, t) for t in sample_ids]
     region = (min(r[0] for r in rects), min(r[1] for r in rects), max(r[2] for r in rects), max(r[3] for r in rects))
     desc = "%d tiles (%dx%d px block at %d,%d) of the %dx%d frame, %dx%d spp" % (
@@ -180,8 +185,10 @@ def cpu_baseline_port(args, render, scene_ptr, n_tiles):
     is not timed, as prepare_render is not in the reference's own frame time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi  # test infrastructure, used here only as a timed CPU baseline
-    cores = min(os.cpu_count() or 1, 64)
-    ids = list(range(n_tiles)) if args.cpu_port_frame else list(range(0, n_tiles, 8))
+    # every hardware thread of the box (64 for workloads with a PathtracingShader: rng[64]); a sample of about two tiles per thread
+    cores = min(os.cpu_count() or 1, 64) if args.workload in ("cornell",) else (os.cpu_count() or 1)
+    every = max(1, min(8, n_tiles // max(1, 2 * cores)))
+    ids = list(range(n_tiles)) if args.cpu_port_frame else list(range(0, n_tiles, every))
     osc = oracle_ffi.OracleScene(scene_ptr)
     t0 = time.perf_counter()
     _, rc = osc.render(render, tile_ids=ids, threads=cores)
@@ -189,7 +196,7 @@ def cpu_baseline_port(args, render, scene_ptr, n_tiles):
     osc.close()
     return {"value": rc.total() / seconds / 1e6, "unit": "Mray/s", "cores": cores, "host_cores": os.cpu_count() or 1,
             "cpu_model": cpu_model(), "kind": "port",
-            "sample": ("the whole frame" if args.cpu_port_frame else "every 8th tile of the frame (%d of %d tiles)" % (len(ids), n_tiles)) +
+            "sample": ("the whole frame" if args.cpu_port_frame else "every %d. tile of the frame (%d of %d tiles)" % (every, len(ids), n_tiles)) +
                       ", %dx%d, %dx%d spp" % (render.xres, render.yres, render.rate_x, render.rate_y),
             "seconds": seconds, "rays": int(rc.total()),
             "frame_seconds_extrapolated": seconds * n_tiles / max(1, len(ids))}
@@ -252,6 +259,8 @@ def pmc_passes(args, kname):
     if args.device_build:
         child += ["--device-build", str(args.device_build)]
     env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)                   # (a parent started through the launcher: the counter child is a plain one-GPU run)
     try:
         for k, cs in enumerate(PMC_SETS):
             d = os.path.join(tmp, "p%d" % k)
@@ -272,6 +281,40 @@ def pmc_passes(args, kname):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def scene_binary_end_to_end(scene_text_fn):
+    """What a user of the reference actually runs: ONE frame per `bin/scene` process (tools/scene_parser/main.cc:34-43) --
+    parse the scene text, read the PLY assets, build the accelerators, upload, allocate the work buffers, render the frame
+    cold, copy it to the host and write the .fb file.  Wall time of the product's own bin/scene on this workload's text with a
+    SaveFrameBuffer appended, plus the parts the binary reports itself."""
+    exe = os.path.join(ROOT, "fujiyama-renderer_amd", "bin", "scene")
+    if not os.path.exists(exe):
+        return None
+    try:
+        tmp = os.path.join(workloads.default_asset_dir(), "bench_e2e")
+        with open(tmp + ".scn", "w") as f:
+            f.write(scene_text_fn() + "SaveFrameBuffer fb1 %s.fb\n" % tmp)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, tmp + ".scn"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        out = {"wall_seconds": wall, "fb_bytes": os.path.getsize(tmp + ".fb") if os.path.exists(tmp + ".fb") else None,
+               "what": "bin/scene <file>: parse + assets + BLAS build + upload + ONE cold frame + .fb written (one process, one GPU)"}
+        for line in r.stdout.splitlines():
+            if line.startswith("# RenderScene"):
+                w = line.split()
+                out["render_scene_seconds"] = float(w[2])
+                out["prepare_seconds"] = float(w[5])
+        for ext in (".scn", ".fb"):
+            try:
+                os.remove(tmp + ext)
+            except OSError:
+                pass
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[-300:]}
 
 
 def cpu_model():
@@ -307,25 +350,69 @@ def dry_ranks_parent(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: this script again as N ranks, one per GPU, under
+    torch.distributed.run with the nccl (= RCCL) backend -- the command shape the driver uses for N > 1, spelled by the
+    script itself so that a bare `--gpus N` measures N GPUs (the reference's worker pool sizes itself the same way,
+    src/fj_renderer.cc:632-641).  `--launcher` forces it for N = 1 as well (the RCCL bring-up on one GPU)."""
+    import socket
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node (one rank per GPU; no oversubscription -- "
+                         "--dry-ranks N is the one-GPU code-path check)" % (args.gpus, have))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    argv = [a for a in sys.argv[1:] if a != "--launcher"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FJ_BENCH_LAUNCHED="1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
     dry = os.environ.get("FJ_BENCH_DRY") == "1"
     if args.dry_ranks > 1 and not dry:
         dry_ranks_parent(args)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and not dry and (args.gpus > 1 or args.launcher):
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if dry else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the fjgpu core has no CPU fallback")
+    if under_launcher and not dry and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): the two must agree" % (args.gpus, world))
+    if not dry and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible): one rank per GPU" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    backend = None
+    if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if dry:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)
+            # RCCL bring-up check before any frame: one all-reduce across the ranks (also with ONE rank: the communicator
+            # is created and a kernel of the collective library runs on this GPU)
+            probe = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise SystemExit("bench.py: RCCL all-reduce over %d rank(s) returned %r" % (world, probe.item()))
+            # ... and the frame exchange's own collective (dist.gather of equal slabs to rank 0) on a token slab
+            tok = torch.full((4,), float(rank), dtype=torch.float32, device=device)
+            got = [torch.empty_like(tok) for _ in range(world)] if rank == 0 else None
+            dist.gather(tok, gather_list=got, dst=0)
+            if rank == 0 and [int(g[0].item()) for g in got] != list(range(world)):
+                raise SystemExit("bench.py: RCCL gather over %d rank(s) returned the slabs out of order" % world)
+        backend = dist.get_backend()
 
     # ---------------- untimed: assets, scene, BLAS build, upload
     kw = {}
@@ -390,15 +477,33 @@ def main():
         torch.cuda.synchronize(device)
         return (time.perf_counter() - t1) / 5 * 1e3, slabs.slab.numel() * 4
 
+    presize_ms = None
     if world > 1 and balance.adapting:
         # the work buffers follow the longest tile list a call has seen, and growing them costs seconds: one untimed frame
         # of as many tiles as the balance may ever hand to this rank
         own = set(my_tiles)
         spare = [t for t in range(n_tiles) if t not in own]
+        t1 = time.perf_counter()
         gs.render_tiles(render, (my_tiles + spare)[:capacity], fb.data_ptr(), stream)
         torch.cuda.synchronize(device)
+        presize_ms = (time.perf_counter() - t1) * 1e3
+
+    first = {}
 
     def step():
+        nonlocal my_tiles
+        cold = not first
+        if cold:
+            torch.cuda.synchronize(device)
+            first["t0"] = time.perf_counter()
+        st = step_()
+        if cold:
+            torch.cuda.synchronize(device)
+            first["ms"] = (time.perf_counter() - first["t0"]) * 1e3
+            first["device_ms"] = st.total_ms if st is not None else None
+        return st
+
+    def step_():
         nonlocal my_tiles
         if dry:
             # ranks share ONE device here: they render one after the other
@@ -430,6 +535,14 @@ def main():
     if world > 1 and rank == 0 and os.environ.get("FJGPU_VERBOSE"):
         sys.stderr.write("bench: %d ranks, backend %s, %d of %d tiles on rank 0\n" % (world, dist.get_backend(), len(my_tiles), n_tiles))
 
+    # The feedback deal converges BEFORE the timed region: its frames (each ends with an exchange of the ranks' times, every
+    # second one with a re-deal) are untimed, so the K timed steps all run the final deal and nothing but the frame's own
+    # exchange sits inside them (adapting deals mixed into ms_per_step).  The line says how many there were.
+    balance_frames_untimed = 0
+    while world > 1 and balance.adapting:
+        step()
+        balance_frames_untimed += 1
+    closed = False
     for _ in range(args.warmup):
         step()
     sync()
@@ -456,12 +569,19 @@ def main():
     launches_local = float(sum(s.trace_launches for s in stats))
     agg = torch.tensor([rays_local, alg_bytes_local, launches_local, elapsed, trace_ms_local], dtype=torch.float64, device=device)
     mx = agg.clone()
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     total_rays = float(agg[0])
     elapsed_max = float(mx[3])
 
+    # HBM this rank holds now (scene + work arena + framebuffers; the arena only grows, so this is the peak): the driver's view
+    # (hipMemGetInfo through torch) and the core's own books
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    hbm_use = {"device_used_bytes": int(total_b - free_b), "device_total_bytes": int(total_b),
+               "scene_bytes": int(gs.query("scene_bytes")), "work_arena_bytes": int(gs.query("work_bytes")),
+               "note": "rank 0's GPU after the timed frames; device_used counts every allocation on the GPU (this process's HIP / "
+                       "torch / RCCL contexts and the PMC children are gone by then)"}
     if rank == 0:
         s0 = stats[-1]
         per = {k: int(getattr(s0.rays, k)) for k in ("camera", "shadow", "diffuse", "reflect", "refract")}
@@ -592,8 +712,14 @@ def main():
             "metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp",
             "value": total_rays / elapsed_max / 1e6,
             "unit": "Mray/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            # the process's FIRST frame, cold: work-buffer allocation, first launches, the exchange's first call (steady-state
+            # frames follow; with N > 1 a rank's first render is the untimed one that sizes its buffers: presize_ms)
+            "first_frame_ms": presize_ms if presize_ms is not None else first.get("ms"),
+            "first_frame_device_ms": first.get("device_ms"),
+            "peak_hbm_bytes": hbm_use,
             "traversed_Mray_s": walked / elapsed_max / 1e6 if world == 1 else None,
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -603,7 +729,8 @@ def main():
                        "mesh": args.mesh or {"dragon": "dragon", "buddhas": "buddha", "teapot": "teapot",
                                              "furry": "furbunny"}.get(args.workload, args.workload),
                        "rays_per_frame_rank0": per, "parallelism": "tiles%%%d" % world, "tile_deal": args.deal,
-                       "tile_balance": {"frames": args.balance_frames, "tiles_per_rank": [len(l) for l in balance.lists],
+                       "tile_balance": {"frames": args.balance_frames, "untimed_frames_before_warmup": balance_frames_untimed,
+                                        "tiles_per_rank": [len(l) for l in balance.lists],
                                         "slowest_rank_ms_by_deal": balance.history} if world > 1 else None,
                        "blas_build": ("host binned SAH", "device clustering (PLOC)", "device radix tree (LBVH)")[args.device_build],
                        "prepare_seconds": prep_seconds,
@@ -690,9 +817,14 @@ def main():
             # host core (the reference hands whole tiles to its worker threads)
             nx = -(-render.xres // render.tile_w)
             ny = -(-render.yres // render.tile_h)
-            # (capped at 64 tiles: the reference's per-ray heap traffic makes it scale badly past
-            # that many threads -- 512 tiles took 142 s on the 256-core host of the GPU box)
-            want = args.cpu_tiles if args.cpu_tiles > 0 else min(2 * (os.cpu_count() or 1), 64)
+            # Default sample: ONE tile per hardware thread of the box, so that every worker thread the reference spawns
+            # (use_max_thread) has a tile -- the stated baseline is "the same box's host cores", all of them.  (Round 4 capped
+            # the sample at 64 tiles = 64 busy threads of 256; 2 tiles per thread, 512 tiles, took 142 s of wall time on the
+            # GPU box -- the reference allocates per ray and its heap traffic scales badly -- which no default run can afford.)
+            # Workloads with a PathtracingShader keep at most 64 tiles: the plugin owns rng[64], one generator per worker
+            # thread id (shaders/pathtracing_shader/pathtracing_shader.cc), so 64 is the most threads it may run with.
+            pt_cap = args.workload in ("cornell",)
+            want = args.cpu_tiles if args.cpu_tiles > 0 else (min(2 * (os.cpu_count() or 1), 64) if pt_cap else (os.cpu_count() or 1))
             want = max(1, min(want, nx * ny))
             bw = max(1, min(nx, 32, want))
             bh = max(1, min(ny, -(-want // bw)))
@@ -704,9 +836,14 @@ def main():
             out["cpu_baseline"]["gpu_ms_same_sample"] = sst.total_ms
             # ... and the restatement (the faster CPU code: no per-ray heap traffic) on a sample with the frame's own mix of tiles
             out["cpu_baseline_port"] = cpu_baseline_port(args, render, scene_ptr, n_tiles)
+        if world == 1 and args.cpu_tiles != 0 and not args.no_e2e and args.as_rank_of <= 1:
+            gs.close()          # (its ~100 GB of work buffers go back first: the binary is a process of its own on the same GPU)
+            closed = True
+            out["scene_binary_end_to_end"] = scene_binary_end_to_end(scene_text)
         print(json.dumps(out))
-    gs.close()
-    if world > 1:
+    if not closed:
+        gs.close()
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -49,6 +49,7 @@ struct DeviceBuffers {
     void *d = nullptr;
     if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return -1;
     ptrs.push_back(d);
+    bytes += n * sizeof(T);
     if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -1;
     *out = static_cast<const T *>(d);
     return 0;
@@ -105,6 +106,7 @@ struct fjgpu_scene {
   hipEvent_t ev_shadow_done[FJ_LREC_BUFS];    // shadow work reading d_lrecs[k] has finished
   std::vector<hipEvent_t> ev_pool; // per-launch timing events (resolved at the end of the frame: no host sync per launch)
   DShadowRay *d_squeue;
+  size_t squeue_rec_bytes = 0;       // bytes per entry the queue was allocated for (DShadowRayC or DShadowRay)
   size_t squeue_cap;
   uint32_t *d_join = nullptr; size_t join_cap = 0;   // DScene.shadow_join (work arena)
   bool split_overflowed = false;   // the last render call overflowed a queue while rays were split
@@ -666,7 +668,12 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (sh.type == FJ_SHADER_PATHTRACING && (lum(sh.diffuse) || (int) lum(sh.reflect) + (int) lum(sh.refract) >= 2)) incoherent = true;
     }
     std::vector<HostFlat> hf;
-    if (incoherent && g_flat_groups && !getenv("FJGPU_NO_FLAT") && FJ_CLOSEST_QNODES && build_flat_groups(hs, &hf)) {
+    // k_trace_closest_flat reads the instance level from its blocks' LDS copy (launch_trace_closest: S.flats && InstLds::fits(S)):
+    // a scene beyond that budget -- build_flat_group admits 32 instances per group, the LDS copy 16 in all -- or with the option
+    // off would walk k_trace_closest_phased, and must then keep the ray sort that walk wants.  ONE decision, made here: such a
+    // scene builds no flat trees, S.flats stays null, and ray_sort_bits / the closest_kernel query / the launcher all follow it.
+    const bool flat_fits = S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES && S.n_instances <= FJ_INST_LDS_INSTS && S.n_groups <= FJ_INST_LDS_GROUPS;
+    if (incoherent && flat_fits && g_flat_groups && !getenv("FJGPU_NO_FLAT") && FJ_CLOSEST_QNODES && build_flat_groups(hs, &hf)) {
       std::vector<DFlat> df(hf.size());
       for (size_t g = 0; g < hf.size() && !e; g++) {
         HostFlat &F = hf[g];
@@ -856,6 +863,8 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   if (n == "node_record_bytes") { *value = (double) sizeof(DNode); return 0; }
   if (n == "anyhit_node_record_bytes") { *value = (double) sizeof(DNodeQ); return 0; }
   if (n == "tri_record_bytes") { *value = scene->tri_record_bytes; return 0; }
+  if (n == "scene_bytes") { *value = (double) scene->mem.bytes; return 0; }
+  if (n == "work_bytes") { *value = (double) (scene->work ? scene->work->bytes : 0); return 0; }
   if (n == "stack_need") { *value = scene->stack_need; return 0; }
   if (n == "blas_nodes") { *value = (double) scene->blas_nodes; return 0; }
   // 1: shadow rays are walked by k_shadow_anyhit (every occluder opaque, no curves, no motion), 0: by k_shadow_trace
@@ -912,11 +921,29 @@ namespace {
 
 struct BatchTile { fjgpu::TileRect r; int nx, ny; uint32_t offset; };
 
+// compact queue records (DShadowRayC, 56 bytes) where the consumers rebuild direction and distance: the lean and the curve any-hit walk,
+// point / dome lights, no motion
+bool scene_compact_squeue(const DScene &S)
+{
+  const bool lean = S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base;
+  const bool curve_walk = S.has_curves && !S.has_motion && S.all_opaque && S.curve_anyhit && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES_CURVES &&
+      S.n_instances <= FJ_INST_LDS_INSTS_CURVES && S.n_groups <= FJ_INST_LDS_GROUPS_CURVES && FJ_CURVE_QNODES && FJ_CLOSEST_QNODES;
+  return (lean || curve_walk) && !S.has_area && g_compact_squeue && !getenv("FJGPU_NO_COMPACT_SQUEUE");
+}
+
 int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t tab_len)
 {
   const int want_bufs = sc->overlap_now ? FJ_LREC_BUFS : 2;
-  if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap || want_bufs > sc->lrec_bufs) {
-    sc->lrec_bufs = want_bufs;
+  // the shadow queue is allocated at the record size the scene's walks read (56 or 80 bytes: 12 GB apart at the headline size); a scene
+  // that goes back to the long record (option compact_squeue switched off between calls) gets a new arena
+  const size_t rec_bytes = scene_compact_squeue(sc->S) ? sizeof(DShadowRayC) : sizeof(DShadowRay);
+  if (samples > sc->work_samples || rays > sc->work_rays || tiles > sc->tiles_cap || want_bufs > sc->lrec_bufs || rec_bytes > sc->squeue_rec_bytes) {
+    // the arena only GROWS: a reallocation for one reason (a small batch that wants the overlap's extra light-record buffers after a
+    // whole frame, a longer tile list) keeps every other dimension at the largest size seen, or callers that alternate whole frames
+    // with region / rank-share renders would free and reallocate tens of GB on every call
+    samples = std::max(samples, sc->work_samples); rays = std::max(rays, sc->work_rays); tiles = std::max(tiles, sc->tiles_cap);
+    const int old_bufs = sc->lrec_bufs;
+    sc->lrec_bufs = std::max(sc->lrec_bufs, want_bufs);
     sc->work.reset(new DeviceBuffers());
     // the adaptive sampler's buffers lived in the old arena (a new arena may be allocated at the
     // old one's address, so the owner pointer alone does not tell)
@@ -939,8 +966,11 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     // (sized for the light loop's WORST case -- every (record, light) pair survives the cull -- where the memory is there: the bound decides
     // into how many launches the light loop of a level is cut, and each cut is a host round trip: a rank's share of C3 took three)
     const size_t per_ray = std::max<size_t>(sc->split_shadow ? 16 : 8, std::min<size_t>(64, (size_t) std::max(1, sc->n_light_samples) * (sc->split_shadow ? 2 : 1)));
-    sc->squeue_cap = std::min<size_t>(rays * per_ray, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
-    e |= W.alloc(sc->squeue_cap, &sc->d_squeue);
+    // (from the batch's own samples, not from the 8 M-entry floor small frames get for their RAY queues: a 64 x 64 render under a dome
+    // light of 64 samples allocated 40 GB here -- ADVICE round 4.  The bound only decides into how many launches the shadow walk is cut.)
+    const size_t lrec_bound = std::min<size_t>(rays, std::max<size_t>(samples * 4, (size_t) 1 << 16));
+    sc->squeue_cap = std::min<size_t>(lrec_bound * per_ray, sc->squeue_max) + 4096 * 1024;   // + one chunk per resident wave
+    { char *q = nullptr; e |= W.alloc(sc->squeue_cap * rec_bytes, &q); sc->d_squeue = (DShadowRay *) q; sc->squeue_rec_bytes = e ? 0 : rec_bytes; }
     // join slots of shadow rays queued once per candidate instance (DScene.shadow_join): a ray that has one
     // owns at least two queue entries
     sc->d_join = nullptr; sc->join_cap = 0;
@@ -951,7 +981,7 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     if (sc->split_shadow) { sc->join_cap = sc->squeue_cap + 1 + 32 * (persistent_threads() / 64) * 64; e |= W.alloc(sc->join_cap, &sc->d_join); }
     e |= W.alloc(1, &sc->d_cnt);
     e |= W.alloc((size_t) tiles, &sc->d_tiles);
-    if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; return -1; }
+    if (e) { sc->work.reset(); sc->work_samples = sc->work_rays = 0; sc->tiles_cap = 0; sc->lrec_bufs = std::min(old_bufs, 2); sc->squeue_rec_bytes = 0; return -1; }
     sc->work_samples = samples; sc->work_rays = rays; sc->tiles_cap = tiles;
   }
   if (tab_len > sc->tab_len) {
@@ -1072,12 +1102,13 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // with a 196 ms frame: two batches 195.8 ms, one 192.9 ms.
   // (asked once per arena: the query is a driver round trip, and a rank's share of a frame is 20 ms; an allocation that fails because
   // somebody else took the memory meanwhile halves the batch below)
-  if (!sc->work || sc->free_cached == 0) {
+  auto query_free = [&]() {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t) 16 << 30;
     sc->free_cached = free_b + (sc->work ? sc->work->bytes : 0);   // our own work buffers are re-usable
-  }
-  const size_t free_now = sc->free_cached;
+  };
+  if (!sc->work || sc->free_cached == 0) query_free();
+  size_t free_now = sc->free_cached;
   // recursion levels this scene can reach: one queue per level, level = bounces so far, and a
   // bounce type only occurs if some shader of the scene emits it
   const int deepest = (sc->bounce_diffuse ? std::max(0, r->max_diffuse_depth) : 0) +
@@ -1107,6 +1138,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   if (sc->n_light_samples == 0) sc->squeue_max = (size_t) 4 << 20;
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
   size_t cap_samples = 0, cap_rays = 0;
+  bool requeried = false;
   for (;;) {
     cap_samples = full_tile_samples * (size_t) bt;
     // one level holds at most the rays its parent chunk can emit (the scheduler chunks by
@@ -1114,9 +1146,22 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     // (small frames get queues of at least 8 M entries: with room for the worst-case fan-out the
     // scheduler does not have to cut their levels into chunks of a few thousand rays)
     cap_rays = std::max<size_t>(cap_samples, std::min<size_t>((size_t) 8 << 20, cap_samples * 16)) + 1024;
+    // the arena is about to be replaced: the shadow queue's bound follows what is free NOW, not what was free when the scene's first
+    // frame asked (other scenes or processes may have allocated since)
+    if (!requeried && sc->work && (cap_samples > sc->work_samples || cap_rays > sc->work_rays || (int) bt > sc->tiles_cap ||
+                                   (sc->overlap_now ? FJ_LREC_BUFS : 2) > sc->lrec_bufs)) {
+      requeried = true;
+      query_free();
+      free_now = sc->free_cached;
+      if (!getenv("FJGPU_SQUEUE_M") && sc->n_light_samples != 0)
+        sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
+    }
     bool ok = ensure_work(sc, cap_samples, cap_rays, (int) bt, full_tile_samples) == 0;
     // every reachable level now, so that a failure shrinks the batch instead of ending the frame
-    for (int l = 0; ok && l <= deepest; l++) ok = ensure_level(sc, l, cap_rays) == 0;
+    // (level 0 only where camera rays are explicit records: with implicit camera rays -- the rule of `implicit_cam` below -- nothing reads
+    // its 112 bytes per sample, 15 GB of a cold C3 frame's allocations)
+    const bool level0_implicit = !adaptive && sc->S.cam_xform == nullptr && (!sc->uses_sample_uid || !sc->S.has_motion) && !getenv("FJGPU_EXPLICIT_CAMERA_RAYS");
+    for (int l = level0_implicit ? 1 : 0; ok && l <= deepest; l++) ok = ensure_level(sc, l, cap_rays) == 0;
     // ... and the ray sort's scratch (a failure here also halves the batch)
     if (ok && sc->ray_sort_bits > 0 && deepest >= 1) ok = ensure_sort(sc, cap_rays) == 0;
     if (ok) break;
@@ -1164,13 +1209,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   swp.pre_resolve = (S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base) ? 1 : 0;   // the lean any-hit walk consumes the queue
   swp.cast_shadow = r->cast_shadow;
   // compact queue records (DShadowRayC) where the consumers rebuild direction and distance: the lean and the curve any-hit walk, point / dome lights, no motion
-  {
-    const bool lean = S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base;
-    const bool curve_walk = S.has_curves && !S.has_motion && S.all_opaque && S.curve_anyhit && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES_CURVES &&
-        S.n_instances <= FJ_INST_LDS_INSTS_CURVES && S.n_groups <= FJ_INST_LDS_GROUPS_CURVES && FJ_CURVE_QNODES && FJ_CLOSEST_QNODES;
-    S.compact_squeue = ((lean || curve_walk) && !S.has_area && g_compact_squeue && !getenv("FJGPU_NO_COMPACT_SQUEUE")) ? 1 : 0;
-    S.pad_cs_ = 0;
-  }
+  S.compact_squeue = scene_compact_squeue(S) ? 1 : 0;
+  S.pad_cs_ = 0;
   swp.compact = S.compact_squeue; swp.pad_ = 0;
   swp.queue_capacity = (uint32_t) sc->squeue_cap;
   swp.join_capacity = (swp.pre_resolve && sc->split_shadow && sc->d_join) ? (uint32_t) sc->join_cap : 0u;

@@ -145,7 +145,7 @@ struct DInstEntry {
   int32_t xform;
 };
 #define FJ_INST_LDS_ENTRY_WORDS 38      // sizeof(DInstEntry) / 8
-// budgets: DTNodes (56 B), DInstEntry records (256 B), DGroups (64 B)
+// budgets: DTNodes (56 B), DInstEntry records (304 B = 38 words), DGroups (64 B)
 #define FJ_INST_LDS_NODES 39            // 8 072 bytes next to the 32 KB of stacks of a block: the phased walk still has 4 blocks per CU.  (The curve
                                         // instantiations have a budget of their own below; the motion kernels read global memory.)
 #define FJ_INST_LDS_INSTS 16

@@ -241,15 +241,25 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None, rects=None
         from . import gpu
         # (the rectangle table and the frame size are part of the key: another region or resolution with the same tile count
         # and the same framebuffer allocation must not scatter with the old tables)
-        key = (fb.data_ptr(), H, W, n_tiles, tile_w, tile_h, rank, world, per_rank, hash(tuple(tuple(int(v) for v in r) for r in rects)))
-        deal_key = hash(tuple(tuple(l) for l in lists))
+        key = (fb.data_ptr(), H, W, n_tiles, tile_w, tile_h, rank, world, per_rank)
+        # (per frame this is two identity tests: the tables are compared by VALUE only when the caller hands over another
+        # object -- hashing 2040 rectangles and every tile id cost ~1 ms of every timed frame on every rank)
+        if _state.get("rects_ref") is not rects:
+            rv = tuple(tuple(int(v) for v in r) for r in rects)
+            if _state.get("rects_val") != rv:
+                _state["slabs_key"] = None
+            _state["rects_ref"], _state["rects_val"] = rects, rv
+        deal_changed = False
+        if _state.get("lists_ref") is not lists:
+            lv = tuple(tuple(l) for l in lists)
+            deal_changed = _state.get("lists_val") != lv
+            _state["lists_ref"], _state["lists_val"] = lists, lv
         if _state.get("slabs_key") != key:
             _state["slabs"], _state["slabs_key"] = _DeviceSlabs(fb, rects, n_tiles, tile_w, tile_h, rank, world, lists, per_rank), key
-            _state["deal_key"] = deal_key
+            deal_changed = False
         ds = _state["slabs"]
-        if _state.get("deal_key") != deal_key:
+        if deal_changed:
             ds.retable(rects, rank, lists)
-            _state["deal_key"] = deal_key
         stream = torch.cuda.current_stream(fb.device).cuda_stream
         gpu.pack_tiles(fb.data_ptr(), W, ds.mine.data_ptr(), per_rank, ds.tile_px, ds.slab.data_ptr(), stream)
         slab = ds.slab

@@ -169,9 +169,11 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * triangles of all its instances; the exact tests stay in object space (k_trace_closest_flat).  0: the instance loop of k_trace_closest_phased.
  * "curve_anyhit" 1/0 (default 1): scenes created from now on that hold curve sets, no time-sampled motion and only opaque occluders walk their
  * shadow rays with k_shadow_anyhit_curves (phase-scheduled, ribbon tests as a phase of their own); 0: with the general k_shadow_trace.
- * "inst_lds" 1/0 (default 1): scenes created from now on whose instance level is small (79 threaded nodes / 40 instances /
- * 24 groups for the closest-hit and general shadow walks of mesh scenes, 39 / 20 / 12 for the phase-scheduled walk, 292 nodes
- * for the light loop) have it copied to LDS by every block of those walks; 0: it is read from global memory (same results).
+ * "inst_lds" 1/0 (default 1): scenes created from now on whose instance level is small (79 threaded nodes / 33 instances /
+ * 24 groups for the closest-hit and general shadow walks of mesh scenes, 39 / 16 / 12 for the phase-scheduled and the flat-group
+ * walk, 15 / 6 / 12 for the walks of curve scenes, 292 nodes for the light loop; one instance is a 304-byte DInstEntry) have it
+ * copied to LDS by every block of those walks; 0, or a scene beyond its kernel's budget: it is read from global memory (same
+ * results; a scene beyond the 39 / 16 / 12 budget also builds no flat groups).
  * "batch_tiles" n: scenes created from now on start with the per-scene option of that name set to n (0 = sized by
  * memory; how a host that never sees the scene handle -- SiRenderScene -- cuts a frame into batches).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
@@ -191,7 +193,9 @@ int fjgpu_host_instance_level(const fj_scene_desc *desc, int group, int32_t *out
  * k_shadow_anyhit, 0: not), "curve_anyhit" (1: by k_shadow_anyhit_curves -- curve scene, every occluder opaque, no motion; both 0: by the
  * general k_shadow_trace), "closest_kernel" (0 k_trace_closest, 1 k_trace_closest_phased,
  * 2 its curve instantiation, 3 its motion instantiation, 4 k_trace_closest_flat: one world-space tree per group), "closest_node_record_bytes" (64: the closest-hit walk reads the
- * quantised nodes too; 128 in scenes with curve sets or motion), "has_curves", "has_motion".  Returns 0 or FJGPU_EINVAL. */
+ * quantised nodes too; 128 in scenes with curve sets or motion), "has_curves", "has_motion", "scene_bytes" (device memory of the
+ * resident scene: BLAS, instance level, lights, textures), "work_bytes" (the wavefront work arena -- queues, accumulators -- as the
+ * largest call so far sized it; scene_bytes + work_bytes = the HBM this scene holds).  Returns 0 or FJGPU_EINVAL. */
 int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value);
 
 /* Diagnostics: the host-side math that feeds geometry to the device (matrices,

@@ -66,3 +66,38 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     # the feedback deal ran (a re-deal after every second frame; the last frames are re-dealt ones) and kept every tile
     tb = d["config"]["tile_balance"]
     assert tb["frames"] == 8 and len(tb["slowest_rank_ms_by_deal"]) >= 1 and len(tb["tiles_per_rank"]) == 3
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_over_rccl():
+    """`python bench.py --gpus N` with no launcher around it re-runs itself as N ranks under torch.distributed.run with the nccl
+    (= RCCL) backend -- what the driver's scaling run needs from a bare `--gpus N`.  On the one GPU of
+    this box: `--launcher` forces that path for N = 1, so the RCCL communicator is created, an all-reduce and the frame
+    exchange's gather run on real hardware, and the line says which backend carried it; asking for more GPUs than the node
+    has fails loudly instead of rendering on one."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--gpus", "1", "--launcher", "--steps", "2",
+                        "--warmup", "1", "--cpu-tiles", "0", "--no-pmc"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["backend"] == "nccl" and d["rccl_ranks"] == 1 and d["value"] > 0
+    assert d["first_frame_ms"] > 0 and d["peak_hbm_bytes"]["work_arena_bytes"] > 0
+    import torch
+    more = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--gpus", str(more), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]          # no line from a run that did not happen
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """no CPU fallback anywhere: on a machine without a GPU bench.py (with or without --gpus N) stops with a message, prints no line"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    for extra in ([], ["--gpus", "2"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--steps", "1", "--warmup", "0"] + extra,
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
+        assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
