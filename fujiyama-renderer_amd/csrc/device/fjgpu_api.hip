@@ -125,7 +125,7 @@ struct fjgpu_scene {
   // ray-queue sort (fjgpu_raysort.hip): levels >= 1 of scenes with incoherent secondary rays
   int ray_sort_bits = 0;           // grid bits per axis; 0 = rays are walked in queue order
   double scene_box[6];             // union of the instances' world boxes (the sort's grid)
-  uint32_t *d_sort[4] = {nullptr, nullptr, nullptr, nullptr};   // keys, keys_alt, slots, perm (in the `work` arena)
+  uint32_t *d_sort[4] = {nullptr, nullptr, nullptr, nullptr};   // -, keys_alt, -, perm (in the `work` arena)
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0; size_t sort_cap = 0;
   // frame-level buffers of fjgpu_render_frame_multi (lazily sized, freed with the scene)
   float *d_frame = nullptr; size_t d_frame_n = 0;      // this device's framebuffer
@@ -900,6 +900,41 @@ int fjgpu_set_batch_callback(fjgpu_scene *scene, fjgpu_batch_fn fn, void *user)
   return 0;
 }
 
+int fjgpu_dev_sort_pairs(int device, const uint32_t *keys, int n, int key_bits, uint32_t *keys_out, uint32_t *perm, int repeats, double *sort_ms)
+{
+  if (n < 0 || key_bits < 1 || key_bits > 32 || (n > 0 && !keys)) return fail(FJGPU_EINVAL, "bad sort call");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) return fail(FJGPU_ENODEV, "no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  if (sort_ms) *sort_ms = 0;
+  if (n == 0) return 0;
+  DeviceBuffers M;
+  const uint32_t *d_keys = nullptr;
+  uint32_t *d_out = nullptr, *d_perm = nullptr;
+  char *d_tmp = nullptr;
+  const size_t tmp_bytes = ray_sort_pairs_temp_bytes((uint32_t) n, key_bits);
+  if (M.upload(keys, (size_t) n, &d_keys) || M.alloc((size_t) n, &d_out) || M.alloc((size_t) n, &d_perm) || M.alloc(tmp_bytes, &d_tmp))
+    return fail(FJGPU_ENOMEM, "device allocation failed for the sort");
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int k = 0; k < std::max(1, repeats); k++) {
+    (void) hipEventRecord(e0, nullptr);
+    if (ray_sort_pairs(nullptr, d_keys, (uint32_t) n, key_bits, d_out, d_perm, d_tmp, tmp_bytes, keys_out != nullptr)) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return fail(FJGPU_ENODEV, "the sort's launches failed"); }
+    (void) hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return fail(FJGPU_ENODEV, std::string("sort: ") + hipGetErrorString(hipGetLastError())); }
+    float ms = 0.f;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    best = std::min(best, (double) ms);
+  }
+  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+  if (sort_ms) *sort_ms = best;
+  if (keys_out) HIP_TRY(hipMemcpy(keys_out, d_out, sizeof(uint32_t) * (size_t) n, hipMemcpyDeviceToHost));
+  if (perm) HIP_TRY(hipMemcpy(perm, d_perm, sizeof(uint32_t) * (size_t) n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
 {
   if (!scene || !name) return fail(FJGPU_EINVAL, "bad option call");
@@ -1026,12 +1061,12 @@ int ensure_sort(fjgpu_scene *sc, size_t cap)
 {
   if (sc->sort_cap >= cap) return 0;
   DeviceBuffers &W = *sc->work;
-  for (int k = 0; k < 4; k++) if (W.alloc(cap, &sc->d_sort[k])) return -1;
+  sc->d_sort[0] = sc->d_sort[2] = nullptr;       // (keys come from the shading kernel; the values are the indices, implicit in the first pass)
+  if (W.alloc(cap, &sc->d_sort[1]) || W.alloc(cap, &sc->d_sort[3])) return -1;
   sc->sort_tmp_bytes = ray_sort_temp_bytes((uint32_t) cap, sc->ray_sort_bits);
   char *tmp = nullptr;
   if (W.alloc(sc->sort_tmp_bytes, &tmp)) return -1;
   sc->d_sort_tmp = tmp;
-  if (ray_sort_fill_iota(nullptr, sc->d_sort[2], (uint32_t) cap) || hipDeviceSynchronize() != hipSuccess) return -1;   // the sort's values: 0 .. n-1
   sc->sort_cap = cap;
   return 0;
 }
@@ -1359,7 +1394,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
           if (ensure_sort(sc, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for the ray sort");   // (sized with the queues: cannot fail here)
           // (the keys were written by the shading kernel that emitted these rays: ShadeParams.next_keys)
           e = timed(st, &acc.sort_ms, [&]() {
-            return launch_ray_sort_keyed(st, sc->levels[level].keys + off, n, sc->ray_sort_bits, sc->d_sort[1], sc->d_sort[2], sc->d_sort[3],
+            return launch_ray_sort_keyed(st, sc->levels[level].keys + off, n, sc->ray_sort_bits, sc->d_sort[1], sc->d_sort[3],
                 sc->d_sort_tmp, sc->sort_tmp_bytes);
           });
           if (e) return e;

@@ -36,6 +36,7 @@ def lib():
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.fjgpu_global_option.argtypes = [C.c_char_p, C.c_long]
         L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        L.fjgpu_dev_sort_pairs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -167,6 +168,17 @@ def global_option(name, value):
 
 def tile_count(render):
     return lib().fjgpu_tile_count(C.byref(render))
+
+
+def sort_pairs(keys, key_bits, device=0, repeats=1):
+    """the ray-queue sort on its own (include/fjgpu.h: fjgpu_dev_sort_pairs): (keys[i], i) pairs, stable, over the low key_bits
+    bits -> (sorted keys, perm, milliseconds of the fastest of `repeats` device-side runs)"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    out, perm = np.empty_like(keys), np.empty_like(keys)
+    ms = C.c_double(0)
+    _check(lib().fjgpu_dev_sort_pairs(device, keys.ctypes.data_as(C.c_void_p), int(keys.size), int(key_bits),
+                                      out.ctypes.data_as(C.c_void_p), perm.ctypes.data_as(C.c_void_p), int(repeats), C.byref(ms)))
+    return out, perm, ms.value
 
 
 def tile_rect(render, tile_id):

@@ -206,6 +206,13 @@ void fjgpu_host_xorshift_f01(int n, double *out);
 void fjgpu_host_sampler_margin(const fj_render_desc *render, int32_t *margin2);
 double fjgpu_host_camera_uv_size_y(double fov);
 
+/* Diagnostics: the ray-queue sort on its own (fjgpu_raysort.hip: the hand-written wave64 LSD radix sort that orders the rays
+ * of recursion level >= 1 in front of the closest-hit walk).  Sorts the pairs (keys[i], i) of HOST arrays on `device`,
+ * stable, over the low key_bits bits (1 .. 32): keys_out ascending, perm[k] = index of the k-th pair (either may be NULL; without
+ * keys_out the last pass writes the permutation only, as the product's sort does).
+ * sort_ms (may be NULL): the fastest of `repeats` device-side runs, HIP events around the sort's launches alone. */
+int fjgpu_dev_sort_pairs(int device, const uint32_t *keys, int n, int key_bits, uint32_t *keys_out, uint32_t *perm, int repeats, double *sort_ms);
+
 /* Human-readable message for the last error on this thread. */
 const char *fjgpu_last_error(void);
 
