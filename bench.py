@@ -295,18 +295,28 @@ def scene_binary_end_to_end(scene_text_fn):
         tmp = os.path.join(workloads.default_asset_dir(), "bench_e2e")
         with open(tmp + ".scn", "w") as f:
             f.write(scene_text_fn() + "SaveFrameBuffer fb1 %s.fb\n" % tmp)
-        t0 = time.perf_counter()
-        r = subprocess.run([exe, tmp + ".scn"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-300:]}
-        out = {"wall_seconds": wall, "fb_bytes": os.path.getsize(tmp + ".fb") if os.path.exists(tmp + ".fb") else None,
-               "what": "bin/scene <file>: parse + assets + BLAS build + upload + ONE cold frame + .fb written (one process, one GPU)"}
-        for line in r.stdout.splitlines():
-            if line.startswith("# RenderScene"):
-                w = line.split()
-                out["render_scene_seconds"] = float(w[2])
-                out["prepare_seconds"] = float(w[5])
+        def run(env):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, tmp + ".scn"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-300:]}
+            o = {"wall_seconds": wall}
+            for line in r.stdout.splitlines():
+                if line.startswith("# RenderScene"):
+                    w = line.split()
+                    o["render_scene_seconds"] = float(w[2])
+                    o["prepare_seconds"] = float(w[5])
+            return o
+        out = run(dict(os.environ))
+        if "error" in out:
+            return out
+        out["fb_bytes"] = os.path.getsize(tmp + ".fb") if os.path.exists(tmp + ".fb") else None
+        out["what"] = ("bin/scene <file>: parse + assets + BLAS build + upload + ONE cold frame + .fb written (one process, one GPU); SiRenderScene renders "
+                       "its one frame in batches of 16 M samples (FJ_BATCH_SAMPLES): a work arena of a few GB instead of ~110 GB")
+        # ... and the same with the core's default batch (the whole frame at once: what the timed steps above run): the cold frame then
+        # waits for ~110 GB of work buffers, up to seconds when the driver has to clear that memory first
+        out["with_whole_frame_batches"] = run(dict(os.environ, FJ_BATCH_SAMPLES="0"))
         for ext in (".scn", ".fb"):
             try:
                 os.remove(tmp + ext)
@@ -498,7 +508,10 @@ def main():
             first["t0"] = time.perf_counter()
         st = step_()
         if cold:
+            _t = time.perf_counter()
             torch.cuda.synchronize(device)
+            if os.environ.get("FJ_BENCH_TRACE"):
+                sys.stderr.write("bench trace: cold step %.1f ms before the closing synchronize, %.1f ms in it\n" % ((_t - first["t0"]) * 1e3, (time.perf_counter() - _t) * 1e3))
             first["ms"] = (time.perf_counter() - first["t0"]) * 1e3
             first["device_ms"] = st.total_ms if st is not None else None
         return st
@@ -514,12 +527,19 @@ def main():
                     torch.cuda.synchronize(device)
                 dist.barrier()
         else:
+            _t = time.perf_counter()
             st = gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
+            if os.environ.get("FJ_BENCH_TRACE"):
+                torch.cuda.synchronize(device)
+                sys.stderr.write("bench trace: render_tiles %.1f ms wall, %.1f ms device\n" % ((time.perf_counter() - _t) * 1e3, st.total_ms))
         adapting = balance.adapting
         frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world, rects=tile_rects,
                                     lists=balance.lists, capacity=capacity)
         if rank == 0:
+            _t = time.perf_counter()
             host_fb.copy_(frame, non_blocking=False)       # framebuffer resident in host memory
+            if os.environ.get("FJ_BENCH_TRACE"):
+                sys.stderr.write("bench trace: frame copy to host %.1f ms\n" % ((time.perf_counter() - _t) * 1e3))
         if adapting:
             # the ranks' render times -> the next frame's deal (the same arithmetic on every rank; what follows the renders --
             # exchange, scatter, the frame's copy to the host -- waits for the slowest rank whoever that is)

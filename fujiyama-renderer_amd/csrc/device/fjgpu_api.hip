@@ -75,6 +75,7 @@ struct fjgpu_scene {
   int n_light_samples;
   // options
   long batch_tiles;
+  long batch_samples = 0;          // option "batch_samples": samples per batch where batch_tiles is 0 (0: as many as the memory budget holds)
   long count_events;
   long count_all_shadow;
   // work buffers (lazily sized)
@@ -940,6 +941,7 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
   if (!scene || !name) return fail(FJGPU_EINVAL, "bad option call");
   const std::string n(name);
   if (n == "batch_tiles") { scene->batch_tiles = value; return 0; }
+  if (n == "batch_samples") { scene->batch_samples = value < 0 ? 0 : value; return 0; }
   if (n == "count_nodes") { scene->count_events = value != 0; return 0; }
   if (n == "count_all_shadow") { scene->count_all_shadow = value != 0; return 0; }
   if (n == "overlap_shadow") {
@@ -1150,6 +1152,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
       (sc->bounce_reflect ? std::max(0, r->max_reflect_depth) : 0) + (sc->bounce_refract ? std::max(0, r->max_refract_depth) : 0);
   if (sc->levels.size() < (size_t) deepest + 1) sc->levels.resize((size_t) deepest + 1, fjgpu_scene::Level{nullptr, nullptr, 0, nullptr});
   long bt = sc->batch_tiles;
+  // (a caller that renders ONE frame per scene -- SiRenderScene -- asks for batches of a few M samples: the work arena is then a few GB
+  // instead of ~110 GB at the headline size, and a cold frame does not wait for the driver to hand out, and clear, that much memory)
+  if (bt <= 0 && sc->batch_samples > 0) bt = std::max<long>(1, (long) ((size_t) sc->batch_samples / full_tile_samples));
   if (bt <= 0) {
     const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
         ((sc->ray_sort_bits > 0 && deepest >= 1) ? 24 : 0);       // (the ray sort's keys, slots, permutation and scratch)

@@ -493,6 +493,15 @@ static int render_scene(Scene *sc, Renderer *ren)
   int err = fjgpu_scene_create_multi(&sc->desc, devices.data(), want, gs.data());
   if (err) { g_last_error = std::string("fjgpu_scene_create: ") + fjgpu_last_error(); return -1; }
   auto destroy_all = [&]() { for (fjgpu_scene *g : gs) fjgpu_scene_destroy(g); };
+  // One frame per device scene here (it is destroyed below), like one frame per bin/scene process in the reference
+  // (tools/scene_parser/main.cc:34-43): every frame is a COLD frame, and the core's default -- the whole frame as one batch, ~110 GB of
+  // wavefront queues at 1080p / 64 spp -- would spend up to seconds waiting for the driver to hand out (and clear) memory that is used for
+  // 0.1 s.  Batches of 16 M samples (FJ_BATCH_SAMPLES, 0 = the core's default) cost a 1080p frame ~10 ms in launch tails.
+  {
+    long bs = 16l << 20;
+    if (const char *e = getenv("FJ_BATCH_SAMPLES")) bs = std::max(0l, atol(e));
+    for (fjgpu_scene *g : gs) fjgpu_set_option(g, "batch_samples", bs);
+  }
   const double t1 = now_s();
 
   const int ntiles = fjgpu_tile_count(&sc->render);

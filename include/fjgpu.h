@@ -143,7 +143,9 @@ int fjgpu_unpack_tiles(float *d_fb, int xres, const int32_t *d_rects, int n_tile
 int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
     double *out_t, int32_t *out_ids, double *out_uv, fjgpu_stats *stats);
 
-/* Tunables (all have defaults): "batch_tiles" tiles per wavefront batch,
+/* Tunables (all have defaults): "batch_tiles" tiles per wavefront batch, "batch_samples" samples per batch where batch_tiles is 0
+ * (0, the default: as many as the memory budget holds -- fastest where frames repeat; a caller that renders one frame per scene
+ * sets a few M: the work arena shrinks from ~110 GB to a few GB at the headline size and the cold frame starts sooner),
  * "count_nodes" 0/1 enable traversal event counters, "overlap_shadow" 0/1 run the shadow work of
  * a recursion level on its own stream, concurrent with the next level. Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
