@@ -81,6 +81,7 @@ __device__ __forceinline__ bool tri_ray_anyhit(V3 v0, V3 v1, V3 v2, V3 orig, V3 
 }
 
 #ifdef FJ_PHASE_STATS
+__device__ unsigned long long g_ahphase[16];
 // debug build only: wave-level phase executions and the lanes active in them
 #define PH(i, v) do { ph[i] += (unsigned long long) (v); } while (0)
 #else
@@ -274,7 +275,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
       continue;
     }
 
-    if (n_inner >= n_leaf) {
+    if (n_inner * tune.leaf_bias8 >= n_leaf * 8u) {
       // ---- inner nodes: one 64-byte node per lane; further steps without a new vote while at
       // least tune.min_inner lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
@@ -284,6 +285,12 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         if (step >= tune.anyhit_steps || n_now < tune.min_inner) break;
         PH(3, 1); PH(4, n_now);
       } else { PH(3, 1); PH(4, n_inner); }
+#ifdef FJ_PHASE_STATS
+      // where the lanes that take no part in this inner step are: idle (ray finished, waiting for the turnover) or held at a leaf
+      { const bool in_ = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
+        const bool fin_ = cur == TRAV_DONE && pleaf == TRAV_DONE;
+        PH(7, __popcll(__ballot(fin_))); PH(8, __popcll(__ballot(!in_ && !fin_))); }
+#endif
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
       const bool deep = __ballot(in_now && spa + 3u * BLOCK * 4u > ah_ovf0) != 0ull;
       if (in_now) {
@@ -332,6 +339,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
     } else {
       // ---- leaves: ONE triangle per lane; the first hit inside [tmin, tmax] ends the ray
       PH(5, 1); PH(6, n_leaf);
+      PH(9, __popcll(__ballot(fin))); PH(11, __popcll(__ballot(!at_leaf && !fin)));
       if (at_leaf) {
         const bool from_p = pleaf != TRAV_DONE;        // the postponed leaf first: its slot frees
         const uint32_t lf = from_p ? pleaf : cur;
@@ -364,7 +372,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   // 0-6 are wave-uniform tallies (lane 0 speaks for the wave); 10 was counted by single lanes
   for (int i = 0; i < 16; i++) {
     const unsigned long long v = i == 10 ? wave_sum(ph[i]) : ph[i];
-    if (lane == 0 && v) atomicAdd(&g_phase[i], v);
+    if (lane == 0 && v) atomicAdd(&g_ahphase[i], v);      // (tallies of its own: g_phase also takes the closest-hit walks' ticks)
   }
 #endif
 }

@@ -198,6 +198,10 @@ static TravTune trav_tune()
     // (round 4, six waves and the cheaper step: 4 / 24 -> 8 / 16: C3 walk 58.1 -> 56.8 ms; 6 / 16 56.9, 6 / 12 57.3, 6 / 8 57.9, 4 / 32 59.2)
     t.anyhit_steps = env("FJGPU_TRAV_ANYHIT_STEPS", 8);
     t.min_inner = env("FJGPU_TRAV_MININNER", 16);
+    // the any-hit walk's vote between an inner step and a leaf step: inner while n_inner * leaf_bias8 >= n_leaf * 8 (8: whichever more lanes wait for)
+    // (round 5: lanes held at a leaf, not idle lanes, are what an inner step of the any-hit walk runs without -- 35.4 of 64 at inner nodes, 15.8 held,
+    // 12.8 idle on C3 --, so the leaf step runs a little before the held lanes are the majority; C3 walk at 10 / 8 / 6 / 5 / 4 / 3: 55.7 / 54.7 / 54.1 / 54.2 / 54.1 / 54.5 ms)
+    t.leaf_bias8 = env("FJGPU_TRAV_LEAF_BIAS", 5);
     // the phase-scheduled closest-hit walk (incoherent rays): C4 closest-hit side 758 / 748 ms at 3 / 5 steps, 766 / 758 / 739 at
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);
@@ -462,6 +466,17 @@ void debug_phase_stats()
   static const char *names[16] = {"iters", "entry_execs|entry_ticks", "entry_lanes", "inner_execs|inner_ticks", "inner_lanes", "leaf_execs|leaf_ticks", "leaf_lanes",
       "tri_execs|stage2_ticks", "tri_lanes", "", "hits", "refills", "tail_iters_max", "tail_iters_sum", "walk_iters_sum", "walk_waves"};
   for (int i = 0; i < 16; i++) if (names[i][0]) fprintf(stderr, "fjgpu phase %-24s %llu\n", names[i], h[i]);
+  // (the lean any-hit walk, tallies of its own: where the lanes are that take no part in a step -- idle = ray finished, waiting for the turnover)
+  {
+    unsigned long long a[16];
+    if (hipMemcpyFromSymbol(a, HIP_SYMBOL(g_ahphase), sizeof(a)) == hipSuccess && a[3] && a[5]) {
+      fprintf(stderr, "fjgpu phase anyhit-lanes: %llu iterations | inner steps %llu with %.1f lanes at inner nodes, %.1f idle, %.1f held at a leaf | leaf steps %llu with %.1f lanes, %.1f idle, "
+          "%.1f at inner nodes | turnovers %llu with %.1f lanes | %llu rays occluded\n", a[0], a[3], (double) a[4] / a[3], (double) a[7] / a[3], (double) a[8] / a[3], a[5], (double) a[6] / a[5],
+          (double) a[9] / a[5], (double) a[11] / a[5], a[1], (double) a[2] / (a[1] ? a[1] : 1), a[10]);
+      unsigned long long z[16] = {0};
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_ahphase), z, sizeof(z));
+    }
+  }
   // (the phase-scheduled closest-hit walk, traverse_phased: ticks / lanes of turnover, inner, leaf in 1..6, their executions in 7..9,
   //  trips of the instance loop summed over lanes in 10 and as the wave's maximum per turnover in 11)
   if (h[7] && h[11]) fprintf(stderr, "fjgpu phase phased-walk: turnover %llu execs %.1f lanes %.0f ticks | inner %llu execs %.1f lanes %.0f ticks | leaf %llu execs %.1f lanes %.0f ticks | "
