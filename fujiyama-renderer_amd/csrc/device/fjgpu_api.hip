@@ -318,7 +318,8 @@ static long g_flat_groups = 1;     // "flat_groups": scenes with incoherent clos
 static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occluders are all opaque walk their shadow rays with k_shadow_anyhit_curves
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
-static long g_device_build = 0;    // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree
+static long g_device_build = -1;   // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree; 0 = on the host; -1 = not set
+static long g_single_frame = 0;    // "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU
 
 extern "C" {
 
@@ -335,7 +336,8 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
   if (std::string(name) == "compact_squeue") { g_compact_squeue = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
-  if (std::string(name) == "device_build") { g_device_build = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+  if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
+  if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
 
@@ -787,8 +789,10 @@ static int build_host_scene(const fj_scene_desc *desc, fjgpu::HostScene *hs)
 {
   std::string err;
   const auto t_build0 = std::chrono::steady_clock::now();
-  long device_mode = g_device_build;
-  if (const char *e = getenv("FJGPU_DEVICE_BUILD")) device_mode = atoi(e) == 2 ? 2 : 1;
+  // not set: the host's binned-SAH build where frames repeat (its tree traces 3-6 % faster), the GPU's clustering build for a scene that
+  // renders one frame (0.03 s instead of 0.4 s at 7.2 M triangles; bin/scene on C3 end to end: 2.2 -> 1.5 s, profiles/r05_e2e_scene.txt)
+  long device_mode = g_device_build >= 0 ? g_device_build : (g_single_frame ? 1 : 0);
+  if (const char *e = getenv("FJGPU_DEVICE_BUILD")) device_mode = std::max(0, std::min(2, atoi(e)));
   const bool device_build = device_mode != 0;
   hs->device_build_quality = device_mode == 2 ? 0 : 1;
   const int be = fjgpu::BuildHostScene(desc, hs, &err, device_build);

@@ -490,7 +490,10 @@ static int render_scene(Scene *sc, Renderer *ren)
   std::vector<int> devices(want);
   for (int k = 0; k < want; k++) devices[k] = k;
   std::vector<fjgpu_scene *> gs(want, nullptr);
+  // (one frame per device scene: the BLAS of the meshes is built on the GPU unless the "device_build" option says otherwise, fjgpu.h)
+  fjgpu_global_option("single_frame_build", 1);
   int err = fjgpu_scene_create_multi(&sc->desc, devices.data(), want, gs.data());
+  fjgpu_global_option("single_frame_build", 0);
   if (err) { g_last_error = std::string("fjgpu_scene_create: ") + fjgpu_last_error(); return -1; }
   auto destroy_all = [&]() { for (fjgpu_scene *g : gs) fjgpu_scene_destroy(g); };
   // One frame per device scene here (it is destroyed below), like one frame per bin/scene process in the reference

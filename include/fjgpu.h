@@ -151,10 +151,12 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
 /* Process-wide options read by fjgpu_scene_create (which stands for the reference's
- * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" 0/1/2 -- 0 (default):
- * the host's binned-SAH build; 1: build the BLAS of meshes on the GPU by locally-ordered clustering
- * (surface-area agglomeration over the Morton order); 2: on the GPU as the radix tree of the Morton
- * codes (fastest build, slowest tree).
+ * build_accelerators(), src/fj_scene_interface.cc:1161-1202): "device_build" -1/0/1/2 -- 0: the host's binned-SAH
+ * build; 1: build the BLAS of meshes on the GPU by locally-ordered clustering (surface-area agglomeration over the
+ * Morton order); 2: on the GPU as the radix tree of the Morton codes (fastest build, slowest tree); -1 (default): not
+ * set -- the host build, or, for scenes created while "single_frame_build" is 1, the GPU's clustering build.
+ * "single_frame_build" 0/1: the caller renders ONE frame per scene it creates (SiRenderScene switches it on around its
+ * scene creation): the 0.4 s of host build the tree's 3-6 % faster frames would need many frames to earn back are not spent.
  * "device_tlas" 1/0 (default 1): the instance level of every group (the reference's BVHAccelerator over
  * ObjectInstances, src/fj_bvh_accelerator.cc:253-334) is built on the GPU; 0: by the host's builder (the
  * same list).  "tlas_verify" 0/1: scene creation also builds it on the host and fails on any byte that differs.

@@ -66,7 +66,7 @@ def test_global_options_and_host_build_paths_without_a_device(asset_dir):
     the whole host-side preparation (flatten, BLAS build or its device-build bypass, instance
     boxes, light tables) before it reports the missing device"""
     gpu.global_option("device_build", 1)
-    gpu.global_option("device_build", 0)
+    gpu.global_option("device_build", -1)
     with pytest.raises(gpu.GpuError) as e:
         gpu.global_option("no_such_option", 1)
     assert "unknown global option" in str(e.value)
@@ -84,7 +84,7 @@ def test_global_options_and_host_build_paths_without_a_device(asset_dir):
                     gpu.Scene(sp)
                 assert "no CPU fallback" in str(e.value)
             finally:
-                gpu.global_option("device_build", 0)
+                gpu.global_option("device_build", -1)
 
 
 def test_parser_grammar_and_errors(asset_dir):
