@@ -1,6 +1,9 @@
 // fjgpu_api.hip -- C ABI of libfjgpu.so (include/fjgpu.h): device scene
 // residency, the wavefront batch loop, and the ray-batch trace entry point.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <map>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -64,6 +67,60 @@ struct DeviceBuffers {
     return 0;
   }
 };
+
+// ---- RCCL, loaded at first use (no link-time dependency: the single-device paths never need it).  The slab exchange of
+// fjgpu_render_frame_multi in RCCL's spelling -- ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, SURVEY 8(e) -- beside the peer copy.
+struct Rccl {
+  typedef void *comm_t;
+  int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  void *handle = nullptr;
+  bool ok = false;
+  static constexpr int kFloat = 7;          // ncclFloat32 (rccl.h)
+};
+
+Rccl &rccl()
+{
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (R.handle) break; }
+    if (!R.handle) return;
+    auto sym = [&](const char *n) { return dlsym(R.handle, n); };
+    R.CommInitAll = (decltype(R.CommInitAll)) sym("ncclCommInitAll");
+    R.CommDestroy = (decltype(R.CommDestroy)) sym("ncclCommDestroy");
+    R.GroupStart = (decltype(R.GroupStart)) sym("ncclGroupStart");
+    R.GroupEnd = (decltype(R.GroupEnd)) sym("ncclGroupEnd");
+    R.Send = (decltype(R.Send)) sym("ncclSend");
+    R.Recv = (decltype(R.Recv)) sym("ncclRecv");
+    R.GetErrorString = (decltype(R.GetErrorString)) sym("ncclGetErrorString");
+    R.ok = R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv;
+  });
+  return R;
+}
+
+// one communicator set per list of devices, created at first use and kept for the process (bring-up takes of the order of a second)
+std::mutex g_rccl_mu;
+std::map<std::vector<int>, std::vector<Rccl::comm_t>> g_rccl_comms;
+
+const std::vector<Rccl::comm_t> *rccl_comms(const std::vector<int> &devices, std::string *why)
+{
+  Rccl &R = rccl();
+  if (!R.ok) { *why = "librccl.so not loadable"; return nullptr; }
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  auto it = g_rccl_comms.find(devices);
+  if (it != g_rccl_comms.end()) return it->second.empty() ? nullptr : &it->second;
+  std::vector<Rccl::comm_t> comms(devices.size(), nullptr);
+  const int e = R.CommInitAll(comms.data(), (int) devices.size(), devices.data());
+  if (e) { *why = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); comms.clear(); }
+  auto &slot = g_rccl_comms[devices] = comms;
+  return slot.empty() ? nullptr : &slot;
+}
 
 }  // namespace
 
@@ -319,6 +376,7 @@ static long g_curve_anyhit = 1;    // "curve_anyhit": curve scenes whose occlude
 static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance level of scenes that fit their budget in LDS (DInstEntry)
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
 static long g_device_build = -1;   // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree; 0 = on the host; -1 = not set
+static long g_multi_exchange = 0;  // "multi_exchange": how fjgpu_render_frame_multi moves the devices' tile slabs: 0 one hipMemcpyPeer each, 1 RCCL grouped send / recv
 static long g_single_frame = 0;    // "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU
 
 extern "C" {
@@ -338,6 +396,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
+  if (std::string(name) == "multi_exchange") { if (value < 0 || value > 1) return fail(FJGPU_EINVAL, "multi_exchange: 0 peer copies, 1 RCCL send / recv"); g_multi_exchange = value; return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
 
@@ -905,6 +964,35 @@ int fjgpu_set_batch_callback(fjgpu_scene *scene, fjgpu_batch_fn fn, void *user)
   return 0;
 }
 
+int fjgpu_dev_rccl_selftest(int device, int n_floats)
+{
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) return fail(FJGPU_ENODEV, "no such HIP device");
+  if (n_floats < 1) return fail(FJGPU_EINVAL, "bad size");
+  HIP_TRY(hipSetDevice(device));
+  std::string why;
+  const std::vector<Rccl::comm_t> *comms = rccl_comms(std::vector<int>{device}, &why);
+  if (!comms) return fail(FJGPU_ENODEV, "RCCL: " + why);
+  Rccl &R = rccl();
+  DeviceBuffers M;
+  std::vector<float> src((size_t) n_floats), got((size_t) n_floats, -1.f);
+  for (int i = 0; i < n_floats; i++) src[(size_t) i] = (float) (i % 1013) * .5f;
+  const float *d_src = nullptr;
+  float *d_dst = nullptr;
+  if (M.upload(src.data(), src.size(), &d_src) || M.alloc(src.size(), &d_dst)) return fail(FJGPU_ENOMEM, "device allocation failed");
+  HIP_TRY(hipMemset(d_dst, 0xff, sizeof(float) * src.size()));
+  // the exchange's own calls on a communicator of one rank: a send to, and the matching receive from, rank 0 in one group
+  int e = R.GroupStart();
+  if (!e) e = R.Send(d_src, src.size(), Rccl::kFloat, 0, (*comms)[0], nullptr);
+  if (!e) e = R.Recv(d_dst, src.size(), Rccl::kFloat, 0, (*comms)[0], nullptr);
+  const int e2 = R.GroupEnd();
+  if (e || e2) return fail(FJGPU_ENODEV, std::string("RCCL self exchange: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpy(got.data(), d_dst, sizeof(float) * got.size(), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < got.size(); i++) if (got[i] != src[i]) return fail(FJGPU_ENODEV, "RCCL self exchange returned other data");
+  return 0;
+}
+
 int fjgpu_dev_sort_pairs(int device, const uint32_t *keys, int n, int key_bits, uint32_t *keys_out, uint32_t *perm, int repeats, double *sort_ms)
 {
   if (n < 0 || key_bits < 1 || key_bits > 32 || (n > 0 && !keys)) return fail(FJGPU_EINVAL, "bad sort call");
@@ -961,6 +1049,7 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
 namespace {
 
 struct BatchTile { fjgpu::TileRect r; int nx, ny; uint32_t offset; };
+
 
 // compact queue records (DShadowRayC, 56 bytes) where the consumers rebuild direction and distance: the lean and the curve any-hit walk,
 // point / dome lights, no motion
@@ -1610,6 +1699,24 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
       return fail(FJGPU_ENOMEM, "device allocation failed for the tile slabs");
   }
 
+  // The exchange: one peer copy per device (default: nothing to bring up for a frame), or -- option "multi_exchange" 1 / FJGPU_MULTI_RCCL=1, devices all
+  // distinct -- RCCL's grouped point-to-point calls: every device's thread sends its slab to rank 0, whose thread posts all receives in one group
+  // (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd over xGMI).  A communicator set that cannot be created falls back to the peer copies.
+  const std::vector<Rccl::comm_t> *comms = nullptr;
+  {
+    bool want = g_multi_exchange == 1;
+    if (const char *e = getenv("FJGPU_MULTI_RCCL")) want = atoi(e) != 0;
+    std::vector<int> devs(G);
+    for (int d = 0; d < G; d++) devs[d] = scenes[d]->device;
+    std::vector<int> uniq = devs;
+    std::sort(uniq.begin(), uniq.end());
+    const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
+    if (want && G > 1 && distinct) {
+      std::string why;
+      comms = rccl_comms(devs, &why);
+      if (!comms && getenv("FJGPU_VERBOSE")) fprintf(stderr, "fjgpu: RCCL exchange not available (%s): peer copies\n", why.c_str());
+    }
+  }
   std::vector<int> rcs(G, 0);
   std::vector<std::string> errs(G);
   std::vector<fjgpu_stats> sts(G);
@@ -1644,8 +1751,24 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
       if (launch_move_tiles(nullptr, false, fb, r->xres, sc->d_rects, (int) mine[d].size(), tile_px, sc->d_slab)) return bad(FJGPU_ENODEV, "pack launch failed");
       // one peer copy per device: over xGMI when peer access is available, staged by the runtime otherwise
       const size_t bytes = mine[d].size() * (size_t) tile_px * 4 * sizeof(float);
-      if (hipMemcpyPeer(first->d_slab + stage_off[d] * 4, first->device, sc->d_slab, sc->device, bytes) != hipSuccess)
+      if (comms) {
+        Rccl &R = rccl();
+        int e = R.GroupStart();
+        if (!e) e = R.Send(sc->d_slab, bytes / sizeof(float), Rccl::kFloat, 0, (*comms)[d], nullptr);
+        const int e2 = R.GroupEnd();
+        if (e || e2 || hipStreamSynchronize(nullptr) != hipSuccess) return bad(FJGPU_ENODEV, std::string("RCCL send of a tile slab: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
+      }
+      else if (hipMemcpyPeer(first->d_slab + stage_off[d] * 4, first->device, sc->d_slab, sc->device, bytes) != hipSuccess)
         return bad(FJGPU_ENODEV, std::string("peer copy of a tile slab: ") + hipGetErrorString(hipGetLastError()));
+    }
+    else if (comms) {
+      // rank 0: every other device's slab, all receives in ONE group
+      Rccl &R = rccl();
+      int e = R.GroupStart();
+      for (int q = 1; q < G && !e; q++)
+        if (!mine[q].empty()) e = R.Recv(first->d_slab + stage_off[q] * 4, mine[q].size() * (size_t) tile_px * 4, Rccl::kFloat, q, (*comms)[0], nullptr);
+      const int e2 = R.GroupEnd();
+      if (e || e2 || hipStreamSynchronize(nullptr) != hipSuccess) return bad(FJGPU_ENODEV, std::string("RCCL receive of the tile slabs: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
     }
   };
   if (G == 1) work(0);

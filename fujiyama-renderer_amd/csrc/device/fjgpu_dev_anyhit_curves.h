@@ -223,7 +223,7 @@ __device__ void traverse_anyhit_curves(const DScene &S, const DShadowRay *squeue
       continue;
     }
 
-    if (n_inner >= n_leaf) {
+    if (n_inner * tune.leaf_bias8_canyhit >= n_leaf * 8u) {
       // ---- inner nodes: one 64-byte node per lane; further steps without a new vote while enough lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));

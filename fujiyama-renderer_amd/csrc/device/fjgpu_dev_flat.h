@@ -111,7 +111,7 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
       continue;
     }
 
-    if (n_inner >= n_leaf) {
+    if (n_inner * tune.leaf_bias8_flat >= n_leaf * 8u) {
       // ---- inner nodes; further steps without a new vote while enough lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));

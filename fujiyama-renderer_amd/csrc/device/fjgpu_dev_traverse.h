@@ -79,7 +79,7 @@ __device__ unsigned long long g_rayhist[64];
 #define FJ_TL_ITER(dry) do { } while (0)
 #define FJ_TL_END() do { } while (0)
 #endif
-struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased, refill_canyhit, steps_canyhit, min_inner_canyhit, leaf_wait_canyhit, refill_flat, steps_flat, min_inner_flat, leaf_bias8; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased, refill_canyhit, steps_canyhit, min_inner_canyhit, leaf_wait_canyhit, refill_flat, steps_flat, min_inner_flat, leaf_bias8, leaf_bias8_flat, leaf_bias8_phased, leaf_bias8_canyhit; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic
@@ -704,7 +704,7 @@ __device__ void traverse_phased(const DScene &S, Policy &pol, TravTune tune, uin
       continue;
     }
 
-    if (n_inner >= n_leaf) {
+    if (n_inner * tune.leaf_bias8_phased >= n_leaf * 8u) {
       // ---- inner nodes; further steps without a new vote while enough lanes stay at inner nodes
       for (uint32_t step = 0;; step++) {
         const bool in_now = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));

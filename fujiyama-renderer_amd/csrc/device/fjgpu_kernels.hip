@@ -202,6 +202,9 @@ static TravTune trav_tune()
     // (round 5: lanes held at a leaf, not idle lanes, are what an inner step of the any-hit walk runs without -- 35.4 of 64 at inner nodes, 15.8 held,
     // 12.8 idle on C3 --, so the leaf step runs a little before the held lanes are the majority; C3 walk at 10 / 8 / 6 / 5 / 4 / 3: 55.7 / 54.7 / 54.1 / 54.2 / 54.1 / 54.5 ms)
     t.leaf_bias8 = env("FJGPU_TRAV_LEAF_BIAS", 5);
+    t.leaf_bias8_flat = env("FJGPU_TRAV_LEAF_BIAS_FLAT", 8);
+    t.leaf_bias8_phased = env("FJGPU_TRAV_LEAF_BIAS_PHASED", 8);
+    t.leaf_bias8_canyhit = env("FJGPU_TRAV_LEAF_BIAS_CANYHIT", 8);
     // the phase-scheduled closest-hit walk (incoherent rays): C4 closest-hit side 758 / 748 ms at 3 / 5 steps, 766 / 758 / 739 at
     // min_inner 32 / 24 / 16; with 5 steps 727 / 716 at 16 / 12
     t.steps_phased = env("FJGPU_TRAV_STEPS_PHASED", 5);

@@ -36,6 +36,7 @@ def lib():
         L.fjgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.fjgpu_global_option.argtypes = [C.c_char_p, C.c_long]
         L.fjgpu_scene_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        L.fjgpu_dev_rccl_selftest.argtypes = [C.c_int, C.c_int]
         L.fjgpu_dev_sort_pairs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -168,6 +169,11 @@ def global_option(name, value):
 
 def tile_count(render):
     return lib().fjgpu_tile_count(C.byref(render))
+
+
+def rccl_selftest(device=0, n_floats=1 << 20):
+    """RCCL bring-up on one device through the core's own loader (include/fjgpu.h: fjgpu_dev_rccl_selftest)"""
+    _check(lib().fjgpu_dev_rccl_selftest(device, n_floats))
 
 
 def sort_pairs(keys, key_bits, device=0, repeats=1):

@@ -155,6 +155,10 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * build; 1: build the BLAS of meshes on the GPU by locally-ordered clustering (surface-area agglomeration over the
  * Morton order); 2: on the GPU as the radix tree of the Morton codes (fastest build, slowest tree); -1 (default): not
  * set -- the host build, or, for scenes created while "single_frame_build" is 1, the GPU's clustering build.
+ * "multi_exchange" 0/1: how fjgpu_render_frame_multi moves the devices' tile slabs to the first device -- 0 (default): one hipMemcpyPeer per
+ * device (over xGMI where peer access exists; nothing to bring up, which is what a one-frame process wants); 1: RCCL, every device's thread
+ * sends its slab with ncclSend, the first device posts all ncclRecv in one ncclGroupStart / ncclGroupEnd (librccl.so is loaded at first use;
+ * devices must be distinct; a communicator that cannot be created falls back to the peer copies).  Same bytes over the same links.
  * "single_frame_build" 0/1: the caller renders ONE frame per scene it creates (SiRenderScene switches it on around its
  * scene creation): the 0.4 s of host build the tree's 3-6 % faster frames would need many frames to earn back are not spent.
  * "device_tlas" 1/0 (default 1): the instance level of every group (the reference's BVHAccelerator over
@@ -209,6 +213,12 @@ void fjgpu_host_make_transform(int transform_order, int rotate_order, const doub
 void fjgpu_host_xorshift_f01(int n, double *out);
 void fjgpu_host_sampler_margin(const fj_render_desc *render, int32_t *margin2);
 double fjgpu_host_camera_uv_size_y(double fov);
+
+/* Diagnostics: RCCL bring-up on one device.  fjgpu_render_frame_multi can move the devices' tile slabs with RCCL's grouped point-to-point
+ * calls (global option "multi_exchange" 1); this runs the same calls -- ncclCommInitAll, ncclGroupStart, ncclSend + ncclRecv, ncclGroupEnd --
+ * on a communicator of ONE rank (`device` sends n_floats to itself) and checks the data: librccl.so is loadable, its symbols bind, a
+ * collective-library kernel runs.  0, or FJGPU_ENODEV with the reason. */
+int fjgpu_dev_rccl_selftest(int device, int n_floats);
 
 /* Diagnostics: the ray-queue sort on its own (fjgpu_raysort.hip: the hand-written wave64 LSD radix sort that orders the rays
  * of recursion level >= 1 in front of the closest-hit walk).  Sorts the pairs (keys[i], i) of HOST arrays on `device`,

@@ -812,6 +812,34 @@ def test_multi_device_frame_equals_single_device_frame(asset_dir):
         ms.close()
 
 
+def test_rccl_spelling_of_the_slab_exchange(asset_dir):
+    """the C++ core's RCCL path (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd for the tile slabs of
+    fjgpu_render_frame_multi, option "multi_exchange" 1): librccl.so loads through the core's own loader and the exchange's calls run on
+    this GPU (a communicator of one rank that sends to itself: fjgpu_dev_rccl_selftest); with the option on, a one-device frame and a
+    frame of replicas that share a device -- RCCL refuses two ranks on one GPU, the core keeps the peer copies there -- are unchanged;
+    the multi-GPU form needs a node with several GPUs (the driver's scaling run uses the per-process form of bench.py --gpus N)"""
+    gpu.rccl_selftest(0, 1 << 18)
+    gpu.rccl_selftest(0, 1)
+    with pytest.raises(gpu.GpuError):
+        gpu.global_option("multi_exchange", 2)
+    text = workloads.teapot(asset_dir, res=(100, 76), spp=(2, 2), mesh="tiny", extra=(("tilesize", (16, 16)),))
+    sp, rd = prepare(text)
+    gs = gpu.Scene(sp)
+    one, st1 = gs.render_frame(rd)
+    gpu.global_option("multi_exchange", 1)
+    try:
+        again, st2 = gs.render_frame(rd)
+        assert float(rel_err(again, one).max()) <= 1e-6 and st2.rays.as_dict() == st1.rays.as_dict()
+        ms = gpu.MultiScene(sp, [0, 0])
+        fb, sts = ms.render_frame(rd)
+        ms.close()
+        assert float(rel_err(fb, one).max()) <= 1e-6
+        assert sum(s.rays.total() for s in sts) == st1.rays.total()
+    finally:
+        gpu.global_option("multi_exchange", 0)
+        gs.close()
+
+
 def test_si_callbacks_and_interrupts(asset_dir):
     """SiSetFrameReportCallback / SiSetTileReportCallback (src/fj_callback.h:15-98) on the GPU path:
     one tile_start / tile_done per tile, TileInfo.framebuffer readable in tile_done, and the
