@@ -22,10 +22,10 @@ gs.close()
 print("device: %.1f ms, rays %s" % (st.total_ms, st.rays.as_dict()), flush=True)
 t0 = time.perf_counter()
 osc = oracle_ffi.OracleScene(sp)
-ref, rc = osc.render(rd, threads=min(64, os.cpu_count() or 1))
+ref, rc = osc.render(rd, threads=os.cpu_count() or 1)
 osc.close()
 dt = time.perf_counter() - t0
-print("oracle: %.1f s (build + render, %d threads), rays %s" % (dt, min(64, os.cpu_count() or 1), rc.as_dict()), flush=True)
+print("oracle: %.1f s (build + render, %d threads), rays %s" % (dt, os.cpu_count() or 1, rc.as_dict()), flush=True)
 rel = np.abs(fb - ref) / np.maximum(np.abs(ref), 1e-3)
 print("ray counts equal:", st.rays.as_dict() == rc.as_dict())
 print("pixels %d x %d: max relative error %.3g, max absolute %.3g, pixels above 1e-5 relative: %d, identical: %.2f %%" % (

@@ -20,6 +20,6 @@ for l in sys.stdin:
 if cur:
     rows.append(cur)
 for r in rows:
-    n = subprocess.run(['c++filt', r['name']], capture_output=True, text=True).stdout.strip().split('(')[0]
+    n = subprocess.run(['c++filt', r['name']], capture_output=True, text=True).stdout.strip().replace('(anonymous namespace)::', '').split('(')[0]
     if flt in n:
         print("%-52s vgprs %3d  spill %3d  lds %6d  waves/SIMD %d" % (n[:52], r.get('vgprs', 0), r.get('spill', 0), r.get('lds', 0), r.get('waves', 0)))
