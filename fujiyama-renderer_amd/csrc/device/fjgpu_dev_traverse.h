@@ -108,21 +108,9 @@ __device__ __forceinline__ uint32_t xcc_id()      // the XCD this wave runs on (
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
   return x & 0xfu;
 }
-// FJ_GUIDED_CLAIMS (experiment, default off): towards the end of a region a wave claims less than `grab` -- what it last saw left of the
-// region over twice the waves that pull from it (guided self-scheduling), never below FJ_GUIDED_MIN -- so that the launch does not end
-// with a few waves working through full-size claims of expensive rays.  Unlike round 2's guided claims (a second device-scope round trip
-// per claim to read the head: every walk 5-10 % slower) the estimate comes from the return value of the wave's PREVIOUS claim: no memory
-// operation is added.
-#ifndef FJ_GUIDED_CLAIMS
-#define FJ_GUIDED_CLAIMS 0
-#endif
-#ifndef FJ_GUIDED_MIN
-#define FJ_GUIDED_MIN 64u
-#endif
 struct QueueClaim {
   uint32_t *heads;
   uint32_t n, per, grab, region, left;
-  uint32_t seen, pullers;          // (guided claims) the region's head as this wave last saw it; waves per region
   __device__ __forceinline__ void init(uint32_t *heads_, uint32_t n_, uint32_t grab_)
   {
     heads = heads_; n = n_; grab = grab_;
@@ -130,9 +118,6 @@ struct QueueClaim {
     per = ((n / parts + grab) / grab) * grab;       // a multiple of the claim; parts * per >= n
     region = FJ_XCD_HEADS ? (xcc_id() & 7u) : 0u;
     left = parts;
-    seen = 0;
-    pullers = (gridDim.x * (BLOCK / 64)) / parts;
-    if (pullers == 0) pullers = 1;
   }
   // the next slice [*next, *range_end) of the queue; false: the queue is empty
   __device__ __forceinline__ bool claim(unsigned lane, uint32_t *next, uint32_t *range_end)
@@ -141,21 +126,13 @@ struct QueueClaim {
       const uint32_t lo = region * per;
       if (lo < n) {
         const uint32_t hi = (n - lo < per) ? n : lo + per;
-        uint32_t take = grab;
-        if (FJ_GUIDED_CLAIMS) {
-          const uint32_t rest = seen < hi - lo ? hi - lo - seen : 0u;
-          const uint32_t g = rest / (2u * pullers);
-          take = g >= grab ? grab : (g < FJ_GUIDED_MIN ? (FJ_GUIDED_MIN < grab ? FJ_GUIDED_MIN : grab) : g);
-        }
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&heads[region * 32u], take);
+        if (lane == 0) base = atomicAdd(&heads[region * 32u], grab);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (FJ_GUIDED_CLAIMS) seen = base + take;
-        if (base < hi - lo) { *next = lo + base; *range_end = (hi - *next < take) ? hi : *next + take; return true; }
+        if (base < hi - lo) { *next = lo + base; *range_end = (hi - *next < grab) ? hi : *next + grab; return true; }
       }
       left--;
       region = (region + 1u) & 7u;
-      if (FJ_GUIDED_CLAIMS) seen = 0;
     }
     return false;
   }
