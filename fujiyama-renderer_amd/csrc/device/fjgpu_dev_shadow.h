@@ -49,11 +49,30 @@ __device__ __forceinline__ void sq_ray(const DScene &S, const DShadowRay *squeue
   *o = Ps; *d = Ln; *tmax = distance;
 }
 
+// a light sample through the constant address space (wave-uniform address: scalar loads)
+__device__ __forceinline__ DLightSample ld_light_sample_k(const DLightSample *p)
+{
+  typedef const __attribute__((address_space(4))) double kd;
+  typedef const __attribute__((address_space(4))) float kf;
+  typedef const __attribute__((address_space(4))) int32_t ki;
+  kd *q = (kd *) (uintptr_t) p;
+  kf *f = (kf *) (uintptr_t) (p->Cl);
+  ki *i = (ki *) (uintptr_t) (&p->light);
+  DLightSample r;
+  r.P[0] = q[0]; r.P[1] = q[1]; r.P[2] = q[2];
+  r.Cl[0] = f[0]; r.Cl[1] = f[1]; r.Cl[2] = f[2];
+  r.light = i[0]; r.type = i[1]; r.ordinal = i[2];
+  return r;
+}
+
 #ifndef FJ_CULL_MINB
 #define FJ_CULL_MINB 1
 #endif
 #ifndef FJ_CULL_MINB_PLAIN
-#define FJ_CULL_MINB_PLAIN 3      // point lights, no hair: 166 VGPRs as written; the split instantiation is held to the same 3 waves
+#define FJ_CULL_MINB_PLAIN 3      // point lights, no hair, rays split per candidate instance: 164 VGPRs as written (capped to 128 it spills 21-24)
+#endif
+#ifndef FJ_CULL_MINB_WHOLE
+#define FJ_CULL_MINB_WHOLE 4      // ... whole rays (single-instance shadow groups: C3, C6): 137 VGPRs as written, 127 without a spill when capped: C3 light loop 18.9 -> 18.5 ms
 #endif
 // kNodesLds: every block keeps the scene's threaded instance nodes (DScene.group_nodes, at most FJ_CULL_LDS_NODES) in LDS -- the
 // candidate search of a (point, light) pair is a chain of dependent node reads (launch_shadow_cull picks it where the scene fits)
@@ -61,7 +80,7 @@ __device__ __forceinline__ void sq_ray(const DScene &S, const DShadowRay *squeue
 #define FJ_CULL_LDS_NODES 292      // 16 352 bytes
 #endif
 template <bool kHair, bool kArea, bool kSplit, bool kNodesLds = false>
-__global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CULL_MINB_PLAIN) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
+__global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : (kSplit ? FJ_CULL_MINB_PLAIN : FJ_CULL_MINB_WHOLE)) k_shadow_cull(DScene S, ShadowParams sp, const DLightRec *lrecs,
     uint32_t rec_begin, uint32_t rec_end, float *s_accum, DShadowRay *squeue, DCounters *cnt, int count_events)
 {
   __shared__ double s_nodes[kNodesLds ? FJ_CULL_LDS_NODES * 7 : 1];
@@ -158,7 +177,11 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : FJ_CU
       double dist_s = 0;
       float k_s[3] = {0.f, 0.f, 0.f};
       if (active) {
-        const DLightSample LS = S.light_samples[l];
+        // (the table is written once at scene creation: read through the constant address space the wave-uniform record comes through the scalar
+        // cache into SGPRs -- as a generic pointer it was three vector loads of 64 identical lanes, waited for at the head of every iteration:
+        // C3 light loop 19.8 -> 18.9 ms, C6 47.9 -> 46.5, C5 57.7 -> 55.3)
+        // (loaded one iteration ahead: 18.8 -> 19.8 ms, dropped)
+        const DLightSample LS = ld_light_sample_k(S.light_samples + l);
         V3 Pl = mk(LS.P[0], LS.P[1], LS.P[2]);
         float Cl[3] = {LS.Cl[0], LS.Cl[1], LS.Cl[2]};
         if (kArea && (LS.type == FJ_GRID_LIGHT || LS.type == FJ_SPHERE_LIGHT)) {
