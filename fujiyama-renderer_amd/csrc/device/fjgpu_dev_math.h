@@ -281,7 +281,10 @@ __device__ __noinline__ void xform_at(const fj_xform_desc *x, double time, doubl
 #ifndef FJ_BOXREF_ATTR
 #define FJ_BOXREF_ATTR __forceinline__
 #endif
-__device__ FJ_BOXREF_ATTR bool box_ray_ref(const double *b, V3 o, V3 d, double ray_tmin, double ray_tmax)
+// (BoxPtr: `const double *`, or a pointer with an address space -- a box behind a pointer that came out of a record is generic to the
+// compiler: FLAT loads, each waited for with both counters)
+template <class BoxPtr>
+__device__ FJ_BOXREF_ATTR bool box_ray_ref(BoxPtr b, V3 o, V3 d, double ray_tmin, double ray_tmax)
 {
   double tmin, tmax, tymin, tymax, tzmin, tzmax;
   if (d.x >= 0) { tmin = (b[0] - o.x) / d.x; tmax = (b[3] - o.x) / d.x; }
@@ -304,7 +307,8 @@ __device__ FJ_BOXREF_ATTR bool box_ray_ref(const double *b, V3 o, V3 d, double r
 // every case that is not within 1e-12 (relative) of a boundary; the rest takes the exact
 // path.  `plain` = no direction component is zero (else 0 * inf = NaN: exact path);
 // overflow makes m infinite, which also lands in the exact path.
-__device__ __forceinline__ bool box_ray_ref_fast(const double *b, V3 o, V3 d, V3 inv, bool plain, double ray_tmin, double ray_tmax)
+template <class BoxPtr>
+__device__ __forceinline__ bool box_ray_ref_fast(BoxPtr b, V3 o, V3 d, V3 inv, bool plain, double ray_tmin, double ray_tmax)
 {
   const double x0 = (b[0] - o.x) * inv.x, x1 = (b[3] - o.x) * inv.x;
   const double y0 = (b[1] - o.y) * inv.y, y1 = (b[4] - o.y) * inv.y;
