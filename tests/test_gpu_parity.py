@@ -325,6 +325,17 @@ def test_tile_subsets_and_batching_are_consistent(asset_dir):
     one_by_one, st1 = gs.render_frame(rd)
     assert float(rel_err(one_by_one, full).max()) <= 1e-6
     assert st1.rays.as_dict() == st_full.rays.as_dict() and st1.batches == 15
+    # ... and by a sample budget (option "batch_samples": what SiRenderScene sets for its one-frame scenes): batches of whole tiles
+    # that hold at most that many samples, batch_tiles = 0 meaning "not set"
+    gs.set_option("batch_tiles", 0)
+    per_tile = (2 * rd.tile_w + 2 * 2) * (2 * rd.tile_h + 2 * 2)          # (upper bound of a tile's samples: rate 2, filter margin <= 2)
+    gs.set_option("batch_samples", 4 * per_tile)
+    by_samples, st2 = gs.render_frame(rd)
+    assert float(rel_err(by_samples, full).max()) <= 1e-6
+    assert st2.rays.as_dict() == st_full.rays.as_dict() and 4 <= st2.batches <= 8
+    gs.set_option("batch_samples", 0)
+    whole, st3 = gs.render_frame(rd)
+    assert st3.batches == 1 and float(rel_err(whole, full).max()) <= 1e-6
     gs.close()
 
 
