@@ -359,7 +359,9 @@ static bool build_flat_groups(const fjgpu::HostScene &hs, std::vector<HostFlat> 
   out->clear();
   if (hs.groups.empty() || !hs.xforms.empty()) return false;
   std::vector<HostFlat> flats(hs.groups.size());
-  for (size_t g = 0; g < hs.groups.size(); g++) if (!build_flat_group(hs, g, (size_t) FJ_FLAT_MAX_TRIS, &flats[g])) return false;
+  size_t max_tris = (size_t) FJ_FLAT_MAX_TRIS;
+  if (const char *e = getenv("FJGPU_FLAT_MAX_TRIS_LOG2")) max_tris = (size_t) 1 << std::max(1, std::min(27, atoi(e)));
+  for (size_t g = 0; g < hs.groups.size(); g++) if (!build_flat_group(hs, g, max_tris, &flats[g])) return false;
   out->swap(flats);
   return true;
 }
@@ -391,7 +393,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "split_shadow") { g_split_shadow = value != 0; return 0; }
   if (std::string(name) == "inst_lds") { g_inst_lds = value != 0; return 0; }
   if (std::string(name) == "curve_anyhit") { g_curve_anyhit = value != 0; return 0; }
-  if (std::string(name) == "flat_groups") { g_flat_groups = value != 0; return 0; }
+  if (std::string(name) == "flat_groups") { g_flat_groups = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "compact_squeue") { g_compact_squeue = value != 0; return 0; }
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
@@ -730,12 +732,14 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       if (sh.type == FJ_SHADER_PATHTRACING && (lum(sh.diffuse) || (int) lum(sh.reflect) + (int) lum(sh.refract) >= 2)) incoherent = true;
     }
     std::vector<HostFlat> hf;
-    // k_trace_closest_flat reads the instance level from its blocks' LDS copy (launch_trace_closest: S.flats && InstLds::fits(S)):
-    // a scene beyond that budget -- build_flat_group admits 32 instances per group, the LDS copy 16 in all -- or with the option
-    // off would walk k_trace_closest_phased, and must then keep the ray sort that walk wants.  ONE decision, made here: such a
-    // scene builds no flat trees, S.flats stays null, and ray_sort_bits / the closest_kernel query / the launcher all follow it.
-    const bool flat_fits = S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES && S.n_instances <= FJ_INST_LDS_INSTS && S.n_groups <= FJ_INST_LDS_GROUPS;
-    if (incoherent && flat_fits && g_flat_groups && !getenv("FJGPU_NO_FLAT") && FJ_CLOSEST_QNODES && build_flat_groups(hs, &hf)) {
+    // k_trace_closest_flat keeps M^-1 of every instance in its blocks' LDS (FJ_FLAT_LDS_INSTS of them; until round 5 it shared the phased walk's
+    // copy of the whole instance level and its budget of 16 instances, while build_flat_group admits 32 per group: ADVICE round 4).  ONE decision,
+    // made here: a scene beyond the budget, or with the inst_lds option off, builds no flat trees, S.flats stays null, and ray_sort_bits / the
+    // closest_kernel query / the launcher all follow it.
+    const bool flat_fits = S.inst_lds && S.n_instances <= FJ_FLAT_LDS_INSTS;
+    // (option "flat_groups" 2 / FJGPU_FLAT_ALL: scenes with coherent closest-hit rays as well)
+    const bool flat_wanted = incoherent || g_flat_groups >= 2 || getenv("FJGPU_FLAT_ALL");
+    if (flat_wanted && flat_fits && g_flat_groups && !getenv("FJGPU_NO_FLAT") && FJ_CLOSEST_QNODES && build_flat_groups(hs, &hf)) {
       std::vector<DFlat> df(hf.size());
       for (size_t g = 0; g < hf.size() && !e; g++) {
         HostFlat &F = hf[g];
@@ -945,8 +949,7 @@ int fjgpu_scene_query(const fjgpu_scene *scene, const char *name, double *value)
   // 4 k_trace_closest_flat (incoherent rays, every group flat, instance level within the phased walk's LDS budget)
   if (n == "closest_kernel") {
     const DScene &S = scene->S;
-    const bool flat = !S.has_motion && !S.has_curves && S.incoherent_rays && S.flats && S.inst_lds && S.n_group_nodes <= FJ_INST_LDS_NODES &&
-        S.n_instances <= FJ_INST_LDS_INSTS && S.n_groups <= FJ_INST_LDS_GROUPS;
+    const bool flat = !S.has_motion && !S.has_curves && S.flats;
     *value = S.has_motion ? 3 : (S.has_curves ? 2 : (flat ? 4 : (S.incoherent_rays ? 1 : 0)));
     return 0;
   }

@@ -23,7 +23,7 @@
 template <bool kCount, bool kOne, class Policy>
 __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint32_t n, uint32_t *head, TravStack stk, LocalCounters *lc, const double *s_inst)
 {
-  const DInstEntry *gents = (const DInstEntry *) (s_inst + InstLds::ENTRIES_AT);
+  const double *s_minv = s_inst;          // [instance][12]: M^-1 of every instance (k_trace_closest_flat fills it)
   const unsigned lane = __lane_id();
   bool head_live = true;
   uint32_t next = 0, range_end = 0;        // wave-uniform: the wave's claimed slice of the queue
@@ -156,8 +156,8 @@ __device__ void traverse_flat(const DScene &S, Policy &pol, TravTune tune, uint3
         const uint32_t ref_io = q2.y;
         const uint32_t inst = ref_io >> 8, ord = ref_io & 255u, bit = 1u << ord;
         if (!(fl_fail & bit)) {
-          const DInstEntry *E = &gents[inst];
-          const V3 oo = xpoint(E->Minv, o), od = xvector(E->Minv, d);
+          const double *Mi = s_minv + 12 * inst;
+          const V3 oo = xpoint(Mi, o), od = xvector(Mi, d);
           bool ok = true;
           if (!(fl_pass & bit)) {
             // first candidate of this instance for this ray: the tests that decide whether the ray reaches the instance at all
@@ -207,8 +207,10 @@ __global__ void __launch_bounds__(BLOCK, FJ_FLAT_MINB) k_trace_closest_flat(DSce
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
   __shared__ uint32_t s_stack[FJ_STACK_LDS_FLAT * BLOCK];
-  __shared__ double s_inst[InstLds::WORDS];
-  InstLds::fill(S, s_inst);         // (the launcher picked this kernel because the scene fits)
+  __shared__ double s_inst[FJ_FLAT_LDS_INSTS * 12];
+  // M^-1 of every instance (the launcher picked this kernel because the scene has at most FJ_FLAT_LDS_INSTS of them)
+  for (uint32_t w = threadIdx.x; w < (uint32_t) S.n_instances * 12u; w += BLOCK) s_inst[w] = S.inst_entries[w / 12u].Minv[w % 12u];
+  __syncthreads();
   ClosestPolicy pol;
   pol.S = &S; pol.rays = rays; pol.paths = paths; pol.hits = hits; pol.default_group = S.target_group;
   LocalCounters lc = {0, 0, 0};

@@ -298,7 +298,7 @@ int launch_trace_closest(hipStream_t st, const DScene &S, const DRay *rays, cons
     }
     else if (count_events) FJ_LAUNCH_CLOSEST(true, true, false); else FJ_LAUNCH_CLOSEST(true, false, false);
   }
-  else if (S.incoherent_rays && S.flats && InstLds::fits(S)) {      // ... whose groups are flat: one world-space tree per group (fjgpu_dev_flat.h)
+  else if (S.flats) {      // scenes whose groups are flat: one world-space tree per group (fjgpu_dev_flat.h; built only where the scene fits the kernel)
     if (S.n_groups == 1) {      // (one group: its arrays in scalar registers)
       if (count_events) hipLaunchKernelGGL((k_trace_closest_flat<true, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());
       else hipLaunchKernelGGL((k_trace_closest_flat<false, true>), grid, dim3(BLOCK), 0, st, S, rays, paths, hits, n, cnt, trav_tune());

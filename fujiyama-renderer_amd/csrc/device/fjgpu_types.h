@@ -156,6 +156,8 @@ struct DInstEntry {
 #define FJ_INST_LDS_NODES_CURVES 15     // the curve instantiations (3 blocks per CU, 20 KB of stacks + 28 KB of ray space per block): 3 656 bytes
 #define FJ_INST_LDS_INSTS_CURVES 6
 #define FJ_INST_LDS_GROUPS_CURVES 12
+// k_trace_closest_flat needs M^-1 of a candidate's instance and nothing else of the instance level: a table of 12 doubles per instance in LDS
+#define FJ_FLAT_LDS_INSTS 80            // 7 680 bytes (what the phased walk's instance level takes: 4 blocks per CU either way)
 #define FJ_INST_LDS_BYTES (FJ_INST_LDS_NODES * 56 + FJ_INST_LDS_INSTS * 8 * FJ_INST_LDS_ENTRY_WORDS + FJ_INST_LDS_GROUPS * 64)
 
 // Everything the lean any-hit walk needs to enter an instance, in one record (one dependent

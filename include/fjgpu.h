@@ -172,16 +172,18 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * instead of walking the group's instance level in the traversal kernel (C2: 134 -> 121 ms per frame).
  * "compact_squeue" 1/0 (default 1): shadow-queue records of 56 instead of 80 bytes (no direction / distance: the walk rebuilds them from the origin and
  * the light sample, same statements, same bits) where the lean or the curve any-hit walk consumes the queue and the lights are point / dome lights.
- * "flat_groups" 1/0 (default 1): scenes created from now on whose closest-hit rays are incoherent (glass, pathtracing shaders) and whose groups hold only
- * small static meshes built on the host (at most 2 M triangles and 32 instances per group) get ONE world-space culling tree per group over the
- * triangles of all its instances; the exact tests stay in object space (k_trace_closest_flat).  0: the instance loop of k_trace_closest_phased.
+ * "flat_groups" 0/1/2 (default 1): scenes created from now on whose closest-hit rays are incoherent (glass, pathtracing shaders) and whose groups hold only
+ * small static meshes built on the host (at most 2 M triangles and 32 instances per group, 80 instances in the scene: the walk keeps every instance's
+ * M^-1 in LDS) get ONE world-space culling tree per group over the triangles of all its instances; the exact tests stay in object space
+ * (k_trace_closest_flat).  0: the instance loop of k_trace_closest_phased.  2: scenes with coherent rays as well (an experiment switch: their walks lose
+ * with it -- C2's closest-hit side 21 -> 29 ms, C3's 24 -> 104 with FJGPU_FLAT_MAX_TRIS_LOG2=25 -- profiles/r05_flat_for_coherent_scenes.txt).
  * "curve_anyhit" 1/0 (default 1): scenes created from now on that hold curve sets, no time-sampled motion and only opaque occluders walk their
  * shadow rays with k_shadow_anyhit_curves (phase-scheduled, ribbon tests as a phase of their own); 0: with the general k_shadow_trace.
  * "inst_lds" 1/0 (default 1): scenes created from now on whose instance level is small (79 threaded nodes / 33 instances /
- * 24 groups for the closest-hit and general shadow walks of mesh scenes, 39 / 16 / 12 for the phase-scheduled and the flat-group
- * walk, 15 / 6 / 12 for the walks of curve scenes, 292 nodes for the light loop; one instance is a 304-byte DInstEntry) have it
+ * 24 groups for the closest-hit and general shadow walks of mesh scenes, 39 / 16 / 12 for the phase-scheduled walk (the flat-group
+ * walk keeps only M^-1 of up to 80 instances), 15 / 6 / 12 for the walks of curve scenes, 292 nodes for the light loop; one instance is a 304-byte DInstEntry) have it
  * copied to LDS by every block of those walks; 0, or a scene beyond its kernel's budget: it is read from global memory (same
- * results; a scene beyond the 39 / 16 / 12 budget also builds no flat groups).
+ * results; option 0, or a scene of more than 80 instances, also builds no flat groups).
  * "batch_tiles" n: scenes created from now on start with the per-scene option of that name set to n (0 = sized by
  * memory; how a host that never sees the scene handle -- SiRenderScene -- cuts a frame into batches).  0 or FJGPU_EINVAL. */
 int fjgpu_global_option(const char *name, long value);
