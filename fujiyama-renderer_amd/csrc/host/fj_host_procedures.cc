@@ -12,7 +12,13 @@
 #include <thread>
 #include "fj_host.h"
 
+#include <chrono>
 #include <cstdint>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <functional>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -55,18 +61,30 @@ struct Reader {
   std::ifstream f;
   int format;   // 0 ascii, 1 little, 2 big
   bool ok;
-  std::vector<char> body;     // binary files: everything after the header, read in one piece (a stream read per
-  size_t pos = 0;             // number cost 0.8 s of the 1.5 s a 7.2 M-triangle scene takes to assemble)
-  void slurp()
+  // binary files: everything after the header in one piece (a stream read per number cost 0.8 s of the 1.5 s a 7.2 M-triangle scene took to
+  // assemble) -- the file is mapped, not copied (a 104 MB read into a zero-filled vector was a third of what was left of the procedure)
+  struct View { const char *p = nullptr; size_t n = 0; const char *data() const { return p; } size_t size() const { return n; } } body;
+  void *map = nullptr; size_t map_len = 0;
+  std::vector<char> copy;
+  size_t pos = 0;
+  ~Reader() { if (map) munmap(map, map_len); }
+  void slurp(const std::string &path)
   {
     const std::streampos here = f.tellg();
     f.seekg(0, std::ios::end);
     const std::streampos end = f.tellg();
     f.seekg(here);
-    body.resize((size_t) (end - here));
-    if (!body.empty()) f.read(body.data(), (std::streamsize) body.size());
-    if (!f) ok = false;
     pos = 0;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd >= 0) {
+      void *m = mmap(nullptr, (size_t) end, PROT_READ, MAP_PRIVATE, fd, 0);
+      ::close(fd);
+      if (m != MAP_FAILED) { map = m; map_len = (size_t) end; body.p = (const char *) m + (size_t) here; body.n = (size_t) (end - here); return; }
+    }
+    copy.resize((size_t) (end - here));
+    if (!copy.empty()) f.read(copy.data(), (std::streamsize) copy.size());
+    if (!f) ok = false;
+    body.p = copy.data(); body.n = copy.size();
   }
   double read_number(PlyType t)
   {
@@ -99,6 +117,7 @@ struct Reader {
 
 int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
 {
+  const auto t0_ = std::chrono::steady_clock::now();
   Reader rd;
   rd.ok = true;
   rd.format = -1;
@@ -141,7 +160,7 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
     }
   }
   if (rd.format < 0) { *err = "unknown PLY format in " + path; return -1; }
-  if (rd.format != 0) rd.slurp();
+  if (rd.format != 0) rd.slurp(path);
 
   std::vector<double> P;
   std::vector<float> uv;
@@ -164,6 +183,93 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
       P.assign(3 * (size_t) nverts, 0.);
       has_uv = iu >= 0 || iv >= 0;
       if (has_uv) uv.assign(2 * (size_t) nverts, 0.f);
+    }
+    // Fast paths for little-endian binary files (what the converters write): fixed-size vertex records are decoded on the host threads; so are
+    // faces that all have the same number of corners (one list property, verified before anything is written).  Same values as the loop below.
+    if (rd.format == 1 && e.count > 0) {
+      const unsigned hc = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+      const unsigned nt = (unsigned) std::max<long>(1, std::min<long>((long) hc, e.count / 65536 + 1));
+      auto run = [&](const std::function<void(long, long)> &fn) {
+        if (nt == 1) { fn(0, e.count); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, e.count * t / nt, e.count * (t + 1) / nt);
+        for (auto &x : th) x.join();
+      };
+      auto num = [](const char *p, PlyType t) -> double {
+        switch (t) {
+        case T_I8: { int8_t v; std::memcpy(&v, p, 1); return v; }
+        case T_U8: { uint8_t v; std::memcpy(&v, p, 1); return v; }
+        case T_I16: { int16_t v; std::memcpy(&v, p, 2); return v; }
+        case T_U16: { uint16_t v; std::memcpy(&v, p, 2); return v; }
+        case T_I32: { int32_t v; std::memcpy(&v, p, 4); return v; }
+        case T_U32: { uint32_t v; std::memcpy(&v, p, 4); return v; }
+        case T_F32: { float v; std::memcpy(&v, p, 4); return v; }
+        case T_F64: { double v; std::memcpy(&v, p, 8); return v; }
+        default: return 0;
+        }
+      };
+      bool fixed = true;
+      size_t stride = 0;
+      std::vector<size_t> off(e.props.size(), 0);
+      for (size_t k = 0; k < e.props.size(); k++) { if (e.props[k].is_list) fixed = false; off[k] = stride; stride += (size_t) type_size(e.props[k].type); }
+      if (fixed && stride > 0) {
+        if (rd.pos + stride * (size_t) e.count > rd.body.size()) { rd.ok = false; break; }
+        if (is_vertex) {
+          const char *base = rd.body.data() + rd.pos;
+          run([&](long i0, long i1) {
+            for (long i = i0; i < i1; i++) {
+              const char *r = base + stride * (size_t) i;
+              if (ix >= 0) P[3 * i] = num(r + off[ix], e.props[ix].type);
+              if (iy >= 0) P[3 * i + 1] = num(r + off[iy], e.props[iy].type);
+              if (iz >= 0) P[3 * i + 2] = num(r + off[iz], e.props[iz].type);
+              if (iu >= 0) uv[2 * i] = (float) num(r + off[iu], e.props[iu].type);
+              if (iv >= 0) uv[2 * i + 1] = (float) num(r + off[iv], e.props[iv].type);
+            }
+          });
+        }
+        rd.pos += stride * (size_t) e.count;
+        continue;
+      }
+      if (is_face && e.props.size() == 1 && ilist == 0) {
+        const PlyProp &p = e.props[0];
+        const size_t cs = (size_t) type_size(p.count_type), vs = (size_t) type_size(p.type);
+        if (rd.pos + cs <= rd.body.size()) {
+          const int n = (int) num(rd.body.data() + rd.pos, p.count_type);
+          const size_t rec = cs + vs * (size_t) (n > 0 ? n : 0);
+          if (n >= 3 && n <= 255 && rd.pos + rec * (size_t) e.count <= rd.body.size()) {
+            const char *base = rd.body.data() + rd.pos;
+            std::vector<char> same(nt, 1);
+            if (nt == 1) { for (long i = 0; i < e.count; i++) if ((int) num(base + rec * (size_t) i, p.count_type) != n) { same[0] = 0; break; } }
+            else {
+              std::vector<std::thread> th;
+              for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
+                for (long i = e.count * t / nt; i < e.count * (t + 1) / nt; i++) if ((int) num(base + rec * (size_t) i, p.count_type) != n) { same[t] = 0; break; }
+              });
+              for (auto &x : th) x.join();
+            }
+            bool all_same = true;
+            for (char c : same) all_same = all_same && c;
+            if (all_same) {
+              const size_t tri0 = indices.size();
+              indices.resize(tri0 + (size_t) e.count * 3 * (size_t) (n - 2));
+              run([&](long i0, long i1) {
+                for (long i = i0; i < i1; i++) {
+                  const char *r = base + rec * (size_t) i + cs;
+                  const int32_t a0 = (int32_t) num(r, p.type);
+                  int32_t *out = &indices[tri0 + (size_t) i * 3 * (size_t) (n - 2)];
+                  for (int j = 0; j < n - 2; j++) {     // n triangles in a polygon is (n vertices - 2)
+                    out[3 * j] = a0;
+                    out[3 * j + 1] = (int32_t) num(r + vs * (size_t) (j + 1), p.type);
+                    out[3 * j + 2] = (int32_t) num(r + vs * (size_t) (j + 2), p.type);
+                  }
+                }
+              });
+              rd.pos += rec * (size_t) e.count;
+              continue;
+            }
+          }
+        }
+      }
     }
     for (long i = 0; i < e.count && rd.ok; i++) {
       for (size_t k = 0; k < e.props.size(); k++) {
@@ -192,6 +298,7 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
   for (int32_t i : indices)
     if (i < 0 || i >= nverts) { *err = "PLY face index out of range: " + path; return -1; }
 
+  const auto tA_ = std::chrono::steady_clock::now();
   mesh->P.swap(P);
   mesh->indices.swap(indices);
   mesh->uv.swap(uv);
@@ -199,7 +306,11 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
   mesh->velocity.clear();
   mesh->face_group.clear();
   mesh->ComputeNormals();
+  const auto tB_ = std::chrono::steady_clock::now();
   mesh->ComputeBounds();
+  if (getenv("FJ_SCENE_TIMING"))
+    fprintf(stderr, "fjhost: ply %s: read %.3f s, normals %.3f s, bounds %.3f s\n", path.c_str(), std::chrono::duration<double>(tA_ - t0_).count(),
+        std::chrono::duration<double>(tB_ - tA_).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tB_).count());
   return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace fjhost {
 
@@ -82,40 +83,73 @@ void Mesh::ComputeNormals()
 {
   if (P.empty() || indices.empty()) return;
   N.assign(P.size(), 0.);
-  const int nf = face_count();
-  for (int f = 0; f < nf; f++) {
-    const int32_t *ix = &indices[3 * f];
-    double a[3], b[3], ng[3];
-    sub3(&P[3 * ix[1]], &P[3 * ix[0]], a);
-    sub3(&P[3 * ix[2]], &P[3 * ix[0]], b);
-    ng[0] = a[1] * b[2] - a[2] * b[1];
-    ng[1] = a[2] * b[0] - a[0] * b[2];
-    ng[2] = a[0] * b[1] - a[1] * b[0];
-    normalize3(ng);
-    // the three point normals are read first and then written back as N_k + Ng
-    // (a face that repeats an index therefore adds Ng to it once, like the reference)
-    double cur[3][3];
-    for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) cur[k][c] = N[3 * ix[k] + c];
-    for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) N[3 * ix[k] + c] = cur[k][c] + ng[c];
+  const int nf = face_count(), np = point_count();
+  // The reference adds every face's unit normal to its three point normals in FACE ORDER (one thread), and the last bits of a sum depend
+  // on that order.  Here every host thread owns a range of the POINTS and walks all faces for it: a point's normal still receives its faces'
+  // normals in face order -- the same additions, the same bits --, a face normal is computed by the (at most three) threads that own one of
+  // its points.  (7.2 M triangles: 0.3 s of a 0.6 s scene assembly on one thread.)
+  const unsigned hc = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned nt = (unsigned) std::max(1, std::min<int>((int) hc, np / 4096 + 1));
+  auto work = [&](unsigned t) {
+    const int v0 = (int) ((long long) np * t / nt), v1 = (int) ((long long) np * (t + 1) / nt);
+    for (int f = 0; f < nf; f++) {
+      const int32_t *ix = &indices[3 * (size_t) f];
+      const bool m0 = ix[0] >= v0 && ix[0] < v1, m1 = ix[1] >= v0 && ix[1] < v1, m2 = ix[2] >= v0 && ix[2] < v1;
+      if (!(m0 || m1 || m2)) continue;
+      double a[3], b[3], ng[3];
+      sub3(&P[3 * (size_t) ix[1]], &P[3 * (size_t) ix[0]], a);
+      sub3(&P[3 * (size_t) ix[2]], &P[3 * (size_t) ix[0]], b);
+      ng[0] = a[1] * b[2] - a[2] * b[1];
+      ng[1] = a[2] * b[0] - a[0] * b[2];
+      ng[2] = a[0] * b[1] - a[1] * b[0];
+      normalize3(ng);
+      // the three point normals are read first and then written back as N_k + Ng
+      // (a face that repeats an index therefore adds Ng to it once, like the reference)
+      if (m0) for (int c = 0; c < 3; c++) N[3 * (size_t) ix[0] + c] += ng[c];
+      if (m1 && ix[1] != ix[0]) for (int c = 0; c < 3; c++) N[3 * (size_t) ix[1] + c] += ng[c];
+      if (m2 && ix[2] != ix[0] && ix[2] != ix[1]) for (int c = 0; c < 3; c++) N[3 * (size_t) ix[2] + c] += ng[c];
+    }
+    for (int i = v0; i < v1; i++) normalize3(&N[3 * (size_t) i]);
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
   }
-  for (int i = 0; i < point_count(); i++) normalize3(&N[3 * i]);
 }
 
 // Mesh::ComputeBounds, reference src/fj_mesh.cc:235-244 (union of triangle bounds)
 void Mesh::ComputeBounds()
 {
   const double big = 1.7976931348623157e308;
-  double mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
   const int nf = face_count();
-  for (int f = 0; f < nf; f++)
-    for (int k = 0; k < 3; k++) {
-      const int p = indices[3 * f + k];
-      for (int c = 0; c < 3; c++) {
-        double pos[2] = {P[3 * p + c], P[3 * p + c]};
-        if (!velocity.empty()) pos[1] = P[3 * p + c] + velocity[3 * p + c];
-        for (double q : pos) { if (q < mn[c]) mn[c] = q; if (q > mx[c]) mx[c] = q; }
+  const unsigned hc = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned nt = (unsigned) std::max(1, std::min<int>((int) hc, nf / 65536 + 1));
+  std::vector<double> part((size_t) nt * 6);
+  auto work = [&](unsigned t) {
+    double mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+    const int f0 = (int) ((long long) nf * t / nt), f1 = (int) ((long long) nf * (t + 1) / nt);
+    for (int f = f0; f < f1; f++)
+      for (int k = 0; k < 3; k++) {
+        const size_t p = (size_t) indices[3 * (size_t) f + k];
+        for (int c = 0; c < 3; c++) {
+          double pos[2] = {P[3 * p + c], P[3 * p + c]};
+          if (!velocity.empty()) pos[1] = P[3 * p + c] + velocity[3 * p + c];
+          for (double q : pos) { if (q < mn[c]) mn[c] = q; if (q > mx[c]) mx[c] = q; }
+        }
       }
-    }
+    for (int c = 0; c < 3; c++) { part[6 * (size_t) t + c] = mn[c]; part[6 * (size_t) t + 3 + c] = mx[c]; }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+  }
+  double mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+  for (unsigned t = 0; t < nt; t++)
+    for (int c = 0; c < 3; c++) { mn[c] = std::min(mn[c], part[6 * (size_t) t + c]); mx[c] = std::max(mx[c], part[6 * (size_t) t + 3 + c]); }
   for (int c = 0; c < 3; c++) { bounds[c] = mn[c]; bounds[3 + c] = mx[c]; }
 }
 
