@@ -133,6 +133,7 @@ struct fjgpu_scene {
   // options
   long batch_tiles;
   long batch_samples = 0;          // option "batch_samples": samples per batch where batch_tiles is 0 (0: as many as the memory budget holds)
+  long render_calls = 0;           // fjgpu_render_tiles calls that rendered something (the first one sizes its batches for a cold start)
   long count_events;
   long count_all_shadow;
   // work buffers (lazily sized)
@@ -379,6 +380,10 @@ static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance le
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
 static long g_device_build = -1;   // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree; 0 = on the host; -1 = not set
 static long g_multi_exchange = 0;  // "multi_exchange": how fjgpu_render_frame_multi moves the devices' tile slabs: 0 one hipMemcpyPeer each, 1 RCCL grouped send / recv
+static long g_cold_start = 1;      // "cold_start": a scene's first render call uses batches of FJ_COLD_BATCH_SAMPLES samples (a small arena: a fast first frame)
+#ifndef FJ_COLD_BATCH_SAMPLES
+#define FJ_COLD_BATCH_SAMPLES ((size_t) 16 << 20)
+#endif
 static long g_single_frame = 0;    // "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU
 
 extern "C" {
@@ -398,6 +403,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
+  if (std::string(name) == "cold_start") { g_cold_start = value != 0; return 0; }
   if (std::string(name) == "multi_exchange") { if (value < 0 || value > 1) return fail(FJGPU_EINVAL, "multi_exchange: 0 peer copies, 1 RCCL send / recv"); g_multi_exchange = value; return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -1076,7 +1082,9 @@ int ensure_work(fjgpu_scene *sc, size_t samples, size_t rays, int tiles, size_t 
     // with region / rank-share renders would free and reallocate tens of GB on every call
     samples = std::max(samples, sc->work_samples); rays = std::max(rays, sc->work_rays); tiles = std::max(tiles, sc->tiles_cap);
     const int old_bufs = sc->lrec_bufs;
-    sc->lrec_bufs = std::max(sc->lrec_bufs, want_bufs);
+    // (the extra light-record buffers of the overlap mode belong to SMALL batches: an arena that grows to a larger batch -- the second call after
+    // a cold start -- takes what that batch wants, 2 x 80 B per ray, not the 4 the small one had: 21 GB at the headline size)
+    sc->lrec_bufs = samples > sc->work_samples ? want_bufs : std::max(sc->lrec_bufs, want_bufs);
     sc->work.reset(new DeviceBuffers());
     // the adaptive sampler's buffers lived in the old arena (a new arena may be allocated at the
     // old one's address, so the owner pointer alone does not tell)
@@ -1192,6 +1200,7 @@ int fjgpu_render_tiles(fjgpu_scene *sc, const fj_render_desc *r, const int32_t *
     sc->split_shadow = false;
     e = render_tiles_once(sc, r, tile_ids, n_tiles, d_fb, hip_stream, stats);
   }
+  if (!e) sc->render_calls++;
   return e;
 }
 
@@ -1251,6 +1260,14 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // (a caller that renders ONE frame per scene -- SiRenderScene -- asks for batches of a few M samples: the work arena is then a few GB
   // instead of ~110 GB at the headline size, and a cold frame does not wait for the driver to hand out, and clear, that much memory)
   if (bt <= 0 && sc->batch_samples > 0) bt = std::max<long>(1, (long) ((size_t) sc->batch_samples / full_tile_samples));
+  // COLD START: a scene's FIRST call renders in batches of FJ_COLD_BATCH_SAMPLES samples whatever the memory would hold -- a work arena of ~14 GB
+  // instead of ~110 GB at the headline size: the first image is there after 0.15 s instead of the 2-5 s hipMalloc takes to hand out (and, after a process
+  // that has just ended, clear) the large arena (profiles/r05_e2e_scene.txt).  The second call sizes its batches by memory as before and pays for the
+  // growth once; a caller that renders one frame per scene never does.  ("cold_start" 0 / FJGPU_COLD_START=0: the first call already sizes by memory.)
+  if (bt <= 0 && sc->render_calls == 0 && g_cold_start && !adaptive) {
+    static const int on = [] { const char *e = getenv("FJGPU_COLD_START"); return e ? atoi(e) : 1; }();
+    if (on) bt = std::max<long>(1, (long) ((size_t) FJ_COLD_BATCH_SAMPLES / full_tile_samples));
+  }
   if (bt <= 0) {
     const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
         ((sc->ray_sort_bits > 0 && deepest >= 1) ? 24 : 0);       // (the ray sort's keys, slots, permutation and scratch)

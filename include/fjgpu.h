@@ -159,6 +159,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * device (over xGMI where peer access exists; nothing to bring up, which is what a one-frame process wants); 1: RCCL, every device's thread
  * sends its slab with ncclSend, the first device posts all ncclRecv in one ncclGroupStart / ncclGroupEnd (librccl.so is loaded at first use;
  * devices must be distinct; a communicator that cannot be created falls back to the peer copies).  Same bytes over the same links.
+ * "cold_start" 1/0 (default 1): a scene's FIRST fjgpu_render_tiles call renders in batches of 16 M samples whatever the memory would hold (a work
+ * arena of ~14 GB instead of ~110 GB at 1080p / 64 spp: the first image after 0.15 s instead of the seconds the large allocation can take);
+ * the second call sizes its batches by memory and pays for the growth once.  0: the first call already does.
  * "single_frame_build" 0/1: the caller renders ONE frame per scene it creates (SiRenderScene switches it on around its
  * scene creation): the 0.4 s of host build the tree's 3-6 % faster frames would need many frames to earn back are not spent.
  * "device_tlas" 1/0 (default 1): the instance level of every group (the reference's BVHAccelerator over
