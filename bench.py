@@ -258,7 +258,7 @@ def pmc_passes(args, kname):
         child += ["--spp"] + [str(v) for v in args.spp]
     if args.device_build:
         child += ["--device-build", str(args.device_build)]
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", FJGPU_COLD_START="0")       # (ONE production frame in the child: its sums are per frame)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)                   # (a parent started through the launcher: the counter child is a plain one-GPU run)
     try:
@@ -516,10 +516,12 @@ def main():
             first["device_ms"] = st.total_ms if st is not None else None
             # the core's first call renders in cold-start batches (a small work arena); the SECOND call grows the arena to its steady-state
             # size -- one untimed frame here, so that neither the warm-up count nor the timed steps see the allocation
-            _t = time.perf_counter()
-            st = step_()
-            torch.cuda.synchronize(device)
-            first["second_ms"] = (time.perf_counter() - _t) * 1e3
+            # (FJGPU_COLD_START=0, the counter children: one call, one whole-frame arena, as before the policy)
+            if os.environ.get("FJGPU_COLD_START", "1") != "0":
+                _t = time.perf_counter()
+                st = step_()
+                torch.cuda.synchronize(device)
+                first["second_ms"] = (time.perf_counter() - _t) * 1e3
         return st
 
     def step_():
@@ -665,6 +667,7 @@ def main():
                    "frac_of_peak_bounds": [(read_low + pmc["WRITE_SIZE"] * 1024.0) / launches_per_frame / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                            min(1.0, (read_high + pmc["WRITE_SIZE"] * 1024.0) / launches_per_frame / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)],
                    "read_requests_per_frame": {"all": rd, "32B": rd32},
+                   "launches_in_the_counter_child": pmc.get("_launches"), "launches_per_frame_here": launches_per_frame,
                    "FETCH_SIZE_KB_per_frame_as_rocprofv3_reports_it": rd * 64.0 / 1024.0, "WRITE_SIZE_KB_per_frame": pmc["WRITE_SIZE"],
                    "calibration": cal,
                    "traffic_over_algorithmic": traffic / (walk_alg / walk_nl) if walk_alg else None,
