@@ -582,6 +582,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
         I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
         I.pqnodes = P.qnodes ? P.qnodes : cq[I.primset];
+        I.sh_indices = P.indices; I.sh_N = P.N; I.sh_uv = P.uv; I.sh_face_group = P.face_group; I.sh_type = P.type; I.sh_pad = 0;
         for (int k = 0; k < 3; k++) { I.qorigin[k] = qgrid[I.primset][k]; I.qcell[k] = qgrid[I.primset][3 + k]; }
       }
       e |= M.upload(di.data(), di.size(), &S.instances);

@@ -130,7 +130,7 @@ __device__ void tex_lookup(const DTexture &tex, float u, float v, float out[4])
   const int xp = (int) ((su - floorf(su)) * 64);
   const int yp = (int) ((sv - floorf(sv)) * 64);
   if (xp < 0 || xp >= ts || yp < 0 || yp >= ts) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
-  const float *p = tex.tiles + ((size_t) (yt * xnt + xt) * ts * ts + (size_t) (yp * ts + xp)) * tex.nchannels;
+  const FJ_GLOBAL float *p = FJ_G(float, tex.tiles) + ((size_t) (yt * xnt + xt) * ts * ts + (size_t) (yp * ts + xp)) * tex.nchannels;
   switch (tex.nchannels) {
   case 1: out[0] = out[1] = out[2] = p[0]; out[3] = 1.f; break;
   case 3: out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = 1.f; break;
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
     float t0u = 0, t0v = 0, t1u = 0, t1v = 0, t2u = 0, t2v = 0;
     int i0 = 0, i1 = 0, i2 = 0;
     int sg = 0;
-    if (P->type == FJ_PRIMSET_CURVE) {
+    if (I->sh_type == FJ_PRIMSET_CURVE) {
       // --- Curve::ray_intersect attribute part (src/fj_curve.cc:211-229): dPdv = curve
       // derivative at v_hit, Cd = lerp of the end colours; N / uv / dPdu stay zero
       const size_t sl = (size_t) h.v;
@@ -450,21 +450,21 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       Cd[2] = (1 - tl) * cd[2] + tl * cd[5];
     } else {
       // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
-      const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, P->indices) + 3 * (size_t) h.prim;
+      const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, I->sh_indices) + 3 * (size_t) h.prim;
       i0 = ix[0]; i1 = ix[1]; i2 = ix[2];
       V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
-      if (P->N) { n0 = ld3(FJ_G(double, P->N) + 3 * (size_t) i0); n1 = ld3(FJ_G(double, P->N) + 3 * (size_t) i1); n2 = ld3(FJ_G(double, P->N) + 3 * (size_t) i2); }
+      if (I->sh_N) { n0 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i0); n1 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i1); n2 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i2); }
       N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;            // TriComputeNormal, src/fj_triangle.cc:44-49
-      has_uv = P->uv != nullptr;
+      has_uv = I->sh_uv != nullptr;
       if (has_uv) {
-        t0u = FJ_G(float, P->uv)[2 * (size_t) i0]; t0v = FJ_G(float, P->uv)[2 * (size_t) i0 + 1];
-        t1u = FJ_G(float, P->uv)[2 * (size_t) i1]; t1v = FJ_G(float, P->uv)[2 * (size_t) i1 + 1];
-        t2u = FJ_G(float, P->uv)[2 * (size_t) i2]; t2v = FJ_G(float, P->uv)[2 * (size_t) i2 + 1];
+        t0u = FJ_G(float, I->sh_uv)[2 * (size_t) i0]; t0v = FJ_G(float, I->sh_uv)[2 * (size_t) i0 + 1];
+        t1u = FJ_G(float, I->sh_uv)[2 * (size_t) i1]; t1v = FJ_G(float, I->sh_uv)[2 * (size_t) i1 + 1];
+        t2u = FJ_G(float, I->sh_uv)[2 * (size_t) i2]; t2v = FJ_G(float, I->sh_uv)[2 * (size_t) i2 + 1];
         const float tt = (float) (1 - h.u - h.v);                  // f32 barycentric, src/fj_mesh.cc:285
         tu = (float) (tt * t0u + h.u * t1u + h.v * t2u);
         tv = (float) (tt * t0v + h.u * t1v + h.v * t2v);
       }
-      sg = P->face_group ? FJ_G(int32_t, P->face_group)[h.prim] : 0;
+      sg = I->sh_face_group ? FJ_G(int32_t, I->sh_face_group)[h.prim] : 0;
     }
     Pw = oo + h.t * od;                                        // RayPointAt in object space
     // --- ObjectInstance::RayIntersect back-transform (src/fj_object_instance.cc:231-240)

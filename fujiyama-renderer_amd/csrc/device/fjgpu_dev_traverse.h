@@ -145,9 +145,13 @@ struct RayIn { V3 o, d; double tmin, tmax, time; int group; bool anyhit; };
 // Per-lane traversal stack: the first FJ_STACK_LDS entries in LDS ([depth][thread], lane
 // consecutive, conflict free), deeper ones -- the builder reports the worst case of the
 // scene's trees -- in a global overflow area ([depth][global thread]).
+// (lds / ovf carry their address spaces: through generic pointers the pop `sp < lds_n ? lds[..] : ovf[..]` became a choice between two
+// addresses and ONE FLAT load -- issued down the vector-memory path even when it reads LDS, and waited for with both counters -- on the
+// critical path of every step that ends without a child)
+typedef __attribute__((address_space(3))) uint32_t trav_lds_u32;
 struct TravStack {
-  uint32_t *lds;        // s_stack + threadIdx.x
-  uint32_t *ovf;        // overflow base + global thread id (null when no tree needs it)
+  trav_lds_u32 *lds;    // s_stack + threadIdx.x
+  FJ_GLOBAL uint32_t *ovf;   // overflow base + global thread id (null when no tree needs it)
   uint32_t ovf_stride;  // threads in the grid
   double *rayspace;     // curve scenes: s_rayspace + threadIdx.x (RaySpace), else null
   int lds_n;            // entries kept in LDS (FJ_STACK_LDS, or FJ_STACK_LDS_CURVES)
@@ -160,17 +164,20 @@ struct TravStack {
   __device__ __forceinline__ uint32_t pop(int &sp) const
   {
     --sp;
-    return sp < lds_n ? lds[sp * BLOCK] : ovf[(size_t) (sp - lds_n) * ovf_stride];
+    uint32_t v;
+    if (sp < lds_n) v = lds[sp * BLOCK];
+    else v = ovf[(size_t) (sp - lds_n) * ovf_stride];
+    return v;
   }
 };
 __device__ __forceinline__ TravStack make_stack(uint32_t *s_stack, uint32_t *ovf, double *s_rayspace = nullptr, int lds_entries = 0)
 {
   TravStack st;
-  st.lds = s_stack + threadIdx.x;
+  st.lds = (trav_lds_u32 *) (s_stack + threadIdx.x);
   st.lds_n = lds_entries ? lds_entries : (s_rayspace ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS);
   st.rayspace = s_rayspace ? s_rayspace + threadIdx.x : nullptr;
   st.ovf_stride = gridDim.x * BLOCK;
-  st.ovf = ovf ? ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x : nullptr;
+  st.ovf = ovf ? (FJ_GLOBAL uint32_t *) (ovf + (size_t) blockIdx.x * BLOCK + threadIdx.x) : nullptr;
   return st;
 }
 

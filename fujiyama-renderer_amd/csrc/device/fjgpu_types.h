@@ -117,6 +117,15 @@ struct DInstance {
   const DNode *pnodes;
   const DNodeQ *pqnodes;       // meshes: the quantised twin of the node array and its grid (plane = qorigin + q * qcell):
   double qorigin[3], qcell[3]; // the closest-hit walk of scenes without curve sets reads these 64-byte nodes too
+  // ... and of what the SHADING kernel reads of a mesh (DPrimSet indices / N / uv / face_group and the type): a hit's attribute fetch is
+  // hit -> instance -> indices -> normals instead of hit -> instance -> primitive set -> indices -> normals, one dependent gather less in a
+  // kernel that waits for nothing else (k_shade)
+  const int32_t *sh_indices;
+  const double *sh_N;
+  const float *sh_uv;
+  const int32_t *sh_face_group;
+  int32_t sh_type;             // FJ_PRIMSET_*
+  int32_t sh_pad;
 };
 
 // What the closest-hit walks and the general shadow walk read when a ray enters an instance, packed.  A scene whose whole
