@@ -20,6 +20,9 @@ SETS = (("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"), ("WRITE_SIZE",),
 
 
 def main():
+    global SETS
+    if os.environ.get("KPMC_SETS"):          # e.g. KPMC_SETS="SQ_INSTS_SALU SQ_INSTS_SMEM,SQ_INSTS_VMEM_RD SQ_INSTS_LDS": extra passes, printed raw
+        SETS = SETS + tuple(tuple(x.split()) for x in os.environ["KPMC_SETS"].split(","))
     workload, names = sys.argv[1], sys.argv[2:]
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     tmp = tempfile.mkdtemp(prefix="kpmc_", dir="/tmp")
@@ -60,6 +63,10 @@ def main():
             lane = a["SQ_THREAD_CYCLES_VALU"] / (64.0 * a["SQ_ACTIVE_INST_VALU"])
             line += "  | VALU instr %.3g, lanes %.2f, waiting on memory %.2f of wave cycles" % (a.get("SQ_INSTS_VALU", 0.0), lane, a.get("SQ_WAIT_ANY", 0.0) / a["SQ_WAVE_CYCLES"])
         print(line, flush=True)
+        extra = {k: v for k, v in a.items() if not k.startswith("_") and k not in sum((list(x) for x in SETS[:3]), [])}
+        if extra:
+            print("    " + "  ".join("%s %.4g" % kv for kv in sorted(extra.items())) + "  | SQ_WAVES %.4g SQ_WAVE_CYCLES %.4g SQ_BUSY_CYCLES %.4g SQ_ACTIVE_INST_VALU %.4g" %
+                  (a.get("SQ_WAVES", 0), a.get("SQ_WAVE_CYCLES", 0), a.get("SQ_BUSY_CYCLES", 0), a.get("SQ_ACTIVE_INST_VALU", 0)), flush=True)
 
 
 if __name__ == "__main__":
