@@ -384,6 +384,7 @@ static long g_cold_start = 1;      // "cold_start": a scene's first render call 
 #ifndef FJ_COLD_BATCH_SAMPLES
 #define FJ_COLD_BATCH_SAMPLES ((size_t) 16 << 20)
 #endif
+static long g_cold_batch_samples = (long) FJ_COLD_BATCH_SAMPLES;      // "cold_batch_samples": ... of this many samples (0 = the default, 16 M)
 static long g_single_frame = 0;    // "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU
 
 extern "C" {
@@ -404,6 +405,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
   if (std::string(name) == "cold_start") { g_cold_start = value != 0; return 0; }
+  if (std::string(name) == "cold_batch_samples") { g_cold_batch_samples = value > 0 ? value : (long) FJ_COLD_BATCH_SAMPLES; return 0; }
   if (std::string(name) == "multi_exchange") { if (value < 0 || value > 1) return fail(FJGPU_EINVAL, "multi_exchange: 0 peer copies, 1 RCCL send / recv"); g_multi_exchange = value; return 0; }
   return fail(FJGPU_EINVAL, std::string("unknown global option ") + name);
 }
@@ -1267,7 +1269,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // growth once; a caller that renders one frame per scene never does.  ("cold_start" 0 / FJGPU_COLD_START=0: the first call already sizes by memory.)
   if (bt <= 0 && sc->render_calls == 0 && g_cold_start && !adaptive) {
     static const int on = [] { const char *e = getenv("FJGPU_COLD_START"); return e ? atoi(e) : 1; }();
-    if (on) bt = std::max<long>(1, (long) ((size_t) FJ_COLD_BATCH_SAMPLES / full_tile_samples));
+    if (on) bt = std::max<long>(1, (long) ((size_t) g_cold_batch_samples / full_tile_samples));
   }
   if (bt <= 0) {
     const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +

@@ -339,6 +339,42 @@ def test_tile_subsets_and_batching_are_consistent(asset_dir):
     gs.close()
 
 
+def test_cold_start_renders_the_same_frame_from_a_small_arena(asset_dir):
+    """global option "cold_start" (default on): a scene's FIRST render call works in batches of "cold_batch_samples" samples -- a small work
+    arena, the first image without waiting for the whole-frame allocation -- and the second call sizes its batches by memory; the pixels and
+    the ray counts are those of a scene that never batched"""
+    sp, rd = prepare(workloads.dragon(asset_dir, res=(160, 90), spp=(2, 2), mesh="small"))
+    per_tile = (2 * rd.tile_w + 2 * 2) * (2 * rd.tile_h + 2 * 2)          # (upper bound of a tile's samples: rate 2, filter margin <= 2)
+    gpu.global_option("cold_start", 0)
+    try:
+        ref_scene = gpu.Scene(sp)
+        ref, st_ref = ref_scene.render_frame(rd)
+        assert st_ref.batches == 1
+        whole_arena = ref_scene.query("work_bytes")
+        ref_scene.close()
+        gpu.global_option("cold_start", 1)
+        gpu.global_option("cold_batch_samples", 4 * per_tile)
+        gs = gpu.Scene(sp)
+        first, st1 = gs.render_frame(rd)
+        small_arena = gs.query("work_bytes")
+        second, st2 = gs.render_frame(rd)
+        assert 4 <= st1.batches <= 8 and st2.batches == 1
+        assert st1.rays.as_dict() == st_ref.rays.as_dict() == st2.rays.as_dict()
+        assert float(rel_err(first, ref).max()) <= 1e-6 and float(rel_err(second, ref).max()) <= 1e-6
+        # (the arena only grows; at this size its floors decide, so equality is allowed: profiles/r05_arena_sizes.txt has the 14 -> 110 GB of C3)
+        assert small_arena <= gs.query("work_bytes") and gs.query("work_bytes") >= whole_arena
+        # an explicit batch size is the caller's business: the policy stays out of it
+        g2 = gpu.Scene(sp)
+        g2.set_option("batch_tiles", 15)
+        _, st3 = g2.render_frame(rd)
+        assert st3.batches == 1
+        g2.close()
+        gs.close()
+    finally:
+        gpu.global_option("cold_start", 1)
+        gpu.global_option("cold_batch_samples", 0)
+
+
 from edge_scenes import EDGE_CASES, custom_scene as _custom_scene  # noqa: E402
 
 
