@@ -68,6 +68,11 @@ __device__ __forceinline__ DLightSample ld_light_sample_k(const DLightSample *p)
 #ifndef FJ_CULL_MINB
 #define FJ_CULL_MINB 1
 #endif
+#ifndef FJ_CULL_CLAIMS_PER_WAVE
+#define FJ_CULL_CLAIMS_PER_WAVE 16u  // the light loop's record claims: a launch's records over (waves x this), in [64, 1024].  (4 until round 5: the waves of a launch
+                                     // lived 69-87 % of it, scripts/kernel_pmc.py; 4 / 8 / 16 / 32: C3 113.9 / 113.5 / 113.8 / 117.4 ms, C2 98.0 -> 92.4 at 16, a rank's
+                                     // share of C3 18.8 -> 18.5, C6 unchanged)
+#endif
 #ifndef FJ_CULL_MINB_PLAIN
 #define FJ_CULL_MINB_PLAIN 3      // point lights, no hair, rays split per candidate instance: 164 VGPRs as written (capped to 128 it spills 21-24)
 #endif
@@ -98,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK, (kHair || kArea) ? FJ_CULL_MINB : (kSpl
   // the kernel waiting for the waves whose records face the lights, and assumed that every
   // block of the grid is resident
   const uint32_t n_waves = (gridDim.x * BLOCK) >> 6;
-  uint32_t claim = (n / (n_waves * 4u)) & ~63u;
+  uint32_t claim = (n / (n_waves * FJ_CULL_CLAIMS_PER_WAVE)) & ~63u;
   claim = claim < 64u ? 64u : (claim > 1024u ? 1024u : claim);
   // queue space is reserved SQ_CHUNK slots at a time: one atomic per 512 rays
   // instead of one per wave iteration (a single-address atomic per iteration

@@ -40,6 +40,25 @@ def main():
                     if n in r["Kernel_Name"]:
                         a = acc[n]
                         a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        if k == 2 and os.environ.get("KPMC_PER_LAUNCH"):
+            # per launch: how long its waves live on average against how long the launch takes (what is left is its tail)
+            per, dur = {}, {}
+            for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+                for r in csv.DictReader(open(f)):
+                    if any(n in r["Kernel_Name"] for n in names):
+                        per.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+            for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
+                for r in csv.DictReader(open(f)):
+                    if r["Dispatch_Id"] in per:
+                        dur[r["Dispatch_Id"]] = (float(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            ghz = float(os.environ.get("KPMC_GHZ", "2.37"))
+            for did in sorted(dur, key=lambda x: dur[x][0]):
+                p = per[did]
+                if p.get("SQ_WAVES"):
+                    life = p["SQ_WAVE_CYCLES"] / p["SQ_WAVES"] * 4.0 / (ghz * 1e9)
+                    print("  launch %-44s %9.3f ms  %7d waves, average wave alive %5.1f %% of it  VALU instr %.3g lanes %.2f" %
+                          (p["name"].split("(")[0][-44:], dur[did][1] * 1e-6, int(p["SQ_WAVES"]), 100. * life / (dur[did][1] * 1e-9), p.get("SQ_INSTS_VALU", 0),
+                           p.get("SQ_THREAD_CYCLES_VALU", 0) / (64. * p["SQ_ACTIVE_INST_VALU"]) if p.get("SQ_ACTIVE_INST_VALU") else 0), flush=True)
         if k == 0:
             for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
                 for r in csv.DictReader(open(f)):
