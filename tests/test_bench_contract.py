@@ -37,7 +37,9 @@ def test_bench_line_has_the_contract_fields():
         assert r["uncalibrated"] is False, "the rocprofv3 counter passes did not run: " + r["frac_source"]
         assert r["hbm_counters"]["read_bytes_per_frame"] > 0 and r["valu_issue"]["valu_busy"] <= 1.0 + 1e-6
         assert r["binding_resource"] in ("hbm", "valu")
-        # the counter child renders ONE production frame (no cold-start frame beside it): its sums are per frame of this run
+        # the counter child renders ONE production frame (no cold-start frame beside it): its sums are per frame of this run.  (It may cut
+        # that frame into more batches than this process did -- the parent's arena is still allocated while it runs -- but on this small
+        # workload both render it in one.)
         assert r["hbm_counters"]["launches_in_the_counter_child"] == r["hbm_counters"]["launches_per_frame_here"], r["hbm_counters"]
         assert d["first_frame_ms"] > 0 and d["second_frame_ms"] > 0
     else:
