@@ -646,6 +646,9 @@ def main():
         cal = fetch_calibration()
         traffic, pmc, issue, hbm = None, None, None, None
         if world == 1 and not args.no_pmc and args.as_rank_of <= 1:
+            # the counter children render the same frame in processes of their own: this process's work arena (110 GB at the headline size)
+            # goes back to the driver first, so that a child finds the memory the timed frames found and cuts its frame into the same batches
+            gs.set_option("release_work", 1)
             pmc = pmc_passes(args, kname)
         launches_per_frame = walk_nl / nf if nf else 1.0
         avg_ms = walk_ms / walk_nl if walk_nl else None

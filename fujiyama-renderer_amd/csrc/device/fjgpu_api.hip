@@ -1053,6 +1053,20 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value)
     scene->overlap = value;
     return 0;
   }
+  if (n == "release_work") {
+    // the work arena back to the driver (the scene stays): a host that keeps its scene but renders nothing for a while -- or, like bench.py's
+    // counter passes, wants another process to find the memory this one found.  The next render call allocates again.
+    if (value && scene->work) {
+      if (hipSetDevice(scene->device) != hipSuccess) return fail(FJGPU_ENODEV, "hipSetDevice");
+      (void) hipDeviceSynchronize();
+      scene->work.reset();
+      scene->work_samples = scene->work_rays = 0; scene->tiles_cap = 0; scene->lrec_bufs = std::min(scene->lrec_bufs, 2); scene->squeue_rec_bytes = 0;
+      scene->sort_cap = 0; scene->a_owner = nullptr; scene->a_samples = 0; scene->a_cell_bytes = 0;
+      scene->d_aseen = scene->d_afinal = nullptr; scene->d_apstate = scene->d_acells = nullptr;
+      for (auto &L : scene->levels) { L.rays = nullptr; L.paths = nullptr; L.cap = 0; L.keys = nullptr; }
+    }
+    return 0;
+  }
   return fail(FJGPU_EINVAL, "unknown option " + n);
 }
 

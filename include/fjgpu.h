@@ -147,7 +147,8 @@ int fjgpu_trace(fjgpu_scene *scene, int group, int n, const double *rays,
  * (0, the default: as many as the memory budget holds -- fastest where frames repeat; a caller that renders one frame per scene
  * sets a few M: the work arena shrinks from ~110 GB to a few GB at the headline size and the cold frame starts sooner),
  * "count_nodes" 0/1 enable traversal event counters, "overlap_shadow" 0/1 run the shadow work of
- * a recursion level on its own stream, concurrent with the next level. Returns 0 or FJGPU_EINVAL. */
+ * a recursion level on its own stream, concurrent with the next level; "release_work" 1: hand the work arena back to the driver
+ * now (the scene stays resident; the next render call allocates again). Returns 0 or FJGPU_EINVAL. */
 int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
 
 /* Process-wide options read by fjgpu_scene_create (which stands for the reference's

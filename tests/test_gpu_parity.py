@@ -363,6 +363,11 @@ def test_cold_start_renders_the_same_frame_from_a_small_arena(asset_dir):
         assert float(rel_err(first, ref).max()) <= 1e-6 and float(rel_err(second, ref).max()) <= 1e-6
         # (the arena only grows; at this size its floors decide, so equality is allowed: profiles/r05_arena_sizes.txt has the 14 -> 110 GB of C3)
         assert small_arena <= gs.query("work_bytes") and gs.query("work_bytes") >= whole_arena
+        # option "release_work": the arena back to the driver, the scene stays; the next call allocates again and renders the same frame
+        gs.set_option("release_work", 1)
+        assert gs.query("work_bytes") == 0
+        third, st4 = gs.render_frame(rd)
+        assert gs.query("work_bytes") > 0 and st4.rays.as_dict() == st_ref.rays.as_dict() and float(rel_err(third, ref).max()) <= 1e-6
         # an explicit batch size is the caller's business: the policy stays out of it
         g2 = gpu.Scene(sp)
         g2.set_option("batch_tiles", 15)
