@@ -275,7 +275,7 @@ __device__ void traverse_persistent(const DScene &S, Policy &pol, TravTune tune,
     // ---- refill idle lanes from the wave's slice
     const unsigned long long idle = __ballot(!have);
     if (next >= range_end && head_live && (idle == ~0ull || (unsigned) __popcll(idle) >= TRAV_REFILL))
-      head_live = qc.claim(lane, &next, &range_end);
+      { head_live = qc.claim(lane, &next, &range_end); FJ_TL_CLAIM(); }
     if (idle == ~0ull || ((unsigned) __popcll(idle) >= TRAV_REFILL && next < range_end)) {
       if (!have) {
         const uint32_t my = next + (uint32_t) __popcll(idle & lt_mask);
