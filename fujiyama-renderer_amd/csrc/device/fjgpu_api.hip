@@ -162,6 +162,8 @@ struct fjgpu_scene {
   hipEvent_t ev_frame[2] = {nullptr, nullptr};   // frame start / end
   long early_shadow = 0;           // with it: level 0's shadow rays are walked as soon as its light loop has run (FJGPU_EARLY_SHADOW)
   hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
+  hipStream_t read_stream = nullptr;   // the counters of a shading launch come back on this one while the main stream already runs the next level's walk
+  hipEvent_t ev_shaded = nullptr;
   hipEvent_t ev_shadow_done[FJ_LREC_BUFS];    // shadow work reading d_lrecs[k] has finished
   std::vector<hipEvent_t> ev_pool; // per-launch timing events (resolved at the end of the frame: no host sync per launch)
   DShadowRay *d_squeue;
@@ -380,6 +382,7 @@ static long g_inst_lds = 1;        // "inst_lds": the walks keep the instance le
 static long g_batch_tiles = 0;     // "batch_tiles": default of the per-scene option of that name for scenes created from now on (0 = by memory)
 static long g_device_build = -1;   // "device_build": BLAS of meshes built on the GPU (fjgpu_lbvh.hip): 1 = clustering, 2 = radix tree; 0 = on the host; -1 = not set
 static long g_multi_exchange = 0;  // "multi_exchange": how fjgpu_render_frame_multi moves the devices' tile slabs: 0 one hipMemcpyPeer each, 1 RCCL grouped send / recv
+static long g_spec_walk = 1;       // "speculative_walk": the next recursion level's closest-hit walk is enqueued before the host has read how many rays it has (the walk reads the count itself)
 static long g_cold_start = 1;      // "cold_start": a scene's first render call uses batches of FJ_COLD_BATCH_SAMPLES samples (a small arena: a fast first frame)
 #ifndef FJ_COLD_BATCH_SAMPLES
 #define FJ_COLD_BATCH_SAMPLES ((size_t) 16 << 20)
@@ -404,6 +407,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "batch_tiles") { g_batch_tiles = value < 0 ? 0 : value; return 0; }
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
+  if (std::string(name) == "speculative_walk") { g_spec_walk = value != 0; return 0; }
   if (std::string(name) == "cold_start") { g_cold_start = value != 0; return 0; }
   if (std::string(name) == "cold_batch_samples") { g_cold_batch_samples = value > 0 ? value : (long) FJ_COLD_BATCH_SAMPLES; return 0; }
   if (std::string(name) == "multi_exchange") { if (value < 0 || value > 1) return fail(FJGPU_EINVAL, "multi_exchange: 0 peer copies, 1 RCCL send / recv"); g_multi_exchange = value; return 0; }
@@ -832,6 +836,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   S.incoherent_rays = (sc->max_children >= 2 || sc->bounce_diffuse) ? 1 : 0;
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
   S.ray_perm = nullptr;
+  S.trace_n_dev = nullptr;
   S.cam_uv = nullptr; S.cam_slot0 = 0; S.cam_tk = nullptr;
   S.shadow_join = nullptr;
   sc->split_shadow = S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base && g_split_shadow;
@@ -906,6 +911,8 @@ void fjgpu_scene_destroy(fjgpu_scene *scene)
   (void) hipDeviceSynchronize();
   if (getenv("FJGPU_PHASE_STATS")) debug_phase_stats();
   if (scene->shadow_stream) (void) hipStreamDestroy(scene->shadow_stream);
+  if (scene->read_stream) (void) hipStreamDestroy(scene->read_stream);
+  if (scene->ev_shaded) (void) hipEventDestroy(scene->ev_shaded);
   for (hipEvent_t e : scene->ev_shadow_done) if (e) (void) hipEventDestroy(e);
   for (hipEvent_t e : scene->ev_frame) if (e) (void) hipEventDestroy(e);
   for (hipEvent_t e : scene->ev_pool) (void) hipEventDestroy(e);
@@ -1304,6 +1311,10 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   // light loops beside the next levels' closest-hit walks (option overlap_shadow): on, or by the size of the batch
   sc->overlap_now = !adaptive && sc->n_light_samples > 0 && (sc->overlap == 1 || (sc->overlap == 2 && deepest >= 1 && full_tile_samples * (size_t) bt <= FJ_OVERLAP_MAX_SAMPLES));
   if (sc->overlap_now && enable_overlap(sc)) sc->overlap_now = false;
+  if (!sc->read_stream) {      // (the speculative walk's counter read-back; without them the loop reads on the main stream as before)
+    if (hipStreamCreateWithFlags(&sc->read_stream, hipStreamNonBlocking) != hipSuccess) sc->read_stream = nullptr;
+    else if (hipEventCreateWithFlags(&sc->ev_shaded, hipEventDisableTiming) != hipSuccess) { (void) hipStreamDestroy(sc->read_stream); sc->read_stream = nullptr; sc->ev_shaded = nullptr; }
+  }
   sc->squeue_max = std::max<size_t>((size_t) 4 << 20, std::min<size_t>((size_t) 512 << 20, (size_t) (.2 * (double) free_now) / sizeof(DShadowRay)));
   if (sc->n_light_samples == 0) sc->squeue_max = (size_t) 4 << 20;
   if (const char *e = getenv("FJGPU_SQUEUE_M")) sc->squeue_max = (size_t) std::max(1, atoi(e)) << 20;
@@ -1508,10 +1519,20 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
       sq_bound = 0; sq_dirty = false;
       return 0;
     };
+    // SPECULATIVE WALK (round 5): after the shading launch of a level the host needs two counters back -- how many children, how many light
+    // records -- before it can go on, and the device used to wait 40-145 us for that round trip at every level.  The children's closest-hit walk does
+    // not need the host to know: it is enqueued right behind the shading launch and reads its ray count from the counter itself (DScene.trace_n_dev,
+    // bounded by the chunk the host would have cut), while the counters come back on a stream of their own.  `walk_launched`: process() was called
+    // for rays whose first chunk is already being walked.
+    bool walk_launched = false;
+    static const bool spec_env = [] { const char *e = getenv("FJGPU_SPEC_WALK"); return e ? atoi(e) != 0 : true; }();
+    const bool speculate = g_spec_walk && spec_env && sc->ray_sort_bits <= 0 && sc->read_stream && sc->ev_shaded;
     std::function<int(int, uint32_t)> process = [&](int level, uint32_t count) -> int {
       // rays of the deepest reachable level cannot emit children (has_reached_bounce_limit):
       // there is no next queue
       const bool can_emit = level < deepest;
+      bool skip_walk = walk_launched;      // (the first chunk's walk)
+      walk_launched = false;
       if (can_emit && ensure_level(sc, level + 1, cap_rays)) return fail(FJGPU_ENOMEM, "device allocation failed for a ray queue level");
       const uint32_t kids = (uint32_t) std::max(1, sc->max_children);
       const uint32_t chunk_max = kids <= 1 ? count : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
@@ -1536,11 +1557,14 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
           St.ray_perm = sc->d_sort[3];
           acc.rays_sorted += n;
         }
-        e = timed(st, &acc.closest_ms, [&]() {
-          return launch_trace_closest(st, St, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
-        });
-        if (e) return e;
-        acc.trace_launches++; acc.closest_launches++;
+        if (!skip_walk) {
+          e = timed(st, &acc.closest_ms, [&]() {
+            return launch_trace_closest(st, St, rays, paths, sc->d_hits, n, sc->d_cnt, (int) sc->count_events);
+          });
+          if (e) return e;
+          acc.trace_launches++; acc.closest_launches++;
+        }
+        skip_walk = false;
         const unsigned lb = shade_seq++ % lrec_ring;   // light-record buffer of this shading call
         if (shadow_pending[lb] && sst != st) (void) hipStreamWaitEvent(st, sc->ev_shadow_done[lb], 0);
         shadow_pending[lb] = false;
@@ -1555,8 +1579,27 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         });
         if (e) return e;
         DCounters hc;
-        if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        bool launched_next = false;
+        // (with the light loops on their own stream the ORDER of the launches decides who is resident first: level 0's light loop -- the big one -- must
+        // reach the device before level 1's walk fills it, or the two take turns instead of overlapping: C2 93.8 -> 97.3 ms with the walk first; from
+        // level 1 on the light loops are small and the round trip is what costs)
+        if (speculate && can_emit && (sst == st || level >= 1)) {
+          // the children's walk behind the shading launch, the counters back on the side stream (which waits for the shading launch only)
+          if (hipEventRecord(sc->ev_shaded, st) != hipSuccess) return -1;
+          DScene Sn = S;
+          Sn.trace_n_dev = &sc->d_cnt->next_count;
+          const uint32_t next_chunk = kids <= 1 ? (uint32_t) std::min<size_t>(cap_rays, 0xffffffffu) : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
+          e = timed(st, &acc.closest_ms, [&]() {
+            return launch_trace_closest(st, Sn, sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_hits, next_chunk, sc->d_cnt, (int) sc->count_events);
+          });
+          if (e) return e;
+          launched_next = true;
+          if (hipStreamWaitEvent(sc->read_stream, sc->ev_shaded, 0) != hipSuccess ||
+              hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, sc->read_stream) != hipSuccess || hipStreamSynchronize(sc->read_stream) != hipSuccess) return -1;
+        }
+        else if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         if (hc.overflow) { sc->split_overflowed = S.shadow_join != nullptr; return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); }
+        if (launched_next && hc.next_count) { acc.trace_launches++; acc.closest_launches++; }       // (a walk of no rays is not counted)
         if (hc.light_count) {
           // shading has completed (the host just synchronised with it): no event needed.
           // The queue holds hc.shadow_count entries so far (exact when the shadow work runs on
@@ -1600,6 +1643,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         }
         if (hc.next_count) {
           if (!can_emit) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
+          walk_launched = launched_next;
           e = process(level + 1, hc.next_count);
           if (e) return e;
         }

@@ -206,6 +206,7 @@ template <bool kCount, bool kOne>
 __global__ void __launch_bounds__(BLOCK, FJ_FLAT_MINB) k_trace_closest_flat(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
+  if (S.trace_n_dev) { const uint32_t nd_ = *S.trace_n_dev; n = nd_ < n ? nd_ : n; }       // (a speculative launch: fjgpu_api.hip)
   __shared__ uint32_t s_stack[FJ_STACK_LDS_FLAT * BLOCK];
   __shared__ double s_inst[FJ_FLAT_LDS_INSTS * 12];
   // M^-1 of every instance (the launcher picked this kernel because the scene has at most FJ_FLAT_LDS_INSTS of them)

@@ -840,6 +840,7 @@ template <bool kCurves, bool kCount, bool kMotion, bool kInstLds = false>
 __global__ void __launch_bounds__(BLOCK, kMotion ? FJ_MOTION_MINB : (kCurves ? FJ_CURVE_MINB : FJ_CLOSEST_MINB)) k_trace_closest(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
+  if (S.trace_n_dev) { const uint32_t nd_ = *S.trace_n_dev; n = nd_ < n ? nd_ : n; }       // (a speculative launch: fjgpu_api.hip)
   __shared__ uint32_t s_stack[(kCurves ? FJ_STACK_LDS_CURVES : FJ_STACK_LDS) * BLOCK];
   __shared__ double s_rayspace[kCurves ? FJ_RAYSPACE_DOUBLES * BLOCK : 1];
   __shared__ double s_inst[kInstLds ? InstLdsOf<kCurves>::T::WORDS : 1];
@@ -866,6 +867,7 @@ template <bool kCount, bool kInstLds>
 __global__ void __launch_bounds__(BLOCK, FJ_PHASED_MINB) k_trace_closest_phased(DScene S, const DRay *rays, const DPath *paths,
     DHit *hits, uint32_t n, DCounters *cnt, TravTune tune)
 {
+  if (S.trace_n_dev) { const uint32_t nd_ = *S.trace_n_dev; n = nd_ < n ? nd_ : n; }
   __shared__ uint32_t s_stack[FJ_STACK_LDS * BLOCK];
   __shared__ double s_inst[kInstLds ? InstLds::WORDS : 1];
   if (kInstLds) InstLds::fill(S, s_inst);         // (the launcher picked this instantiation because the scene fits)

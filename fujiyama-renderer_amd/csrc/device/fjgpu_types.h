@@ -294,6 +294,7 @@ struct DScene {
   const uint32_t *cam_tk;      // ... in scenes whose random streams are keyed by the sample's uid (pathtracing shader, area lights): (tile id, index of
                                // the sample in its tile), two words per sample slot of the batch: 8 bytes instead of the 48-byte path record; else null
   const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
+  const uint32_t *trace_n_dev; // closest-hit launch enqueued BEFORE the host knows its ray count: the walk takes min(n, *trace_n_dev) rays (null: n)
                                // (hits are written to the ray's own slot); null = queue order
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
   const fj_xform_desc *xforms; // instances with DInstance.xform >= 0

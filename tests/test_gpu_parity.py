@@ -380,6 +380,32 @@ def test_cold_start_renders_the_same_frame_from_a_small_arena(asset_dir):
         gpu.global_option("cold_batch_samples", 0)
 
 
+@pytest.mark.parametrize("scene", ["teapot", "dragon"])
+def test_speculative_walk_changes_nothing(asset_dir, scene):
+    """global option "speculative_walk" (default on): the closest-hit walk of recursion level L + 1 is enqueued behind level L's shading launch and
+    reads its ray count from device memory, the counters come back on a side stream -- the same rays, the same launches that have rays, the same
+    pixels as the loop that waits for the host at every level (glass: two children per hit; plastic mirror: one)"""
+    if scene == "teapot":
+        sp, rd = prepare(workloads.teapot(asset_dir, res=(96, 96), spp=(2, 2)))
+    else:
+        sp, rd = prepare(workloads.dragon(asset_dir, res=(160, 90), spp=(2, 2), mesh="small"))
+    out = {}
+    try:
+        for on in (0, 1):
+            gpu.global_option("speculative_walk", on)
+            gs = gpu.Scene(sp)
+            fb, st = gs.render_frame(rd)
+            fb2, st2 = gs.render_frame(rd)
+            assert st.rays.as_dict() == st2.rays.as_dict()
+            out[on] = (fb2, st2)
+            gs.close()
+    finally:
+        gpu.global_option("speculative_walk", 1)
+    assert out[0][1].rays.as_dict() == out[1][1].rays.as_dict()
+    assert out[0][1].rays.reflect > 0
+    assert float(rel_err(out[1][0], out[0][0]).max()) <= 1e-6
+
+
 from edge_scenes import EDGE_CASES, custom_scene as _custom_scene  # noqa: E402
 
 
