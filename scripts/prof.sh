@@ -4,6 +4,8 @@ name=$1; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# (whole-frame batches from the first call on: the profiles are of the steady-state launches, not of a cold start's 16 M-sample batches)
+export FJGPU_COLD_START=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name.stats -- python $root/bench.py --steps 2 --warmup 1 --cpu-tiles 0 "$@" > $out/$name.bench.json 2>$out/$name.err
 find $out/$name.stats -name "*kernel_stats.csv" -exec cp {} $out/${name}_kernel_stats.csv \;
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_SMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE" "WRITE_SIZE"; do
