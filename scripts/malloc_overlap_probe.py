@@ -17,7 +17,9 @@ if "--dirty" in sys.argv:
     # a previous tenant: a process that allocates and writes most of the memory and ends (what the driver hands out next it clears first)
     import subprocess
     subprocess.run([sys.executable, "-c", "import torch; xs=[torch.ones(1<<28, device='cuda') for _ in range(240)]; torch.cuda.synchronize()"], check=False)
-hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+import os
+_tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")       # (the runtime torch itself loaded)
+hip = ctypes.CDLL(_tl if os.path.exists(_tl) else "/opt/rocm/lib/libamdhip64.so")
 hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
 hip.hipFree.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
@@ -65,6 +67,22 @@ def stats(sel):
     return "n %5d  median %7.3f ms  p99 %7.3f ms  max %8.3f ms" % (len(v), v[len(v) // 2] * 1e3, v[int(len(v) * .99)] * 1e3, v[-1] * 1e3) if v else "none"
 
 
+# ... and is the memory, once cleared for this process and freed by it, handed out again without the wait?
+t = time.perf_counter()
+ps2 = []
+for _ in range(int(gb)):
+    p = ctypes.c_void_p()
+    if hip.hipMalloc(ctypes.byref(p), 1 << 30) != 0:
+        break
+    ps2.append(p)
+t_again = time.perf_counter() - t
+q = ctypes.c_void_p()
+t = time.perf_counter()
+for p in ps2:
+    hip.hipFree(p)
+rc1 = hip.hipMalloc(ctypes.byref(q), int(gb) << 30)
+t_one = time.perf_counter() - t
+print("the same %d GB again after this process freed them: %.3f s in 1 GB pieces; then freed and as ONE allocation: %.3f s (rc %d)" % (len(ps2), t_again, t_one, rc1))
 print("hipMalloc of %d x 1 GB on a second thread took %.3f s" % (state.get("n", 0), state["t1"] - state["t0"]))
 print("kernel + synchronize round trips  before:", stats([r for r in rt if r[0] < state["t0"]]))
 print("                                  during:", stats([r for r in rt if state["t0"] <= r[0] <= state["t1"]]))
