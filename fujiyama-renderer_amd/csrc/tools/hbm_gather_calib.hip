@@ -92,7 +92,7 @@ int main(int argc, char **argv)
 {
   const double gib = argc > 1 ? atof(argv[1]) : 4.0;          // array size
   const uint32_t reps = argc > 2 ? (uint32_t) atoi(argv[2]) : 64u;
-  int log2_bytes = 20;
+  int log2_bytes = 12;      // (arrays from 4 KiB: a footprint inside one CU's 32 KB L1 measures the L1's own request rate)
   while (log2_bytes < 37 && (double) (1ull << (log2_bytes + 1)) <= gib * 1073741824.0) log2_bytes++;
   const size_t bytes = (size_t) 1 << log2_bytes;
   const size_t n16 = bytes / 16;

@@ -32,8 +32,13 @@ def main():
     acc = {n: {} for n in names}
     for k, cs in enumerate(SETS):
         d = os.path.join(tmp, "p%d" % k)
-        subprocess.run([exe, "--kernel-trace", "--pmc"] + list(cs) + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+        try:
+            # (own process group and a short limit: a counter set the profiler cannot schedule has hung a pass for its whole timeout before)
+            subprocess.run([exe, "--kernel-trace", "--pmc"] + list(cs) + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=float(os.environ.get("KPMC_PASS_TIMEOUT", "240")), check=True)
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
+            print("  pass %s FAILED: %s" % (" ".join(cs), type(e).__name__), flush=True)
+            continue
         for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 for n in names:
