@@ -104,22 +104,42 @@ Rccl &rccl()
   return R;
 }
 
-// one communicator set per list of devices, created at first use and kept for the process (bring-up takes of the order of a second)
+// one communicator set per list of devices, created at first use and kept until the process exits (bring-up takes of the order of a second);
+// destroyed by an atexit hook -- live communicators at exit are a known source of RCCL shutdown hangs.  A failed bring-up is remembered WITH its
+// reason (the next frame falls back to peer copies at once and says why) and is retried after FJ_RCCL_RETRY_CALLS calls.
+#define FJ_RCCL_RETRY_CALLS 64
+struct RcclSet { std::vector<Rccl::comm_t> comms; std::string why; int calls_since_failure = 0; };
 std::mutex g_rccl_mu;
-std::map<std::vector<int>, std::vector<Rccl::comm_t>> g_rccl_comms;
+std::map<std::vector<int>, RcclSet> g_rccl_comms;
+
+void rccl_destroy_all()
+{
+  Rccl &R = rccl();
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  for (auto &kv : g_rccl_comms)
+    for (Rccl::comm_t c : kv.second.comms) if (c && R.CommDestroy) (void) R.CommDestroy(c);
+  g_rccl_comms.clear();
+}
 
 const std::vector<Rccl::comm_t> *rccl_comms(const std::vector<int> &devices, std::string *why)
 {
   Rccl &R = rccl();
   if (!R.ok) { *why = "librccl.so not loadable"; return nullptr; }
   std::lock_guard<std::mutex> lock(g_rccl_mu);
+  static bool hooked = false;
+  if (!hooked) { hooked = true; atexit(rccl_destroy_all); }
   auto it = g_rccl_comms.find(devices);
-  if (it != g_rccl_comms.end()) return it->second.empty() ? nullptr : &it->second;
-  std::vector<Rccl::comm_t> comms(devices.size(), nullptr);
-  const int e = R.CommInitAll(comms.data(), (int) devices.size(), devices.data());
-  if (e) { *why = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); comms.clear(); }
-  auto &slot = g_rccl_comms[devices] = comms;
-  return slot.empty() ? nullptr : &slot;
+  if (it != g_rccl_comms.end()) {
+    if (!it->second.comms.empty()) return &it->second.comms;
+    if (++it->second.calls_since_failure < FJ_RCCL_RETRY_CALLS) { *why = it->second.why + " (remembered)"; return nullptr; }
+    g_rccl_comms.erase(it);
+  }
+  RcclSet set;
+  set.comms.assign(devices.size(), nullptr);
+  const int e = R.CommInitAll(set.comms.data(), (int) devices.size(), devices.data());
+  if (e) { set.why = std::string("ncclCommInitAll: ") + (R.GetErrorString ? R.GetErrorString(e) : "error"); set.comms.clear(); *why = set.why; }
+  auto &slot = g_rccl_comms[devices] = set;
+  return slot.comms.empty() ? nullptr : &slot.comms;
 }
 
 }  // namespace
@@ -388,7 +408,10 @@ static long g_cold_start = 1;      // "cold_start": a scene's first render call 
 #define FJ_COLD_BATCH_SAMPLES ((size_t) 16 << 20)
 #endif
 static long g_cold_batch_samples = (long) FJ_COLD_BATCH_SAMPLES;      // "cold_batch_samples": ... of this many samples (0 = the default, 16 M)
-static long g_single_frame = 0;    // "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU
+// "single_frame_build": scenes created while it is on render ONE frame (SiRenderScene): where device_build is not set they build on the GPU.
+// PER THREAD (the caller switches it on around ITS fjgpu_scene_create call, which reads it on the same thread): a scene created at the same time on
+// another thread is not touched by the toggle.
+static thread_local long g_single_frame = 0;
 
 extern "C" {
 
@@ -1588,7 +1611,10 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
           if (hipEventRecord(sc->ev_shaded, st) != hipSuccess) return -1;
           DScene Sn = S;
           Sn.trace_n_dev = &sc->d_cnt->next_count;
-          const uint32_t next_chunk = kids <= 1 ? (uint32_t) std::min<size_t>(cap_rays, 0xffffffffu) : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
+          // (sized by what THIS launch can emit -- n rays, at most `kids` children each -- not by the queue's capacity: a deep level of a few
+          //  hundred rays no longer starts a full persistent grid whose waves read the count and leave)
+          const uint32_t chunk_cap = kids <= 1 ? (uint32_t) std::min<size_t>(cap_rays, 0xffffffffu) : std::max<uint32_t>(1u, (uint32_t) (cap_rays / kids));
+          const uint32_t next_chunk = (uint32_t) std::min<uint64_t>(chunk_cap, (uint64_t) n * kids);
           e = timed(st, &acc.closest_ms, [&]() {
             return launch_trace_closest(st, Sn, sc->levels[level + 1].rays, sc->levels[level + 1].paths, sc->d_hits, next_chunk, sc->d_cnt, (int) sc->count_events);
           });
@@ -1599,7 +1625,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         }
         else if (hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         if (hc.overflow) { sc->split_overflowed = S.shadow_join != nullptr; return fail(FJGPU_ENOMEM, "ray queue overflow: lower the batch_tiles option"); }
-        if (launched_next && hc.next_count) { acc.trace_launches++; acc.closest_launches++; }       // (a walk of no rays is not counted)
+        if (launched_next && hc.next_count) { acc.trace_launches++; acc.closest_launches++; }       // (a walk of no rays is not counted ...
+        else if (launched_next) spans.pop_back();                                                   //  ... and not timed: its span was the last one recorded)
         if (hc.light_count) {
           // shading has completed (the host just synchronised with it): no event needed.
           // The queue holds hc.shadow_count entries so far (exact when the shadow work runs on
@@ -1830,26 +1857,12 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
       if (hipMemcpy(sc->d_rects, rects.data(), rects.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
         return bad(FJGPU_ENODEV, "rect upload failed");
       if (launch_move_tiles(nullptr, false, fb, r->xres, sc->d_rects, (int) mine[d].size(), tile_px, sc->d_slab)) return bad(FJGPU_ENODEV, "pack launch failed");
-      // one peer copy per device: over xGMI when peer access is available, staged by the runtime otherwise
+      // one peer copy per device: over xGMI when peer access is available, staged by the runtime otherwise.  (The RCCL exchange is NOT posted here:
+      // a device whose frame failed would leave its partner waiting in the group for ever -- it runs below, after the join, once every device succeeded.)
       const size_t bytes = mine[d].size() * (size_t) tile_px * 4 * sizeof(float);
-      if (comms) {
-        Rccl &R = rccl();
-        int e = R.GroupStart();
-        if (!e) e = R.Send(sc->d_slab, bytes / sizeof(float), Rccl::kFloat, 0, (*comms)[d], nullptr);
-        const int e2 = R.GroupEnd();
-        if (e || e2 || hipStreamSynchronize(nullptr) != hipSuccess) return bad(FJGPU_ENODEV, std::string("RCCL send of a tile slab: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
-      }
+      if (comms) { if (hipStreamSynchronize(nullptr) != hipSuccess) return bad(FJGPU_ENODEV, "tile pack failed"); }
       else if (hipMemcpyPeer(first->d_slab + stage_off[d] * 4, first->device, sc->d_slab, sc->device, bytes) != hipSuccess)
         return bad(FJGPU_ENODEV, std::string("peer copy of a tile slab: ") + hipGetErrorString(hipGetLastError()));
-    }
-    else if (comms) {
-      // rank 0: every other device's slab, all receives in ONE group
-      Rccl &R = rccl();
-      int e = R.GroupStart();
-      for (int q = 1; q < G && !e; q++)
-        if (!mine[q].empty()) e = R.Recv(first->d_slab + stage_off[q] * 4, mine[q].size() * (size_t) tile_px * 4, Rccl::kFloat, q, (*comms)[0], nullptr);
-      const int e2 = R.GroupEnd();
-      if (e || e2 || hipStreamSynchronize(nullptr) != hipSuccess) return bad(FJGPU_ENODEV, std::string("RCCL receive of the tile slabs: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
     }
   };
   if (G == 1) work(0);
@@ -1860,6 +1873,25 @@ int fjgpu_render_frame_multi(fjgpu_scene *const *scenes, int n_scenes, const fj_
   }
   for (int d = 0; d < G; d++) if (rcs[d]) return fail(rcs[d], "device " + std::to_string(scenes[d]->device) + ": " + errs[d]);
 
+  if (comms) {
+    // The slab exchange in RCCL's spelling, collective over SUCCESS: it is entered only when every device rendered and packed its share (checked above),
+    // from this one thread, as ONE group -- every non-empty device's send to rank 0 on its own communicator and rank 0's receives, also when rank 0
+    // itself holds no tile -- so no rank can be left waiting for a partner that returned early.
+    Rccl &R = rccl();
+    int e = R.GroupStart();
+    for (int q = 1; q < G && !e; q++) {
+      if (mine[q].empty()) continue;
+      const size_t count = mine[q].size() * (size_t) tile_px * 4;
+      e = R.Send(scenes[q]->d_slab, count, Rccl::kFloat, 0, (*comms)[q], nullptr);
+      if (!e) e = R.Recv(first->d_slab + stage_off[q] * 4, count, Rccl::kFloat, q, (*comms)[0], nullptr);
+    }
+    const int e2 = R.GroupEnd();
+    if (e || e2) return fail(FJGPU_ENODEV, std::string("RCCL exchange of the tile slabs: ") + (R.GetErrorString ? R.GetErrorString(e ? e : e2) : "error"));
+    for (int d = 0; d < G; d++) {
+      HIP_TRY(hipSetDevice(scenes[d]->device));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+  }
   HIP_TRY(hipSetDevice(first->device));
   if (G > 1) {
     std::vector<int32_t> rects;

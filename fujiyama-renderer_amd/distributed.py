@@ -225,7 +225,8 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None, rects=None
     point-to-point form is used for this and every later frame.
 
     lists / capacity: the deal (tile ids per rank, `deal_tiles` / `TileBalance.lists`; default: the interleave) and the
-    tiles a slab holds (default: the longest list) -- the same on every rank."""
+    tiles a slab holds (default: the longest list) -- the same on every rank.  `rects` and `lists` are immutable to the
+    caller: a new deal is a new object (the device-side tables are rebuilt when the object or its fingerprint changes)."""
     import os
     H, W, _ = fb.shape
     if world == 1:
@@ -244,16 +245,20 @@ def gather_frame(fb, n_tiles, tile_w, tile_h, rank, world, mode=None, rects=None
         key = (fb.data_ptr(), H, W, n_tiles, tile_w, tile_h, rank, world, per_rank)
         # (per frame this is two identity tests: the tables are compared by VALUE only when the caller hands over another
         # object -- hashing 2040 rectangles and every tile id cost ~1 ms of every timed frame on every rank)
-        if _state.get("rects_ref") is not rects:
+        # `rects` and `lists` are to be treated as IMMUTABLE by the caller (TileBalance builds new lists for every deal).  A caller that edits
+        # the same object in place is still caught by a fingerprint that costs O(world) per frame: lengths, and first / last entry of every list.
+        rfp = (len(rects), tuple(rects[0]) if len(rects) else None, tuple(rects[-1]) if len(rects) else None)
+        lfp = tuple((len(l), l[0] if l else -1, l[-1] if l else -1, l[len(l) // 2] if l else -1) for l in lists)
+        if _state.get("rects_ref") is not rects or _state.get("rects_fp") != rfp:
             rv = tuple(tuple(int(v) for v in r) for r in rects)
             if _state.get("rects_val") != rv:
                 _state["slabs_key"] = None
-            _state["rects_ref"], _state["rects_val"] = rects, rv
+            _state["rects_ref"], _state["rects_val"], _state["rects_fp"] = rects, rv, rfp
         deal_changed = False
-        if _state.get("lists_ref") is not lists:
+        if _state.get("lists_ref") is not lists or _state.get("lists_fp") != lfp:
             lv = tuple(tuple(l) for l in lists)
             deal_changed = _state.get("lists_val") != lv
-            _state["lists_ref"], _state["lists_val"] = lists, lv
+            _state["lists_ref"], _state["lists_val"], _state["lists_fp"] = lists, lv, lfp
         if _state.get("slabs_key") != key:
             _state["slabs"], _state["slabs_key"] = _DeviceSlabs(fb, rects, n_tiles, tile_w, tile_h, rank, world, lists, per_rank), key
             deal_changed = False

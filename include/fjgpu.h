@@ -157,8 +157,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * Morton order); 2: on the GPU as the radix tree of the Morton codes (fastest build, slowest tree); -1 (default): not
  * set -- the host build, or, for scenes created while "single_frame_build" is 1, the GPU's clustering build.
  * "multi_exchange" 0/1: how fjgpu_render_frame_multi moves the devices' tile slabs to the first device -- 0 (default): one hipMemcpyPeer per
- * device (over xGMI where peer access exists; nothing to bring up, which is what a one-frame process wants); 1: RCCL, every device's thread
- * sends its slab with ncclSend, the first device posts all ncclRecv in one ncclGroupStart / ncclGroupEnd (librccl.so is loaded at first use;
+ * device (over xGMI where peer access exists; nothing to bring up, which is what a one-frame process wants); 1: RCCL -- once EVERY device has
+ * rendered and packed its share, one ncclGroupStart / ncclGroupEnd holds each device's ncclSend and the first device's ncclRecv for it (the
+ * exchange is collective over success: a device that failed returns its error and no rank is left waiting; librccl.so is loaded at first use;
  * devices must be distinct; a communicator that cannot be created falls back to the peer copies).  Same bytes over the same links.
  * "cold_start" 1/0 (default 1): a scene's FIRST fjgpu_render_tiles call renders in batches of 16 M samples whatever the memory would hold (a work
  * arena of ~14 GB instead of ~110 GB at 1080p / 64 spp: the first image after 0.15 s instead of the seconds the large allocation can take);
@@ -166,8 +167,8 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * "speculative_walk" 1/0 (default 1): the closest-hit walk of the next recursion level is enqueued behind a level's shading launch, before the
  * host has read how many rays that launch emitted (the walk reads the count from device memory): no host round trip between the levels.
  * "cold_batch_samples" n: ... in batches of n samples instead (0 = back to 16 M).
- * "single_frame_build" 0/1: the caller renders ONE frame per scene it creates (SiRenderScene switches it on around its
- * scene creation): the 0.4 s of host build the tree's 3-6 % faster frames would need many frames to earn back are not spent.
+ * "single_frame_build" 0/1 (per calling THREAD): the caller renders ONE frame per scene it creates (SiRenderScene switches it on around its
+ * scene creation; scenes created on other threads meanwhile are unaffected): the 0.4 s of host build the tree's 3-6 % faster frames would need many frames to earn back are not spent.
  * "device_tlas" 1/0 (default 1): the instance level of every group (the reference's BVHAccelerator over
  * ObjectInstances, src/fj_bvh_accelerator.cc:253-334) is built on the GPU; 0: by the host's builder (the
  * same list).  "tlas_verify" 0/1: scene creation also builds it on the host and fails on any byte that differs.
