@@ -518,6 +518,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
       e |= M.upload(m.velocity, m.velocity ? (size_t) m.n_points * 3 : 0, &d.velocity);
       e |= M.upload(m.P, (size_t) m.n_points * 3, &d.P);
       e |= M.upload(m.N, m.N ? (size_t) m.n_points * 3 : 0, &d.N);
+      e |= M.upload(m.vertex_N, m.vertex_N ? (size_t) m.n_faces * 9 : 0, &d.vN);
       e |= M.upload(m.uv, m.uv ? (size_t) m.n_points * 2 : 0, &d.uv);
       e |= M.upload(m.indices, (size_t) m.n_faces * 3, &d.indices);
       e |= M.upload(m.face_group, m.face_group ? (size_t) m.n_faces : 0, &d.face_group);
@@ -611,7 +612,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         std::memcpy(I.pbounds, P.bounds, sizeof(I.pbounds));
         I.pnodes = P.nodes; I.proot = P.root; I.pn_prims = P.n_prims;
         I.pqnodes = P.qnodes ? P.qnodes : cq[I.primset];
-        I.sh_indices = P.indices; I.sh_N = P.N; I.sh_uv = P.uv; I.sh_face_group = P.face_group; I.sh_type = P.type; I.sh_pad = 0;
+        I.sh_indices = P.indices; I.sh_N = P.N; I.sh_vN = P.vN; I.sh_uv = P.uv; I.sh_face_group = P.face_group; I.sh_type = P.type; I.sh_pad = 0;
         for (int k = 0; k < 3; k++) { I.qorigin[k] = qgrid[I.primset][k]; I.qcell[k] = qgrid[I.primset][3 + k]; }
       }
       e |= M.upload(di.data(), di.size(), &S.instances);

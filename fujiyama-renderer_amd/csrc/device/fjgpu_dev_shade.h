@@ -453,7 +453,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, I->sh_indices) + 3 * (size_t) h.prim;
       i0 = ix[0]; i1 = ix[1]; i2 = ix[2];
       V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
-      if (I->sh_N) { n0 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i0); n1 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i1); n2 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i2); }
+      // compute_shading_normal, src/fj_mesh.cc:108-120: the mesh's per-corner ("vertex") normals where it has them, else its point normals
+      if (I->sh_vN) { const FJ_GLOBAL double *vn = FJ_G(double, I->sh_vN) + 9 * (size_t) h.prim; n0 = ld3(vn); n1 = ld3(vn + 3); n2 = ld3(vn + 6); }
+      else if (I->sh_N) { n0 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i0); n1 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i1); n2 = ld3(FJ_G(double, I->sh_N) + 3 * (size_t) i2); }
       N = (1 - h.u - h.v) * n0 + h.u * n1 + h.v * n2;            // TriComputeNormal, src/fj_triangle.cc:44-49
       has_uv = I->sh_uv != nullptr;
       if (has_uv) {

@@ -74,6 +74,7 @@ struct DPrimSet {
   const uint32_t *prim_ids;    // [n_prims]     original primitive id of leaf slot k
   const double *P;             // [n_points][3] object-space positions (attribute fetch)
   const double *N;             // [n_points][3] or null
+  const double *vN;            // [n_faces][3][3] per-corner normals (fj_mesh_desc.vertex_N) or null: they win over N
   const float *uv;             // [n_points][2] or null
   const int32_t *indices;      // [n_faces][3]
   const int32_t *face_group;   // [n_faces] or null
@@ -124,6 +125,7 @@ struct DInstance {
   const double *sh_N;
   const float *sh_uv;
   const int32_t *sh_face_group;
+  const double *sh_vN;         // per-corner normals of the mesh or null
   int32_t sh_type;             // FJ_PRIMSET_*
   int32_t sh_pad;
 };

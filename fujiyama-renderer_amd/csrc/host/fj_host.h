@@ -33,6 +33,7 @@ struct XformSamples {
 
 struct Mesh {
   std::vector<double> P, N, velocity;
+  std::vector<double> vertex_N;      // [n_faces][3][3] per-corner normals (OBJ files with `vn`), else empty
   std::vector<float> uv;
   std::vector<int32_t> indices, face_group;
   std::map<std::string, int> face_group_name;
@@ -159,6 +160,7 @@ Scene *get_scene();
 
 // procedures (fj_host_procedures.cc)
 int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err);
+int ReadObjFile(const std::string &path, Mesh *mesh, std::string *err);      // WavefrontObjProcedure (face groups, per-corner normals)
 int RunProcedure(Scene *sc, Procedure *proc, std::string *err);
 int RunVelocityGenerator(Scene *sc, Procedure *proc, std::string *err);
 

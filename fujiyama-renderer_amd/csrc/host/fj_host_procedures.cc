@@ -7,6 +7,8 @@
 // own (the reference vendors plyfile.c); it accepts ascii and both binary
 // byte orders with arbitrary extra properties.
 #include <algorithm>
+#include <cmath>
+#include <map>
 #include <string>
 #include <vector>
 #include <thread>
@@ -303,6 +305,7 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
   mesh->indices.swap(indices);
   mesh->uv.swap(uv);
   mesh->N.clear();
+  mesh->vertex_N.clear();
   mesh->velocity.clear();
   mesh->face_group.clear();
   mesh->ComputeNormals();
@@ -311,6 +314,129 @@ int ReadPlyFile(const std::string &path, Mesh *mesh, std::string *err)
   if (getenv("FJ_SCENE_TIMING"))
     fprintf(stderr, "fjhost: ply %s: read %.3f s, normals %.3f s, bounds %.3f s\n", path.c_str(), std::chrono::duration<double>(tA_ - t0_).count(),
         std::chrono::duration<double>(tB_ - tA_).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tB_).count());
+  return 0;
+}
+
+// ---------------------------------------------------------------- WavefrontObjProcedure
+// OBJ -> Mesh with the behaviour of the reference's procedures/wavefrontobj_procedure (ObjParser.cc:158-236 line grammar,
+// ObjBuffer.h:55-146 callbacks, ObjBuffer.cc:6-116 mesh assembly): the one producer of FACE GROUPS (`g name`) and of
+// per-CORNER normals (`vn` + `f v//vn`) among the reference's procedures.
+//   v x y z [w]        position (doubles, as written -- such a mesh need not be f32-exact)
+//   vn x y z           normal value;  vt is parsed and dropped (ObjBufferToMesh sets no texture coordinates)
+//   f a b c d ...      polygon, fan-triangulated (a, k+1, k+2); a corner is v | v/vt | v//vn | v/vt/vn; an index i > 0 names
+//                      element i - 1, i < 0 counts back from the elements read SO FAR, 0 stays 0 (ObjParser.cc:128-137)
+//   g name ...         faces from here on belong to group `name` (first word; ids in order of first appearance, "" = 0)
+// No `vn` anywhere: point normals = sum of the unit face normals of the faces at a point, in face order, normalised
+// (ObjBufferComputeNormals -- a corner repeated within a face counts twice there, unlike Mesh::ComputeNormals).  With `vn`:
+// Mesh.vertex_N[3 f + k] = the value the corner's vn index names; every face must carry vn indices then (the reference
+// reads past its index array otherwise).
+namespace {
+struct ObjScan {
+  const char *p, *end;
+  void blanks() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\f' || *p == '\v' || *p == '\r')) p++; }
+  bool at_eol() const { return p >= end || *p == '\n'; }
+  void next_line() { while (p < end && *p != '\n') p++; if (p < end) p++; }
+  std::string word() { blanks(); const char *b = p; while (p < end && !(*p == ' ' || *p == '\t' || *p == '\f' || *p == '\v' || *p == '\r' || *p == '\n')) p++; return std::string(b, p); }
+  bool number(double *out) { blanks(); if (at_eol()) return false; char *e = nullptr; const double v = std::strtod(p, &e); if (e == p) return false; p = e; *out = v; return true; }
+  bool integer(long *out) { if (at_eol()) return false; char *e = nullptr; const long v = std::strtol(p, &e, 10); if (e == p) return false; p = e; *out = v; return true; }
+};
+inline long obj_index(long count, long i) { return i > 0 ? i - 1 : (i < 0 ? i + count : 0); }
+}
+
+int ReadObjFile(const std::string &path, Mesh *mesh, std::string *err)
+{
+  std::vector<char> text;
+  {
+    FILE *fp = std::fopen(path.c_str(), "rb");
+    if (!fp) { *err = "cannot open OBJ file: " + path; return -1; }
+    std::fseek(fp, 0, SEEK_END);
+    const long n = std::ftell(fp);
+    std::fseek(fp, 0, SEEK_SET);
+    text.resize(n > 0 ? (size_t) n + 1 : 1);
+    const size_t got = n > 0 ? std::fread(text.data(), 1, (size_t) n, fp) : 0;
+    std::fclose(fp);
+    text[got] = '\n';
+    text.resize(got + 1);
+  }
+  std::vector<double> P, Nv;
+  std::vector<int32_t> tri, tri_n, group_of_face;
+  std::map<std::string, int> group_id;
+  group_id[""] = 0;
+  long n_v = 0, n_vt = 0, n_vn = 0;
+  int current_group = 0;
+  std::vector<long> cv, cn;            // the corners of one `f` line
+  ObjScan sc{text.data(), text.data() + text.size()};
+  for (; sc.p < sc.end; sc.next_line()) {
+    const std::string tag = sc.word();
+    if (tag == "v" || tag == "vn" || tag == "vt") {
+      double c[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4 && sc.number(&c[k]); k++) {}
+      if (tag == "v") { P.insert(P.end(), c, c + 3); n_v++; }
+      else if (tag == "vn") { Nv.insert(Nv.end(), c, c + 3); n_vn++; }
+      else n_vt++;
+    } else if (tag == "f") {
+      cv.clear(); cn.clear();
+      for (;;) {
+        sc.blanks();
+        long v = 0, vt = 0, vn = 0;
+        bool has_vn = false;
+        if (!sc.integer(&v)) break;
+        if (sc.p < sc.end && *sc.p == '/') {
+          sc.p++;
+          if (sc.p < sc.end && *sc.p == '/') { sc.p++; has_vn = sc.integer(&vn); }
+          else { (void) sc.integer(&vt); if (sc.p < sc.end && *sc.p == '/') { sc.p++; has_vn = sc.integer(&vn); } }
+        }
+        cv.push_back(obj_index(n_v, v));
+        if (has_vn) cn.push_back(obj_index(n_vn, vn));
+      }
+      (void) n_vt;
+      for (size_t k = 0; k + 2 < cv.size(); k++) {
+        tri.push_back((int32_t) cv[0]); tri.push_back((int32_t) cv[k + 1]); tri.push_back((int32_t) cv[k + 2]);
+        if (!cn.empty()) {
+          if (cn.size() != cv.size()) { *err = "OBJ face with normals on some corners only: " + path; return -1; }
+          tri_n.push_back((int32_t) cn[0]); tri_n.push_back((int32_t) cn[k + 1]); tri_n.push_back((int32_t) cn[k + 2]);
+        }
+        group_of_face.push_back(current_group);
+      }
+    } else if (tag == "g") {
+      const std::string name = sc.word();
+      if (name.empty()) { *err = "OBJ `g` without a name: " + path; return -1; }     // (the reference indexes an empty list there)
+      auto it = group_id.find(name);
+      if (it == group_id.end()) { const int id = (int) group_id.size(); group_id[name] = id; current_group = id; }
+      else current_group = it->second;
+    }
+  }
+  const size_t nf = tri.size() / 3;
+  if (P.empty() || nf == 0) { *err = "OBJ file without vertices or faces: " + path; return -1; }
+  for (int32_t i : tri) if (i < 0 || i >= n_v) { *err = "OBJ face index out of range: " + path; return -1; }
+  for (int32_t i : tri_n) if (i < 0 || i >= n_vn) { *err = "OBJ normal index out of range: " + path; return -1; }
+  if (!Nv.empty() && tri_n.size() != tri.size()) { *err = "OBJ file with `vn` values but faces without normal indices: " + path; return -1; }
+
+  *mesh = Mesh();                                     // Mesh::Clear, src/fj_mesh.cc:127-135
+  mesh->P.swap(P);
+  mesh->indices.swap(tri);
+  if (Nv.empty()) {
+    // ObjBufferComputeNormals, ObjBuffer.cc:80-116: TriComputeFaceNormal = Normalize(Cross(P1 - P0, P2 - P0)), added to the three
+    // corners' points in face order (a repeated corner adds twice), then Normalize (a zero vector stays)
+    std::vector<double> &N = mesh->N;
+    N.assign(mesh->P.size(), 0.);
+    auto normalize = [](double *v) { const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); if (len == 0) return; const double inv = 1. / len; v[0] *= inv; v[1] *= inv; v[2] *= inv; };
+    for (size_t f = 0; f < nf; f++) {
+      const int32_t *ix = &mesh->indices[3 * f];
+      const double *p0 = &mesh->P[3 * (size_t) ix[0]], *p1 = &mesh->P[3 * (size_t) ix[1]], *p2 = &mesh->P[3 * (size_t) ix[2]];
+      const double a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+      double ng[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      normalize(ng);
+      for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) N[3 * (size_t) ix[k] + c] += ng[c];
+    }
+    for (size_t i = 0; i < N.size(); i += 3) normalize(&N[i]);
+  } else {
+    mesh->vertex_N.resize(nf * 9);
+    for (size_t c = 0; c < nf * 3; c++) for (int k = 0; k < 3; k++) mesh->vertex_N[3 * c + k] = Nv[3 * (size_t) tri_n[c] + k];
+  }
+  mesh->face_group.assign(group_of_face.begin(), group_of_face.end());
+  mesh->face_group_name = group_id;
+  mesh->ComputeBounds();
   return 0;
 }
 
@@ -326,6 +452,15 @@ int RunProcedure(Scene *sc, Procedure *proc, std::string *err)
     auto mode = proc->strings.find("io_mode");
     if (mode != proc->strings.end() && mode->second != "r") { *err = "StanfordPlyProcedure: only io_mode r is supported"; return -1; }
     return ReadPlyFile(fp->second, sc->meshes[proc->mesh].get(), err);
+  }
+  if (proc->plugin->name == "WavefrontObjProcedure") {
+    // wavefrontobj_procedure.cc:34-39,77-99: properties "mesh", "filepath", "io_mode" ("r" reads, anything else fails)
+    if (proc->mesh < 0) { *err = "WavefrontObjProcedure: no mesh assigned"; return -1; }
+    auto fp = proc->strings.find("filepath");
+    if (fp == proc->strings.end() || fp->second.empty()) { *err = "WavefrontObjProcedure: no filepath"; return -1; }
+    auto mode = proc->strings.find("io_mode");
+    if (mode != proc->strings.end() && mode->second != "r") { *err = "WavefrontObjProcedure: only io_mode r is supported"; return -1; }
+    return ReadObjFile(fp->second, sc->meshes[proc->mesh].get(), err);
   }
   if (proc->plugin->name == "CurveGeneratorProcedure") return RunCurveGenerator(sc, proc, err);
   if (proc->plugin->name == "VelocityGeneratorProcedure") return RunVelocityGenerator(sc, proc, err);

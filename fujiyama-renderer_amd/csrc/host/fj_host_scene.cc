@@ -422,6 +422,7 @@ static int flatten(Scene *sc, Renderer *ren)
     d.velocity = m->velocity.empty() ? nullptr : m->velocity.data();
     d.indices = m->indices.data();
     d.face_group = m->face_group.empty() ? nullptr : m->face_group.data();
+    d.vertex_N = m->vertex_N.empty() ? nullptr : m->vertex_N.data();
     std::memcpy(d.bounds, m->bounds, sizeof(d.bounds));
     sc->d_meshes.push_back(d);
   }
@@ -649,7 +650,7 @@ static const struct KnownPlugin { const char *name; PluginKind kind; int shader;
   {"GlassShader", PLUGIN_SHADER, FJ_SHADER_GLASS}, {"HairShader", PLUGIN_SHADER, FJ_SHADER_HAIR},
   {"PathtracingShader", PLUGIN_SHADER, FJ_SHADER_PATHTRACING},
   {"StanfordPlyProcedure", PLUGIN_PROCEDURE, 0}, {"CurveGeneratorProcedure", PLUGIN_PROCEDURE, 0},
-  {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0},
+  {"VelocityGeneratorProcedure", PLUGIN_PROCEDURE, 0}, {"WavefrontObjProcedure", PLUGIN_PROCEDURE, 0},
 };
 
 static std::string table_mismatch(const std::string &plugin_name, const Property *theirs);

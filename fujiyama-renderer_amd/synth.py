@@ -170,6 +170,63 @@ def write_mip(path, img, tilesize=64):
         np.ascontiguousarray(tiles).tofile(f)
 
 
+def write_obj_groups(path, verts, quads, tris):
+    """Wavefront OBJ with FACE GROUPS and no normals (the reader accumulates point normals): coordinates are f32 values printed
+    exactly, faces before the first `g` stay in the default group, then bands A B C D by height, and a second stretch of A."""
+    v = np.asarray(verts, dtype=np.float32)
+    faces = [list(q) for q in quads] + [list(t) for t in tris]
+    ymid = [float(np.mean([v[i][1] for i in f])) for f in faces]
+    lo, hi = min(ymid), max(ymid)
+    band = [min(5, int(6 * (y - lo) / (hi - lo + 1e-12))) for y in ymid]
+    names = {0: None, 1: "A", 2: "B", 3: "C", 4: "D", 5: "A"}
+    with open(path, "w") as f:
+        f.write("# synthetic: face groups (default, A, B, C, D, A again)\n")
+        for p in v:
+            f.write("v %.17g %.17g %.17g\n" % (float(p[0]), float(p[1]), float(p[2])))
+        for b in range(6):
+            if names[b]:
+                f.write("g %s extra_word_ignored\n" % names[b])
+            for face, fb in zip(faces, band):
+                if fb == b:
+                    f.write("f " + " ".join(str(i + 1) for i in face) + "\n")
+
+
+def write_obj_normals(path, verts, quads, tris, seed=SEED):
+    """Wavefront OBJ with `vn` and per-CORNER normal indices: smooth normals on most faces, the face's own normal on every third
+    face (a crease: one point, several normals), texture coordinates that the reader drops, corners written as v//vn, v/vt/vn and
+    with NEGATIVE (relative) indices, two groups.  Coordinates are arbitrary doubles (not f32 values)."""
+    rng = np.random.RandomState(seed + 7)
+    v = np.asarray(verts, dtype=np.float64) * (1.0 / 3.0) + [.01, .02, .03]
+    faces = [list(q) for q in quads] + [list(t) for t in tris]
+    n_smooth = v - v.mean(axis=0)
+    n_smooth /= np.linalg.norm(n_smooth, axis=1, keepdims=True)
+    normals = [tuple(n) for n in n_smooth]
+    with open(path, "w") as f:
+        f.write("# synthetic: per-corner normals\n")
+        for p in v:
+            f.write("v %.17g %.17g %.17g 1.0\n" % tuple(p))
+        for k in range(len(v)):
+            f.write("vt %.6f %.6f\n" % (rng.uniform(), rng.uniform()))
+        for n in normals:
+            f.write("vn %.17g %.17g %.17g\n" % n)
+        nv, nn = len(v), len(normals)
+        for k, face in enumerate(faces):
+            if k == len(faces) // 2:
+                f.write("g upper\n")
+            if k % 3 == 0:
+                a, b, c = v[face[0]], v[face[1]], v[face[2]]
+                ng = np.cross(b - a, c - a)
+                ng = ng / max(np.linalg.norm(ng), 1e-300) * (1.5 if k % 2 else 1.0)       # (unnormalised on purpose: the reference does not renormalise here)
+                f.write("vn %.17g %.17g %.17g\n" % tuple(ng))
+                nn += 1
+                corners = ["%d//%d" % (i + 1, -1) for i in face]                               # the normal just written, relative index
+            elif k % 3 == 1:
+                corners = ["%d/%d/%d" % (i + 1, i + 1, i + 1) for i in face]
+            else:
+                corners = ["%d//%d" % (i - nv, i + 1) for i in face]                           # negative position indices
+            f.write("f " + " ".join(corners) + "\n")
+
+
 MESH_CLASSES = {
     # name: (nu, nv) -> 2*nu*(nv-1) triangles
     "dragon": (1900, 1901),    # 7 220 000
@@ -198,6 +255,19 @@ def ensure_assets(root, meshes=("teapot",), textures=True):
             write_ply(tmp, v, faces_quads=q, faces_tris=t)
             os.replace(tmp, path)
         out[name] = path
+    # OBJ twins of the smallest mesh (WavefrontObjProcedure: face groups / per-corner normals)
+    for key, writer in (("tiny_groups_obj", write_obj_groups), ("tiny_normals_obj", write_obj_normals)):
+        if key in meshes:
+            continue
+        path = os.path.join(root, key.replace("_obj", ".obj"))
+        if "tiny" in meshes and not os.path.exists(path):
+            cls = MESH_CLASSES["tiny"]
+            v, q, t = bumpy_sphere(cls[0], cls[1], seed=SEED + len("tiny"))
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            writer(tmp, v, q, t)
+            os.replace(tmp, path)
+        if os.path.exists(path):
+            out[key] = path
     # (every file appears under its name complete or not at all: several ranks may ask for the same assets)
     path = os.path.join(root, "floor.ply")
     if not os.path.exists(path):

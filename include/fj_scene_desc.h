@@ -76,6 +76,8 @@ typedef struct fj_mesh_desc {
   const int32_t *indices;    /* [n_faces][3]                        */
   const int32_t *face_group; /* [n_faces] or NULL (-> group 0)      */
   double bounds[6];          /* Mesh::ComputeBounds: min xyz, max xyz */
+  const double  *vertex_N;   /* [n_faces][3][3] per-CORNER normals (Mesh::GetVertexNormal(3 f + k), src/fj_mesh.cc:100-106:
+                              * a mesh that HasVertexNormal() shades with them instead of N, :108-120) or NULL */
 } fj_mesh_desc;
 
 /* Curve, src/fj_curve.h (cubic Bezier ribbons: 4 control points per curve) */

@@ -68,8 +68,10 @@ bool MeshRayIntersect(const fj_mesh_desc &m, int prim_id, const Ray &ray, double
 
   // TriComputeNormal, src/fj_triangle.cc:44-49; missing normals read as zero
   // (bounds-checked getters return Type(), src/fj_mesh.cc:24-47)
+  // compute_shading_normal, src/fj_mesh.cc:108-120: per-corner ("vertex") normals win over point normals
   V3 n0, n1, n2;
-  if (m.N) { n0 = P3(m.N, ix[0]); n1 = P3(m.N, ix[1]); n2 = P3(m.N, ix[2]); }
+  if (m.vertex_N) { n0 = P3(m.vertex_N, 3 * prim_id); n1 = P3(m.vertex_N, 3 * prim_id + 1); n2 = P3(m.vertex_N, 3 * prim_id + 2); }
+  else if (m.N) { n0 = P3(m.N, ix[0]); n1 = P3(m.N, ix[1]); n2 = P3(m.N, ix[2]); }
   isect->N = (1 - u - v) * n0 + u * n1 + v * n2;
 
   if (m.uv) {

@@ -177,6 +177,79 @@ def test_workload_scene_structure(asset_dir):
     assert n_groups == 2 and d.target_group == 1
 
 
+class _MeshDesc(C.Structure):            # fj_mesh_desc, include/fj_scene_desc.h
+    _fields_ = [("n_points", C.c_int32), ("n_faces", C.c_int32), ("P", C.POINTER(C.c_double)), ("N", C.POINTER(C.c_double)),
+                ("uv", C.POINTER(C.c_float)), ("velocity", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_int32)),
+                ("face_group", C.POINTER(C.c_int32)), ("bounds", C.c_double * 6), ("vertex_N", C.POINTER(C.c_double))]
+
+
+class _SceneHead(C.Structure):           # the head of fj_scene_desc
+    _fields_ = [("n", C.c_int32 * 7), ("target_group", C.c_int32), ("meshes", C.POINTER(_MeshDesc))]
+
+
+def test_wavefront_obj_procedure_face_groups_and_corner_normals(asset_dir):
+    """WavefrontObjProcedure (reference procedures/wavefrontobj_procedure: ObjParser.cc:158-236, ObjBuffer.h:55-146, ObjBuffer.cc:6-116)
+    through the product's reader: fan triangulation, groups in order of first appearance with the default group 0 in front, point normals
+    accumulated when the file has no `vn`, per-corner normals (relative indices, creases) when it has; instance shader lists with an
+    unassigned slot.  (The pictures these meshes give are pinned against the compiled reference: edge cases obj_face_groups / obj_vertex_normals.)"""
+    import edge_scenes
+    host.run_scene_text(edge_scenes.custom_scene(asset_dir, **edge_scenes.EDGE_CASES["obj_face_groups"]), deferred=True)
+    sp, _ = host.get_desc()
+    d = C.cast(sp, C.POINTER(_SceneHead)).contents
+    m = d.meshes[2]                                   # floor, dome, the OBJ object
+    nf = m.n_faces
+    assert m.n_points == 98 and nf == 192             # 12 x 9 bumpy sphere: 84 quads -> 168 triangles, + 24 cap triangles
+    groups = np.ctypeslib.as_array(m.face_group, shape=(nf,))
+    assert sorted(set(groups.tolist())) == [0, 1, 2, 3, 4] and groups[0] == 0
+    # (faces are written band by band: default, A, B, C, D, then A again -- the id of a group is fixed at its first `g` line)
+    first = [int(np.argmax(groups == g)) for g in range(5)]
+    assert first == sorted(first) and groups[-1] == 1
+    assert bool(m.N) and not bool(m.vertex_N)
+    N = np.ctypeslib.as_array(m.N, shape=(m.n_points, 3))
+    assert np.allclose(np.linalg.norm(N, axis=1), 1.0)
+    P = np.ctypeslib.as_array(m.P, shape=(m.n_points, 3))
+    assert np.array_equal(P, P.astype(np.float32).astype(np.float64))          # f32 values written exactly: the lean any-hit walk takes this mesh
+
+    host.run_scene_text(edge_scenes.custom_scene(asset_dir, **edge_scenes.EDGE_CASES["obj_vertex_normals"]), deferred=True)
+    sp, _ = host.get_desc()
+    d = C.cast(sp, C.POINTER(_SceneHead)).contents
+    m = d.meshes[2]
+    assert m.n_faces == 192 and bool(m.vertex_N) and not bool(m.N)
+    vN = np.ctypeslib.as_array(m.vertex_N, shape=(m.n_faces, 3, 3)).copy()
+    ix = np.ctypeslib.as_array(m.indices, shape=(m.n_faces, 3)).copy()
+    P = np.ctypeslib.as_array(m.P, shape=(m.n_points, 3)).copy()
+    assert not np.array_equal(P, P.astype(np.float32).astype(np.float64))      # arbitrary doubles: the FP64 triangle records
+    # a crease: some point carries different normals on different faces
+    by_point = {}
+    for f in range(m.n_faces):
+        for k in range(3):
+            by_point.setdefault(int(ix[f, k]), set()).add(tuple(np.round(vN[f, k], 12)))
+    assert max(len(v) for v in by_point.values()) >= 2
+    # the flat faces carry their own (unnormalised) face normal on all three corners
+    flat = [f for f in range(m.n_faces) if np.array_equal(vN[f, 0], vN[f, 1]) and np.array_equal(vN[f, 1], vN[f, 2])]
+    assert len(flat) >= 40
+    f = flat[0]
+    ng = np.cross(P[ix[f, 1]] - P[ix[f, 0]], P[ix[f, 2]] - P[ix[f, 0]])
+    assert abs(np.dot(ng / np.linalg.norm(ng), vN[f, 0] / np.linalg.norm(vN[f, 0]))) > 0.999999
+    groups = np.ctypeslib.as_array(m.face_group, shape=(m.n_faces,))
+    assert sorted(set(groups.tolist())) == [0, 1]
+
+
+def test_wavefront_obj_procedure_errors(tmp_path, asset_dir):
+    """missing file, a file without faces, an index past the vertices: SiRunProcedure fails (wavefrontobj_procedure.cc:77-99 returns -1)"""
+    head = ("OpenPlugin wavefrontobj_procedure WavefrontObjProcedure.so\nNewMesh m\nNewProcedure p wavefrontobj_procedure\nAssignMesh p mesh m\n"
+            "SetStringProperty p filepath %s\nRunProcedure p\n")
+    bad = tmp_path / "bad.obj"
+    for text in (None, "v 0 0 0\nv 1 0 0\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1 2 3\n"):
+        if text is None:
+            path = tmp_path / "absent.obj"
+        else:
+            bad.write_text(text)
+            path = bad
+        with pytest.raises(RuntimeError):
+            host.run_scene_text(head % path, deferred=True)
+
+
 def test_save_framebuffer_text_format(tmp_path):
     out = tmp_path / "x.fb"
     text = ("NewCamera cam1 PerspectiveCamera\nNewFrameBuffer fb1 rgba\nNewRenderer ren1\nAssignCamera ren1 cam1\n"
