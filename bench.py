@@ -13,6 +13,10 @@ outside the timed region, like the reference's build_accelerators()
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --scale 1,2,4,8        # the scaling curve: one compact JSON line per N, then the speed-ups
+
+With N > 1 the line also carries "multi_gpu": one untimed frame taken apart (every rank's render time, the exchange's time)
+and a self-check -- the frame assembled from the N ranks against rank 0's own render of the whole frame.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: "roofline" -- for the kernel that takes the largest share of the frame BY
@@ -90,6 +94,10 @@ def parse_args():
     ap.add_argument("--launcher", action="store_true",
                     help="start the ranks through torch.distributed.run (nccl) even for --gpus 1: the RCCL bring-up on one GPU; "
                          "--gpus N > 1 without a launcher around the script always does")
+    ap.add_argument("--scale", default=None,
+                    help="the scaling curve in ONE command, e.g. --scale 1,2,4,8: this script once per N (as `--gpus N`, which starts its own N nccl "
+                         "ranks), one compact JSON line per N -- value, ms_per_step, rccl_ranks, the slowest rank's render ms, the exchange's ms, "
+                         "the N > 1 self-check -- and a last line with the speed-ups over the first N; an N beyond the visible GPUs is reported as skipped")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end leg (the product's bin/scene run as a process of its own on this workload: one cold frame, .fb written)")
     ap.add_argument("--no-pmc", action="store_true",
@@ -383,8 +391,86 @@ def launch_ranks(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def scale_points(text):
+    pts = []
+    for tok in str(text).replace(" ", "").split(","):
+        if tok:
+            n = int(tok)
+            if n < 1:
+                raise ValueError("--scale: counts are >= 1")
+            pts.append(n)
+    if not pts:
+        raise ValueError("--scale: empty list")
+    return pts
+
+
+def scale_line(n, line):
+    """the compact per-N record of a --scale run from the full bench line of `--gpus n`"""
+    mg = line.get("multi_gpu") or {}
+    return {"scale_point": n, "metric": line["metric"], "value": line["value"], "unit": line["unit"], "n_gpus": line["n_gpus"],
+            "rccl_ranks": line["rccl_ranks"], "backend": line["backend"], "steps": line["steps"], "warmup": line["warmup"],
+            "ms_per_step": line["ms_per_step"], "slowest_rank_render_ms": mg.get("slowest_rank_render_ms"),
+            "exchange_ms": mg.get("exchange_ms"), "render_ms_by_rank": mg.get("render_ms_by_rank"),
+            "self_check": mg.get("self_check"), "tiles_per_rank": ((line["config"].get("tile_balance") or {}).get("tiles_per_rank")),
+            "workload": line["config"]["workload"]}
+
+
+def scale_parent(args, run=None):
+    """--scale: one child per N (its own process tree: `--gpus N` starts N ranks over RCCL), rank 0's lines collected here.
+    `run(n) -> dict | None` is injectable (tests/test_bench_contract.py drives the plumbing without a GPU)."""
+    pts = scale_points(args.scale)
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+    def child(n):
+        argv, skip = [], False
+        for a in sys.argv[1:]:
+            if skip:
+                skip = False
+                continue
+            if a == "--scale":
+                skip = True
+                continue
+            if a.startswith("--scale=") or a in ("--gpus",):
+                skip = a == "--gpus"
+                continue
+            if a.startswith("--gpus="):
+                continue
+            argv.append(a)
+        for flag in ("--no-pmc", "--no-e2e"):
+            if flag not in argv:
+                argv.append(flag)
+        if "--cpu-tiles" not in argv:
+            argv += ["--cpu-tiles", "0"]
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + argv, stdout=subprocess.PIPE, text=True)
+        if p.returncode != 0:
+            return {"scale_point": n, "error": "bench.py --gpus %d exited with %d" % (n, p.returncode)}
+        for ln in reversed(p.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return scale_line(n, json.loads(ln))
+        return {"scale_point": n, "error": "no JSON line"}
+    run = run or child
+    lines = []
+    for n in pts:
+        if run is child and n > have:
+            rec = {"scale_point": n, "skipped": "%d GPU(s) visible on this node" % have}
+        else:
+            rec = run(n)
+        lines.append(rec)
+        print(json.dumps(rec), flush=True)
+    ok = [r for r in lines if "value" in r]
+    summary = {"scale_summary": True, "points": [r["scale_point"] for r in ok], "value": [r["value"] for r in ok],
+               "ms_per_step": [r["ms_per_step"] for r in ok],
+               "speedup_over_first": [ok[0]["ms_per_step"] / r["ms_per_step"] for r in ok] if ok else [],
+               "skipped": [r["scale_point"] for r in lines if "skipped" in r], "failed": [r["scale_point"] for r in lines if "error" in r],
+               "note": "strong scaling of one frame; efficiency is for the reader to compute (speed-up / N)"}
+    print(json.dumps(summary), flush=True)
+    return 1 if summary["failed"] else 0
+
+
 def main():
     args = parse_args()
+    if args.scale:
+        raise SystemExit(scale_parent(args))
     dry = os.environ.get("FJ_BENCH_DRY") == "1"
     if args.dry_ranks > 1 and not dry:
         dry_ranks_parent(args)
@@ -590,6 +676,31 @@ def main():
     sync()
     gs.set_option("count_nodes", 0)
 
+    # N > 1: one more UNTIMED frame taken apart -- every rank's render on its own clock, then the exchange (pack, gather over RCCL, scatter,
+    # the frame's copy to the host) between two barriers: the two numbers a scaling curve is read with (--scale prints them per N)
+    multi = None
+    if world > 1:
+        sync()
+        render_ms = 0.0
+        for turn in range(world if dry else 1):          # (--dry-ranks: the ranks share one GPU and render in turns)
+            if not dry or turn == rank:
+                t1 = time.perf_counter()
+                gs.render_tiles(render, my_tiles, fb.data_ptr(), stream)
+                torch.cuda.synchronize(device)
+                render_ms = (time.perf_counter() - t1) * 1e3
+            if dry:
+                dist.barrier()
+        by_rank = fjdist.share_times(render_ms, rank, world, device)
+        sync()
+        t1 = time.perf_counter()
+        frame = fjdist.gather_frame(fb, n_tiles, render.tile_w, render.tile_h, rank, world, rects=tile_rects, lists=balance.lists, capacity=capacity)
+        if rank == 0:
+            host_fb.copy_(frame, non_blocking=False)
+        sync()
+        multi = {"render_ms_by_rank": [float(v) for v in by_rank], "slowest_rank_render_ms": float(max(by_rank)),
+                 "exchange_ms": (time.perf_counter() - t1) * 1e3,
+                 "note": "one untimed frame after the timed ones: each rank's render_tiles on its own clock; exchange = pack + gather + scatter + D2H between barriers"}
+
     # ---------------- aggregate over ranks
     rays_local = float(sum(s.rays.total() for s in stats))
     trace_ms_local = float(sum(s.trace_ms for s in stats))
@@ -785,6 +896,20 @@ def main():
             rel = float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
             out["dry_ranks"] = {"ranks": world, "backend": dist.get_backend(), "max_rel_err_vs_single_render": rel, "ok": bool(rel <= 1e-5),
                                 "note": "all ranks on cuda:0, rendering in turns: a code-path check, its timings mean nothing"}
+        if multi is not None and dry:
+            out["multi_gpu"] = multi                     # (the self-check of a dry run is `dry_ranks` above)
+        elif multi is not None:
+            # self-check of the N-GPU frame: the assembled frame (host_fb, the exchange above) against THIS rank's own render of the whole frame.
+            # The other ranks are not held up: every collective of the run lies behind (the closing barrier waits for rank 0 either way).
+            whole = torch.zeros_like(fb)
+            gs.render_tiles(render, list(range(n_tiles)), whole.data_ptr(), stream)
+            torch.cuda.synchronize(device)
+            a, b = host_fb.numpy(), whole.cpu().numpy()
+            rel = float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
+            multi["self_check"] = {"max_rel_err_vs_rank0_whole_render": rel, "ok": bool(rel <= 1e-5)}
+            out["multi_gpu"] = multi
+            if not multi["self_check"]["ok"]:
+                sys.stderr.write("bench.py: the frame assembled from %d ranks differs from rank 0's own render (max rel err %.3g)\n" % (world, rel))
         if world == 1 and args.rank_costs > 1:
             # per-rank cost of an N-GPU job, every rank's tile share timed on this one GPU
             # (tile t -> rank t % N): the slowest share bounds the N-GPU frame before the gather

@@ -71,6 +71,9 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     # the feedback deal ran (a re-deal after every second frame; the last frames are re-dealt ones) and kept every tile
     tb = d["config"]["tile_balance"]
     assert tb["frames"] == 8 and len(tb["slowest_rank_ms_by_deal"]) >= 1 and len(tb["tiles_per_rank"]) == 3
+    # the frame taken apart (what --scale prints per N): every rank's render time and the exchange between two barriers
+    mg = d["multi_gpu"]
+    assert len(mg["render_ms_by_rank"]) == 3 and mg["slowest_rank_render_ms"] == max(mg["render_ms_by_rank"]) > 0 and mg["exchange_ms"] > 0
 
 
 @pytest.mark.gpu
@@ -106,3 +109,64 @@ def test_bench_without_a_gpu_fails_loudly():
                            cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
         assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def _import_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fj_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_scale_sweep_plumbing_without_a_gpu(capsys):
+    """`bench.py --scale 1,2,4,8`: the list is parsed, every N gives ONE compact line with the fields a scaling curve
+    is read with, a failing point is reported and counted, and the last line carries the speed-ups -- with the per-N runner injected (no GPU)."""
+    bench = _import_bench()
+    assert bench.scale_points("1,2, 4,8") == [1, 2, 4, 8]
+    for bad in ("", "0,1", "a"):
+        with pytest.raises(ValueError):
+            bench.scale_points(bad)
+
+    def full_line(n):
+        return {"metric": "Mray/s primary+secondary (and ms/frame) at 1920x1080 64spp", "value": 24000.0 * n * 0.8, "unit": "Mray/s", "n_gpus": n,
+                "rccl_ranks": n, "backend": "nccl" if n > 1 else None, "steps": 3, "warmup": 1, "ms_per_step": 114.0 / (n * 0.8),
+                "config": {"workload": "dragon-class scene", "tile_balance": {"tiles_per_rank": [2040 // n] * n} if n > 1 else None},
+                "multi_gpu": {"render_ms_by_rank": [100.0 / n] * n, "slowest_rank_render_ms": 100.0 / n, "exchange_ms": 0.9,
+                              "self_check": {"max_rel_err_vs_rank0_whole_render": 0.0, "ok": True}} if n > 1 else None}
+
+    def run(n):
+        if n == 4:
+            return {"scale_point": 4, "error": "bench.py --gpus 4 exited with 1"}
+        return bench.scale_line(n, full_line(n))
+
+    class A:
+        scale = "1,2,4,8"
+    rc = bench.scale_parent(A(), run=run)
+    lines = [json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert rc == 1 and len(lines) == 5
+    assert [ln.get("scale_point") for ln in lines[:4]] == [1, 2, 4, 8]
+    one, two, four, eight, summ = lines
+    assert one["n_gpus"] == 1 and one["slowest_rank_render_ms"] is None and one["self_check"] is None
+    assert two["rccl_ranks"] == 2 and two["exchange_ms"] == 0.9 and two["self_check"]["ok"] and two["tiles_per_rank"] == [1020, 1020]
+    assert "error" in four and eight["value"] > two["value"]
+    assert summ["scale_summary"] and summ["points"] == [1, 2, 8] and summ["failed"] == [4] and summ["skipped"] == []
+    assert summ["speedup_over_first"][0] == 1.0 and abs(summ["speedup_over_first"][2] - 8 * 0.8 / 0.8) < 1e-9
+
+
+@pytest.mark.gpu
+def test_scale_sweep_on_this_box():
+    """--scale 1,2 on the GPUs this box has: N = 1 is measured (a bench line's worth), an N beyond the visible GPUs is reported as skipped, not
+    faked; on a node with two GPUs the second point runs over RCCL and must pass its self-check"""
+    import torch
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot", "--steps", "2", "--warmup", "1", "--scale", "1,2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 3
+    assert lines[0]["scale_point"] == 1 and lines[0]["value"] > 0 and lines[0]["n_gpus"] == 1
+    if torch.cuda.device_count() >= 2:
+        assert lines[1]["rccl_ranks"] == 2 and lines[1]["self_check"]["ok"] and lines[1]["exchange_ms"] > 0
+        assert lines[2]["points"] == [1, 2]
+    else:
+        assert "skipped" in lines[1] and lines[2]["points"] == [1] and lines[2]["skipped"] == [2]

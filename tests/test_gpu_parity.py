@@ -959,6 +959,38 @@ def test_rccl_spelling_of_the_slab_exchange(asset_dir):
         gs.close()
 
 
+def test_multi_device_frame_on_distinct_devices(asset_dir):
+    """fjgpu_render_frame_multi on DISTINCT devices, wherever the node has more than one (the driver's scaling node; skipped on a one-GPU box):
+    the assembled frame against device 0's own render, with the peer copies and with the RCCL exchange (one group after the join, collective
+    over success: ADVICE round 5), and a tile subset shorter than the device list (devices without a tile neither send nor are waited for)"""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("one GPU visible: the N-device exchange needs a node with several (replicas on one device: the test above)")
+    text = workloads.teapot(asset_dir, res=(100, 76), spp=(2, 2), mesh="tiny", extra=(("tilesize", (16, 16)),))
+    sp, rd = prepare(text)
+    gs = gpu.Scene(sp)
+    one, st1 = gs.render_frame(rd)
+    gs.close()
+    devs = list(range(min(nd, 8)))
+    for exchange in (0, 1):
+        gpu.global_option("multi_exchange", exchange)
+        try:
+            ms = gpu.MultiScene(sp, devs)
+            fb, sts = ms.render_frame(rd)
+            assert float(rel_err(fb, one).max()) <= 1e-6, exchange
+            assert sum(s.rays.total() for s in sts) == st1.rays.total()
+            # fewer tiles than devices (entry k of the list goes to device k % G): the last devices hold nothing
+            ids = [5, 1] if len(devs) > 2 else [5]
+            sub, _ = ms.render_frame(rd, ids)
+            for t in ids:
+                x0, y0, x1, y1 = gpu.tile_rect(rd, t)
+                assert float(rel_err(sub[y0:y1, x0:x1], one[y0:y1, x0:x1]).max()) <= 1e-6
+            ms.close()
+        finally:
+            gpu.global_option("multi_exchange", 0)
+
+
 def test_si_callbacks_and_interrupts(asset_dir):
     """SiSetFrameReportCallback / SiSetTileReportCallback (src/fj_callback.h:15-98) on the GPU path:
     one tile_start / tile_done per tile, TileInfo.framebuffer readable in tile_done, and the
