@@ -450,8 +450,9 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       Cd[2] = (1 - tl) * cd[2] + tl * cd[5];
     } else {
       // --- Mesh::ray_intersect attribute part (src/fj_mesh.cc:267-305) in object space
-      const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, I->sh_indices) + 3 * (size_t) h.prim;
-      i0 = ix[0]; i1 = ix[1]; i2 = ix[2];
+      // (the face's point indices: only where something is read through them -- a mesh whose normals sit per corner (sh_vN) and that has no
+      //  texture coordinates needs none of them here)
+      if (!I->sh_vN || I->sh_uv) { const FJ_GLOBAL int32_t *ix = FJ_G(int32_t, I->sh_indices) + 3 * (size_t) h.prim; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
       V3 n0 = mk(0, 0, 0), n1 = n0, n2 = n0;
       // compute_shading_normal, src/fj_mesh.cc:108-120: the mesh's per-corner ("vertex") normals where it has them, else its point normals
       if (I->sh_vN) { const FJ_GLOBAL double *vn = FJ_G(double, I->sh_vN) + 9 * (size_t) h.prim; n0 = ld3(vn); n1 = ld3(vn + 3); n2 = ld3(vn + 6); }
