@@ -694,6 +694,9 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
         a.node_base = (uint32_t) (((uintptr_t) P.qnodes - lo) / 128);
         a.tri_base = (uint32_t) ((tris_of(P) - lo) / 128);
         a.tris_f32 = P.tri_verts32 ? 1 : 0;
+        double bm = 0;
+        for (int k = 0; k < 6; k++) bm = std::max(bm, std::fabs(P.bounds[k]));
+        a.fbound = std::nextafter((float) bm, INFINITY);
       }
     }
     e |= M.upload(ai.data(), ai.size(), &S.any_insts);

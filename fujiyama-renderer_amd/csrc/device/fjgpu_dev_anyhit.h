@@ -31,6 +31,23 @@
 // touches of the node / triangle a lane will come back to (63.3 -> 68.3 .. 75.6 ms), the unsigned slab variant, ALU / load
 // padding and the f64 validation of the slab test (profiles/r03_anyhit_bound_experiments.txt, r03_anyhit_wide8_and_perm.txt).
 
+// Leaf phase (round 6).  FJ_ANYHIT_F32 1: a triangle is first put to the conservative packed-f32 filter of fjgpu_tri_filter.h
+// (same determinants, explicit error bounds): FJ_TRI_MISS / FJ_TRI_HIT settle the test as the reference's FP64 statements
+// would; FJ_TRI_MAYBE (a fraction of a percent: rays grazing an edge, a hit at t ~ tmin / tmax) parks the triangle in the
+// lane (`pex`) and the lane walks on as after a miss (any-hit order is free).  A fourth phase -- EXACT, run once
+// tune.exact_min lanes hold such a triangle, or as soon as one of them can do nothing else (its walk is over, or the filter
+// left a second triangle undecided) -- rebuilds the FP64 object-space ray from the queue entry with the entry code's own
+// statements and runs tri_ray_anyhit.  The FP64 ray therefore no longer lives in LDS: a lane keeps ten floats there (fl32(o), o - fl32(o),
+// fl32(d), tfl) instead of seven doubles.  FJ_ANYHIT_F32 0 is round 5's leaf phase (FP64 test on every candidate).
+#ifndef FJ_ANYHIT_F32
+#define FJ_ANYHIT_F32 1
+#endif
+#if FJ_ANYHIT_F32
+#define FJ_ANYHIT_RAY_WORDS 10          // 32-bit words of LDS per lane behind the stack
+#else
+#define FJ_ANYHIT_RAY_WORDS 14
+#endif
+
 // lane id the compiler cannot treat as a loop invariant
 __device__ __forceinline__ uint32_t opaque_lane_id()
 {
@@ -80,6 +97,9 @@ __device__ __forceinline__ bool tri_ray_anyhit(V3 v0, V3 v1, V3 v2, V3 orig, V3 
   return tmin <= t && t <= tmax;
 }
 
+#ifdef FJ_TRI_FILTER_VALIDATE
+__device__ unsigned long long g_trifilter[8];      // verdicts (miss, hit, maybe), contradictions, exact hits
+#endif
 #ifdef FJ_PHASE_STATS
 __device__ unsigned long long g_ahphase[16];
 // debug build only: wave-level phase executions and the lanes active in them
@@ -127,8 +147,16 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   uint32_t idx = 0;
   // object-space ray (f64: the triangle test's operands): it lives in LDS ([k][thread]) instead of in 12 registers -- only
   // the leaf phase reads it -- which is what lets the walk run a sixth wave per SIMD (80 VGPRs)
+#if FJ_ANYHIT_F32
+  typedef __attribute__((address_space(3))) float ah_lds_f32;
+  ah_lds_f32 *const s_ray = (ah_lds_f32 *) (ls_stack + FJ_STACK_LDS_ANYHIT * BLOCK);     // [10][thread]: oh xyz, ol xyz, d xyz, tfl (TriFilterRay)
+  uint32_t pex = TRAV_DONE;                // triangle (leaf slot) the filter left undecided, awaiting the exact phase; bit 31: a SECOND one came up (the lane's
+                                           // leaf cursor stays on it until the exact phase has run)
+#define AH_PEX_STALL 0x80000000u
+  int winst = 0;                           // kMulti: the instance being walked (the exact phase needs its M^-1 again)
+#else
   ah_lds_f64 *const s_ray = (ah_lds_f64 *) (ls_stack + FJ_STACK_LDS_ANYHIT * BLOCK);
-#define AH_RAY(k) s_ray[(k) * BLOCK + AH_TID()]
+#endif
   Slab32P s32;                             // conservative slab constants of (ray, instance), in the packed fma's layout
   s32.ix = s32.iy = s32.iz = 0.f; s32.lhx = s32.lhy = s32.lhz = (fj_v2f) (0.f);
   float tmax32 = 0.f;                      // >= the ray's tmax (the exact f64 value sits in LDS behind the ray, for the triangle test)
@@ -141,6 +169,9 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   // rays reach the light: the order of the tests is free, nothing is wasted but the inner steps an
   // occluded ray takes before its postponed leaf is tested)
   uint32_t pleaf = TRAV_DONE;
+#define AH_POSTPONE() do { if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && spa >= ah_row1) { pleaf = cur; cur = pop(spa); } } while (0)
+#define AH_PLEAF_NEXT() do { pleaf = TRAV_DONE; } while (0)
+#define AH_PLEAF_CLEAR() do { pleaf = TRAV_DONE; } while (0)
   uint32_t spa = ah_base;                  // (set to the lane's own column when a ray enters an instance)
   const double tmin = .0001;
 #ifdef FJ_PHASE_STATS
@@ -154,10 +185,17 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   for (;;) {
     PH(0, 1);
     FJ_TL_ITER(!head_live && next >= range_end);
-    if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && spa >= ah_row1) { pleaf = cur; cur = pop(spa); }
-    const bool fin = cur == TRAV_DONE && pleaf == TRAV_DONE;
+    AH_POSTPONE();
+    const bool walk_over = cur == TRAV_DONE && pleaf == TRAV_DONE;
+#if FJ_ANYHIT_F32
+    const bool has_pex = pex != TRAV_DONE;
+    const bool stalled = has_pex && (pex & AH_PEX_STALL);       // its leaf cursor waits for the exact phase
+#else
+    const bool has_pex = false, stalled = false;
+#endif
+    const bool fin = walk_over && !has_pex;
     const bool at_inner = cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG);
-    const bool at_leaf = pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG));     // a lane may be both
+    const bool at_leaf = (pleaf != TRAV_DONE || (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG))) && !stalled;     // a lane may be both
     const unsigned long long m_leaf = __ballot(at_leaf), m_inner = __ballot(at_inner);
     const unsigned n_leaf = (unsigned) __popcll(m_leaf), n_inner = (unsigned) __popcll(m_inner);
     // lanes for which a turnover does something: a ray to retire / move on, or a new one to fetch
@@ -165,6 +203,35 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
     const unsigned long long m_turn = __ballot(fin && (have || can_fetch));
     const unsigned n_turn = (unsigned) __popcll(m_turn);
 
+#if FJ_ANYHIT_F32
+    {
+      // ---- exact: the reference's FP64 statements for the triangles the filter left undecided
+      const unsigned long long m_ex = __ballot(has_pex);
+      if (m_ex != 0ull && ((unsigned) __popcll(m_ex) >= tune.exact_min || __ballot(has_pex && (walk_over || stalled)) != 0ull)) {
+        PH(12, 1); PH(13, __popcll(m_ex));
+        if (has_pex) {
+          V3 o, d;
+          double tmax;
+          sq_ray(S, squeue, idx, &o, &d, &tmax);
+          const DAnyInst *A = &S.any_insts[kMulti ? winst : ~SQ_FIELD(S, squeue, idx, group)];
+          // (the entry code's statements on the entry code's operands: the same object-space ray, bit for bit)
+          const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
+          FJ_SCHED_FENCE();
+          V3 v0, v1, v2;
+          load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), pex & ~AH_PEX_STALL, &v0, &v1, &v2);
+          if (tri_ray_anyhit(v0, v1, v2, oo_, od_, tmin, tmax)) {
+            have = false; cur = TRAV_DONE; AH_PLEAF_CLEAR();     // occluded: nothing to add
+#ifdef FJ_WAVE_TIMELINE
+            FJ_TL_RAY(ray_steps);
+#endif
+            PH(10, 1); PH(14, 1);
+          }
+          pex = TRAV_DONE;
+        }
+        continue;
+      }
+    }
+#endif
     if (n_turn >= TRAV_REFILL || (n_inner == 0 && n_leaf == 0)) {
       if (m_turn == 0ull) { FJ_TL_END(); break; }           // nothing in flight, nothing left to fetch
       PH(1, 1); PH(2, n_turn);
@@ -256,7 +323,26 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
           if (A->n_prims == 0) continue;
           const V3 oo_ = xpoint(A->Minv, o), od_ = xvector(A->Minv, d);
           if (has_negative_zero(od_)) continue;
+#if FJ_ANYHIT_F32
+          {
+            // the filter's ray (TriFilterRay, fjgpu_tri_filter.h): fl32(o), o - fl32(o), fl32(d), tfl; NaN where the error analysis does not hold
+            const float ohx = (float) oo_.x, ohy = (float) oo_.y, ohz = (float) oo_.z;
+            float dx32 = (float) od_.x, dy32 = (float) od_.y, dz32 = (float) od_.z;
+            const float om = fmaxf(fmaxf(fabsf(ohx), fabsf(ohy)), fabsf(ohz)) * 1.0000002f;
+            const float dm = fmaxf(fmaxf(fabsf(dx32), fabsf(dy32)), fabsf(dz32));
+            float tfl = om * 2.3841864e-7f;
+            // (magnitudes beyond the error analysis of the filter -- or a NaN anywhere: the comparison fails -- poison the ray: every verdict MAYBE.  The
+            //  ray's tmax needs no guard: tmax32 x D may overflow to +inf, which makes "t > tmax" unprovable and "t < tmax" true, as they are.)
+            if (!(dm <= 1073741824.f && om + A->fbound <= 536870912.f)) { dx32 = dy32 = dz32 = tfl = __builtin_nanf(""); }
+            ah_lds_f32 *const wp_ = &s_ray[AH_TID()];
+            wp_[0] = ohx; wp_[BLOCK] = ohy; wp_[2 * BLOCK] = ohz;
+            wp_[3 * BLOCK] = (float) (oo_.x - (double) ohx); wp_[4 * BLOCK] = (float) (oo_.y - (double) ohy); wp_[5 * BLOCK] = (float) (oo_.z - (double) ohz);
+            wp_[6 * BLOCK] = dx32; wp_[7 * BLOCK] = dy32; wp_[8 * BLOCK] = dz32; wp_[9 * BLOCK] = tfl;
+            if (kMulti) winst = inst;
+          }
+#else
           { ah_lds_f64 *const wp_ = &s_ray[AH_TID()]; wp_[0] = oo_.x; wp_[BLOCK] = oo_.y; wp_[2 * BLOCK] = oo_.z; wp_[3 * BLOCK] = od_.x; wp_[4 * BLOCK] = od_.y; wp_[5 * BLOCK] = od_.z; wp_[6 * BLOCK] = tmax; }
+#endif
           const V3 inv = mk(filter_rcp(od_.x), filter_rcp(od_.y), filter_rcp(od_.z));
           // the primitive set's own box: only where several instances are tried (a ray that misses
           // it finds no child box at the root either; in the single-instance walk the 12 registers
@@ -288,7 +374,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 #ifdef FJ_PHASE_STATS
       // where the lanes that take no part in this inner step are: idle (ray finished, waiting for the turnover) or held at a leaf
       { const bool in_ = step == 0 ? at_inner : (cur != TRAV_DONE && !(cur & FJ_LEAF_FLAG));
-        const bool fin_ = cur == TRAV_DONE && pleaf == TRAV_DONE;
+        const bool fin_ = cur == TRAV_DONE && pleaf == TRAV_DONE && !has_pex;
         PH(7, __popcll(__ballot(fin_))); PH(8, __popcll(__ballot(!in_ && !fin_))); }
 #endif
       // (rare) a lane close to the end of its LDS stack: this step pushes through the overflow path
@@ -333,7 +419,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             if (nh > 3) push(spa, r3);
           }
         }
-        if (cur != TRAV_DONE && (cur & FJ_LEAF_FLAG) && pleaf == TRAV_DONE && spa >= ah_row1) { pleaf = cur; cur = pop(spa); }
+        AH_POSTPONE();
       }
       }
     } else {
@@ -346,19 +432,54 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
         const uint32_t first = (lf & 0x7fffffffu) >> 3;
         const uint32_t more = lf & 7u;
         if (kCount) lc->prims++;
+#if FJ_ANYHIT_F32
+        TriFilterRay fr;
+        {
+          ah_lds_f32 *const rp_ = &s_ray[AH_TID()];
+          fr.ohx = rp_[0]; fr.ohy = rp_[BLOCK]; fr.ohz = rp_[2 * BLOCK]; fr.olx = rp_[3 * BLOCK]; fr.oly = rp_[4 * BLOCK]; fr.olz = rp_[5 * BLOCK];
+          fr.dx = rp_[6 * BLOCK]; fr.dy = rp_[7 * BLOCK]; fr.dz = rp_[8 * BLOCK]; fr.tfl = rp_[9 * BLOCK];
+          // tmin = .0001; tmax32 in [tmax, tmax (1 + 2^-23)]: factors 1 -+ 2^-18
+          fr.tmin_lo = 9.9999800e-05f; fr.tmin_hi = 1.0000020e-04f; fr.tmax_lo = tmax32 * 0.99999619f; fr.tmax_hi = tmax32 * 1.0000039f;
+        }
+        const int verdict = tri_filter32<true>((const FJ_GLOBAL float *) (S.blas_base + ((size_t) tri_base << 7)) + (size_t) first * 9, fr);
+#ifdef FJ_TRI_FILTER_VALIDATE
+        {
+          // debug build: the exact test behind every decision of the filter
+          V3 o, d, v0, v1, v2;
+          double tmax;
+          sq_ray(S, squeue, idx, &o, &d, &tmax);
+          const DAnyInst *A = &S.any_insts[kMulti ? winst : ~SQ_FIELD(S, squeue, idx, group)];
+          load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
+          const bool ex_ = tri_ray_anyhit(v0, v1, v2, xpoint(A->Minv, o), xvector(A->Minv, d), tmin, tmax);
+          atomicAdd(&g_trifilter[verdict], 1ull);
+          if ((verdict == FJ_TRI_MISS && ex_) || (verdict == FJ_TRI_HIT && !ex_)) atomicAdd(&g_trifilter[3], 1ull);
+          if (ex_) atomicAdd(&g_trifilter[4], 1ull);
+        }
+#endif
+        // undecided: the triangle waits in `pex` for the exact phase and the cursor moves on as for a miss; with `pex` taken the cursor
+        // stays (the exact phase runs at the next vote, the triangle is put to the filter again after it)
+        const bool stall_now = verdict == FJ_TRI_MAYBE && has_pex;
+        if (verdict == FJ_TRI_MAYBE) pex = has_pex ? (pex | AH_PEX_STALL) : first;
+        const bool occluded = verdict == FJ_TRI_HIT;
+        if (occluded) pex = TRAV_DONE;
+#else
         V3 v0, v1, v2;
         load_tri(nullptr, (const float *) (S.blas_base + ((size_t) tri_base << 7)), first, &v0, &v1, &v2);
         FJ_SCHED_FENCE();
-        ah_lds_f64 *const rp_ = &s_ray[AH_TID()];       // (one address for the six loads: AH_RAY rebuilds the lane id every time)
-        if (tri_ray_anyhit(v0, v1, v2, mk(rp_[0], rp_[BLOCK], rp_[2 * BLOCK]), mk(rp_[3 * BLOCK], rp_[4 * BLOCK], rp_[5 * BLOCK]), tmin, rp_[6 * BLOCK])) {
+        ah_lds_f64 *const rp_ = &s_ray[AH_TID()];       // (one address for the six loads)
+        const bool occluded = tri_ray_anyhit(v0, v1, v2, mk(rp_[0], rp_[BLOCK], rp_[2 * BLOCK]), mk(rp_[3 * BLOCK], rp_[4 * BLOCK], rp_[5 * BLOCK]), tmin, rp_[6 * BLOCK]);
+        const bool stall_now = false;
+#endif
+        if (occluded) {
           have = false; cur = TRAV_DONE;     // occluded: nothing to add
-          pleaf = TRAV_DONE;
+          AH_PLEAF_CLEAR();
 #ifdef FJ_WAVE_TIMELINE
           FJ_TL_RAY(ray_steps);
 #endif
           PH(10, 1);
         }
-        else if (from_p) pleaf = more ? (FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u)) : TRAV_DONE;
+        else if (stall_now) { }
+        else if (from_p) { if (more) pleaf = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u); else AH_PLEAF_NEXT(); }
         else if (more) cur = FJ_LEAF_FLAG | ((first + 1u) << 3) | (more - 1u);
         else cur = (spa < ah_row1) ? TRAV_DONE : pop(spa);
       }
@@ -366,12 +487,14 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
   }
 #undef AH_AT
 #undef AH_OVF
+#undef AH_POSTPONE
+#undef AH_PLEAF_NEXT
+#undef AH_PLEAF_CLEAR
 #undef AH_TID
-#undef AH_RAY
 #ifdef FJ_PHASE_STATS
   // 0-6 are wave-uniform tallies (lane 0 speaks for the wave); 10 was counted by single lanes
   for (int i = 0; i < 16; i++) {
-    const unsigned long long v = i == 10 ? wave_sum(ph[i]) : ph[i];
+    const unsigned long long v = (i == 10 || i == 14) ? wave_sum(ph[i]) : ph[i];
     if (lane == 0 && v) atomicAdd(&g_ahphase[i], v);      // (tallies of its own: g_phase also takes the closest-hit walks' ticks)
   }
 #endif
@@ -385,7 +508,11 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
 // 294.5 -> 281.9, C2 53.8 -> 52.0 (profiles/r03_exp13_six_waves.txt).  A seventh wave (72 VGPRs: 10 spills, 8 stack entries)
 // loses again: 67.4 ms.  The general instantiation needs 98 = 4 waves.
 #ifndef FJ_ANYHIT_MINB
+#if FJ_ANYHIT_F32
+#define FJ_ANYHIT_MINB 7                // (round 6: 88 bytes of LDS per lane and 72 VGPRs; what the compiler spills at 72 it spills inside the rare exact phase)
+#else
 #define FJ_ANYHIT_MINB 6
+#endif
 #endif
 #ifndef FJ_ANYHIT_MINB_MULTI
 #define FJ_ANYHIT_MINB_MULTI 5          // (96 VGPRs, no spill: C2 without the split 134.5 -> 124.1 ms; with the split 117.9)
@@ -395,7 +522,7 @@ template <bool kCount, bool kMulti>
 __global__ void __launch_bounds__(BLOCK, kMulti ? FJ_ANYHIT_MINB_MULTI : FJ_ANYHIT_MINB) k_shadow_anyhit(DScene S, const DShadowRay *squeue, float *s_accum,
     DCounters *cnt, TravTune tune)
 {
-  __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + 14 * BLOCK];     // (+ the rays: 6 doubles per thread, and tmax)
+  __shared__ alignas(16) uint32_t s_stack[FJ_STACK_LDS_ANYHIT * BLOCK + FJ_ANYHIT_RAY_WORDS * BLOCK];     // (+ the rays: TriFilterRay, or 6 doubles per thread and tmax)
   const uint32_t n = cnt->shadow_count < S.shadow_queue_cap ? cnt->shadow_count : S.shadow_queue_cap;
   LocalCounters lc = {0, 0, 0};
   traverse_anyhit<kCount, kMulti>(S, squeue, s_accum, tune, n, &cnt->shadow_xcd_head[0][0], s_stack, &lc);

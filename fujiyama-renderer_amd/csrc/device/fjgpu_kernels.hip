@@ -30,6 +30,7 @@
 #define BLOCK 256
 
 #include "fjgpu_dev_math.h"
+#include "fjgpu_tri_filter.h"
 #include "fjgpu_dev_curve.h"
 #include "fjgpu_dev_traverse.h"
 #include "fjgpu_dev_flat.h"
@@ -184,7 +185,7 @@ static int canyhit_blocks_per_cu()
 
 static TravTune trav_tune()
 {
-  static TravTune t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static TravTune t = {};
   if (t.grab == 0) {
     auto env = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t) atoi(v) : dflt; };
     t.refill = env("FJGPU_TRAV_REFILL", 40);       // (24 until the phase-scheduled any-hit walk; C3: closest 33.4 -> 30.5 ms, any-hit 83.7 -> 76.2)
@@ -202,6 +203,9 @@ static TravTune trav_tune()
     // (round 5: lanes held at a leaf, not idle lanes, are what an inner step of the any-hit walk runs without -- 35.4 of 64 at inner nodes, 15.8 held,
     // 12.8 idle on C3 --, so the leaf step runs a little before the held lanes are the majority; C3 walk at 10 / 8 / 6 / 5 / 4 / 3: 55.7 / 54.7 / 54.1 / 54.2 / 54.1 / 54.5 ms)
     t.leaf_bias8 = env("FJGPU_TRAV_LEAF_BIAS", 5);
+    // ... and the lanes frozen behind an undecided triangle (f32 filter) that make the wave run its exact phase
+    // (C3: 4 / 8 / 16 waiting lanes -> 53.7 / 53.9 / 53.9 ms at six waves, 51.3 / 51.3 at seven; a lane that can do nothing else runs it at once)
+    t.exact_min = env("FJGPU_TRAV_EXACT_MIN", 8);
     t.leaf_bias8_flat = env("FJGPU_TRAV_LEAF_BIAS_FLAT", 8);
     t.leaf_bias8_phased = env("FJGPU_TRAV_LEAF_BIAS_PHASED", 8);
     t.leaf_bias8_canyhit = env("FJGPU_TRAV_LEAF_BIAS_CANYHIT", 8);
@@ -441,6 +445,16 @@ int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const in
 
 void debug_phase_stats()
 {
+#ifdef FJ_TRI_FILTER_VALIDATE
+  {
+    unsigned long long c[8];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_trifilter), sizeof(c)) == hipSuccess && (c[0] | c[1] | c[2])) {
+      fprintf(stderr, "fjgpu tri filter: miss %llu hit %llu maybe %llu | exact hits %llu | CONTRADICTIONS %llu\n", c[0], c[1], c[2], c[4], c[3]);
+      unsigned long long z[8] = {0};
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_trifilter), z, sizeof(z));
+    }
+  }
+#endif
 #ifdef FJ_PHASE_STATS
   {
     unsigned long long c[8];
@@ -476,6 +490,7 @@ void debug_phase_stats()
       fprintf(stderr, "fjgpu phase anyhit-lanes: %llu iterations | inner steps %llu with %.1f lanes at inner nodes, %.1f idle, %.1f held at a leaf | leaf steps %llu with %.1f lanes, %.1f idle, "
           "%.1f at inner nodes | turnovers %llu with %.1f lanes | %llu rays occluded\n", a[0], a[3], (double) a[4] / a[3], (double) a[7] / a[3], (double) a[8] / a[3], a[5], (double) a[6] / a[5],
           (double) a[9] / a[5], (double) a[11] / a[5], a[1], (double) a[2] / (a[1] ? a[1] : 1), a[10]);
+      if (a[12]) fprintf(stderr, "fjgpu phase anyhit-exact: %llu exact phases with %.1f lanes, %llu of them hits\n", a[12], (double) a[13] / a[12], a[14]);
       unsigned long long z[16] = {0};
       (void) hipMemcpyToSymbol(HIP_SYMBOL(g_ahphase), z, sizeof(z));
     }

@@ -184,7 +184,8 @@ struct DAnyInst {
   uint32_t root;
   uint32_t tris_f32;           // 1: f32 records
   int32_t n_prims;
-  uint32_t pad[3];
+  float fbound;                // >= |any coordinate| of `bounds` (the f32 triangle filter's magnitude guard, fjgpu_tri_filter.h)
+  uint32_t pad[2];
 };
 static_assert(sizeof(DAnyInst) == 224, "DAnyInst layout");
 
