@@ -180,7 +180,9 @@ struct fjgpu_scene {
   bool overlap_now = false;        // ... what this render call does
   size_t free_cached = 0;          // free HBM + this scene's own work arena, as of the last query
   hipEvent_t ev_frame[2] = {nullptr, nullptr};   // frame start / end
-  long early_shadow = 0;           // with it: level 0's shadow rays are walked as soon as its light loop has run (FJGPU_EARLY_SHADOW)
+  long early_shadow = 0;           // FJGPU_EARLY_SHADOW = k > 0 (only where the light loops run on their own stream: small batches, a rank's share of a frame): the shadow
+                                   // queue is flushed after level k - 1's light loops, so that the one big any-hit walk runs BESIDE the deeper levels' closest-hit walks
+                                   // instead of after them.  Round 6, a rank's share: C3 0 / 1 / 2 / 3 -> 18.7 / 18.1-18.6 / 18.3 / 18.5 ms, but C2 14.0 -> 15.1 with 1: off.
   hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
   hipStream_t read_stream = nullptr;   // the counters of a shading launch come back on this one while the main stream already runs the next level's walk
   hipEvent_t ev_shaded = nullptr;
@@ -1670,7 +1672,9 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
           if (sst != st) { (void) hipEventRecord(sc->ev_shadow_done[lb], sst); shadow_pending[lb] = true; }
           // overlap: the shadow rays of level 0 -- most of a frame's -- are walked NOW, on the shadow stream, while the main stream runs the
           // deeper levels' closest-hit walks, which are a few long rays each (a launch of its own per level, latency bound): the big walk hides them
-          if (sst != st && level == 0 && can_emit && hc.next_count && sc->early_shadow) { e = flush_shadow(Sl); if (e) return e; }
+          // (early_shadow = k: the queue is flushed after level k - 1's light loops -- 2: levels 0 and 1, nearly all of a frame's shadow rays, are walked
+          //  beside the closest-hit walks of levels >= 2, which are a few long rays each)
+          if (sst != st && sc->early_shadow > 0 && level == (int) sc->early_shadow - 1 && can_emit && hc.next_count) { e = flush_shadow(Sl); if (e) return e; }
         }
         if (hc.next_count) {
           if (!can_emit) return fail(FJGPU_EINVAL, "ray recursion deeper than the depth limits allow");
