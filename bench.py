@@ -820,6 +820,27 @@ def main():
             frac = achieved / HBM_PEAK_GBPS
             frac_source = ("UNCALIBRATED estimate: algorithmic bytes of this run x %.2f (the traffic / algorithmic ratio of the last counter run, "
                            "profiles/r03_bench_dragon1080p.json); the counter passes did not run" % TRAFFIC_OVER_ALGORITHMIC_LAST_MEASURED)
+        # The yardstick for THIS access pattern: the walks gather 64-byte records, and a kernel that does nothing else reaches ~56 G requests/s
+        # (3.5 TB/s) at the scene's footprint on this part, not the 8 TB/s of a stream (profiles/r06_memory_system_notes.txt).  Measured live by the
+        # calibration tool on an array of the scene's size (rounded up to a power of two, >= 256 MiB), and set against the requests the dominant
+        # kernel's L2s sent to the fabric per second (TCC_EA0_RDREQ / launch time).  Reported BESIDE `frac`, which stays the contract's HBM fraction.
+        gather = None
+        if hbm and avg_ms:
+            try:
+                gib = 0.25
+                while gib * (1 << 30) < float(gs.query("scene_bytes")) and gib < 64:
+                    gib *= 2
+                exe = os.path.join(ROOT, "fujiyama-renderer_amd", "bin", "hbm_gather_calib")
+                cj = json.loads(subprocess.run([exe, str(gib), "64"], cwd="/tmp", stdout=subprocess.PIPE, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                ceil_req = cj["kernels"]["k_calib_gather64"]["GBps_needed"] / 64.0            # G requests / s
+                ach_req = hbm["read_requests_per_frame"]["all"] / launches_per_frame / (avg_ms * 1e-3) / 1e9
+                gather = {"achieved_Grequests_per_s": ach_req, "ceiling_Grequests_per_s": ceil_req, "frac_of_gather_ceiling": ach_req / ceil_req,
+                          "calibration_array_GiB": gib, "ceiling_GBps_64B": cj["kernels"]["k_calib_gather64"]["GBps_needed"],
+                          "stream_GBps_same_tool": cj["kernels"]["k_calib_stream"]["GBps_needed"],
+                          "note": "requests past the L2 per second of the dominant kernel against what a pure random 64-byte gather reaches on this GPU at the "
+                                  "scene's footprint (bin/hbm_gather_calib, run now); includes the kernel's coalesced queue reads, so it overstates the gathers"}
+            except Exception as e:  # noqa: BLE001
+                gather = {"error": str(e)}
         binding = None
         if issue and frac is not None:
             binding = "valu" if issue["valu_busy"] > frac else "hbm"
@@ -829,7 +850,7 @@ def main():
                 "share_of_frame": walk_ms / frame_ms_sum,
                 "picked_by": "largest measured HIP-event time among the traversal kernels",
                 "binding_resource": binding, "frac_source": frac_source, "uncalibrated": hbm is None,
-                "hbm_counters": hbm, "valu_issue": issue,
+                "hbm_counters": hbm, "valu_issue": issue, "gather_yardstick": gather,
                 "algorithmic": {"bytes_per_launch": walk_alg / walk_nl if walk_nl else None,
                                 "GBps": walk_alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
                                 "bytes_per_ray": walk_alg / max(1.0, K["rays"]),
