@@ -11,8 +11,10 @@
 // It runs before RenderScene and only writes Curve attributes.
 #include "fj_host.h"
 
+#include <algorithm>
 #include <cmath>
-#include <cstdlib>
+#include <cstdint>
+#include <thread>
 
 namespace fjhost {
 
@@ -91,8 +93,6 @@ double smooth_step(double a, double b, double x)        // src/fj_numeric.h:76-8
   return t * t * (3 - 2 * t);
 }
 
-inline double unit_rand() { return ((double) std::rand()) / RAND_MAX; }
-
 // PerlinNoise3d, src/fj_noise.cc:50-66: three decorrelated scalar fields
 V perlin_noise3d(V P, double lacunarity, double persistence, int octaves)
 {
@@ -160,12 +160,56 @@ void Curve::ComputeBounds()
   for (int a = 0; a < 3; a++) { bounds[a] = mn[a] - max_radius; bounds[3 + a] = mx[a] + max_radius; }
 }
 
-// generate_hair (procedures/curve_generator_procedure/curve_generator_procedure.cc:280-452):
-// strands of five chained cubics grown from the upper, front part of the mesh, bent by
-// Perlin noise and a downward pull, with per-vertex velocities (hair_velocity_blur.py).
-// Positions come from ONE default-seeded XorShift (deterministic), unlike the fur mode's rand().
+// ---------------------------------------------------------------- CurveGeneratorProcedure
+// What the reference's procedure DOES (procedures/curve_generator_procedure/curve_generator_procedure.cc): fur mode (:133-270) grows
+// int(100000 * area) one-cubic strands per face -- root at random barycentrics, direction = the interpolated normal pulled down by a random
+// "gravity", three inner control points jittered, width .003 -> .0001, colour between two fur tones by two octaves of Perlin noise --, every
+// random number being the FIRST values of libc's rand() after an srand() with a seed computed from (face, strand) or (strand, control point);
+// hair mode (:280-452) grows strands of five chained cubics from the upper front of the mesh, positions drawn from one default-seeded
+// XorShift, bent by Perlin noise and a downward pull, with per-control-point velocities.  The fur has to be the REFERENCE's fur (C5 parity),
+// so the arithmetic per strand is the reference's; the organisation is this library's own:
+//   * a strand table (first strand of every face by prefix sum), so every strand is an independent job on the host threads;
+//   * SeededRand: glibc's rand() stream after srand(seed) computed locally (TYPE_3 additive-feedback generator seeded by the Park-Miller
+//     LCG, 310 outputs discarded -- stdlib/random_r.c), thread-safe and the same on any libc: the reference's goldens were made with glibc;
+//   * results written straight into the Curve's flat arrays (P, width, Cd, velocity, indices).
 namespace {
-struct XorShiftHost {
+
+// glibc: srand(seed) then rand(), rand(), ... (TYPE_3: r[i] = r[i-3] + r[i-31], output r[i] >> 1)
+class SeededRand {
+ public:
+  explicit SeededRand(uint32_t seed)
+  {
+    int32_t word = seed ? (int32_t) seed : 1;
+    r_[0] = (uint32_t) word;
+    for (int i = 1; i < 31; i++) {
+      const long hi = word / 127773, lo = word % 127773;
+      long w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      word = (int32_t) w;
+      r_[i] = (uint32_t) word;
+    }
+    f_ = 3; b_ = 0;
+    for (int i = 0; i < 310; i++) (void) next();
+  }
+  uint32_t next()
+  {
+    r_[f_] += r_[b_];
+    const uint32_t out = r_[f_] >> 1;
+    f_ = f_ == 30 ? 0 : f_ + 1;
+    b_ = b_ == 30 ? 0 : b_ + 1;
+    return out;
+  }
+  double unit() { return (double) next() / 2147483647.0; }       // ((double) rand()) / RAND_MAX
+ private:
+  uint32_t r_[31];
+  int f_, b_;
+};
+
+// srand()'s argument is `unsigned`: the reference passes doubles and ints, converted the C way
+inline uint32_t seed_of(double x) { return (uint32_t) x; }
+inline uint32_t seed_of(long x) { return (uint32_t) x; }
+
+struct XorShiftHost {              // src/fj_random.cc:10-43, default seed
   uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
   double f01()
   {
@@ -175,92 +219,162 @@ struct XorShiftHost {
     return (double) s[3] / 4294967295u;
   }
 };
+
+struct Corner3 { V p[3], n[3]; };
+inline Corner3 face_corners(const Mesh &mesh, int face)
+{
+  Corner3 c;
+  const int32_t *ix = &mesh.indices[3 * (size_t) face];
+  const bool has_n = !mesh.N.empty();
+  for (int k = 0; k < 3; k++) { c.p[k] = at(mesh.P, ix[k]); c.n[k] = has_n ? at(mesh.N, ix[k]) : V{0, 0, 0}; }
+  return c;
+}
+inline double face_area(const Corner3 &c)                     // TriComputeArea
+{
+  const V x = cross(c.p[1] - c.p[0], c.p[2] - c.p[0]);
+  return .5 * std::sqrt(dot(x, x));
+}
+inline void put3(std::vector<double> &a, size_t i, V v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
+
+// strands per face -> first strand of every face; returns the total (or -1: too many)
+long strand_table(const std::vector<int> &per_face, std::vector<long> *first)
+{
+  first->assign(per_face.size() + 1, 0);
+  for (size_t f = 0; f < per_face.size(); f++) (*first)[f + 1] = (*first)[f] + per_face[f];
+  return first->back();
+}
+
+// jobs [0, n) on the host threads (strands are independent of each other)
+template <class F> void for_each_job(long n, F body)
+{
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const unsigned nt = (unsigned) std::max<long>(1, std::min<long>(hw, n / 2048 + 1));
+  if (nt == 1) { for (long i = 0; i < n; i++) body(i); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back([=]() { for (long i = n * t / nt; i < n * (t + 1) / nt; i++) body(i); });
+  for (auto &x : th) x.join();
+}
+
+// the face a strand belongs to (binary search in the table)
+inline int face_of(const std::vector<long> &first, long strand)
+{
+  return (int) (std::upper_bound(first.begin(), first.end(), strand) - first.begin()) - 1;
+}
+
 }  // namespace
 
+// hair mode: strands of `kLinks` chained cubics; the (u, v) of every root comes from ONE serial XorShift stream (drawn here in strand order,
+// two numbers per strand), everything after that is per strand
 static int GenerateHair(const Mesh &mesh, Curve &curve, std::string *err)
 {
-  const double ymin = mesh.bounds[1], ymax = mesh.bounds[4], zmin = mesh.bounds[2], zmax = mesh.bounds[5];
-  const int FACE_COUNT = mesh.face_count();
-  const int N_CURVES_PER_HAIR = 5;
-  std::vector<int> ncurves_on_face(FACE_COUNT);
-  long total = 0;
-  for (int i = 0; i < FACE_COUNT; i++) {
-    const int32_t *ix = &mesh.indices[3 * i];
-    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
-    const V c = cross(P1 - P0, P2 - P0);
-    const double area = .5 * std::sqrt(dot(c, c));           // TriComputeArea
-    const double ycenter = (P0.y + P1.y + P2.y) / 3.;
-    const double ynml = (ycenter - ymin) / (ymax - ymin);
-    const double zcenter = (P0.z + P1.z + P2.z) / 3.;
-    const double znml = (zcenter - zmin) / (zmax - zmin);
-    ncurves_on_face[i] = 100000 * area;
-    if (ynml < .5 || znml > .78) ncurves_on_face[i] = 0;
-    total += (long) ncurves_on_face[i] * N_CURVES_PER_HAIR;
+  const int kLinks = 5;
+  const double ylo = mesh.bounds[1], yhi = mesh.bounds[4], zlo = mesh.bounds[2], zhi = mesh.bounds[5];
+  const int n_faces = mesh.face_count();
+  std::vector<int> per_face(n_faces);
+  for (int f = 0; f < n_faces; f++) {
+    const Corner3 c = face_corners(mesh, f);
+    const double yn = ((c.p[0].y + c.p[1].y + c.p[2].y) / 3. - ylo) / (yhi - ylo);
+    const double zn = ((c.p[0].z + c.p[1].z + c.p[2].z) / 3. - zlo) / (zhi - zlo);
+    per_face[f] = 100000 * face_area(c);
+    if (yn < .5 || zn > .78) per_face[f] = 0;             // the upper, front part of the mesh only
   }
-  if (total > 50000000) { *err = "CurveGeneratorProcedure: more than 5e7 curves requested"; return -1; }
-  const int total_ncurves = (int) total;
-  const int total_ncps = 4 * total_ncurves;
-  curve.P.assign((size_t) total_ncps * 3, 0.);
-  curve.width.assign(total_ncps, 0.);
-  curve.Cd.assign((size_t) total_ncps * 3, 0.f);
-  curve.velocity.assign((size_t) total_ncps * 3, 0.);
-  curve.indices.assign(total_ncurves, 0);
+  std::vector<long> first;
+  const long n_strands = strand_table(per_face, &first);
+  if (n_strands * kLinks > 50000000) { *err = "CurveGeneratorProcedure: more than 5e7 curves requested"; return -1; }
+  const size_t n_cubics = (size_t) n_strands * kLinks, n_cp = 4 * n_cubics;
+  curve.P.assign(n_cp * 3, 0.);
+  curve.width.assign(n_cp, 0.);
+  curve.Cd.assign(n_cp * 3, 0.f);
+  curve.velocity.assign(n_cp * 3, 0.);
+  curve.indices.assign(n_cubics, 0);
   curve.uv.clear();
 
-  XorShiftHost rng;
-  const bool has_N = !mesh.N.empty();
-  int curve_id = 0, cp_id = 0;
-  for (int i = 0; i < FACE_COUNT; i++) {
-    const int32_t *ix = &mesh.indices[3 * i];
-    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
-    const V zero{0, 0, 0};
-    const V N0 = has_N ? at(mesh.N, ix[0]) : zero, N1 = has_N ? at(mesh.N, ix[1]) : zero, N2 = has_N ? at(mesh.N, ix[2]) : zero;
-    for (int j = 0; j < ncurves_on_face[i]; j++) {
-      const double u = rng.f01();
-      const double v = (1 - u) * rng.f01();
-      const double t = 1 - u - v;
-      const V src_P = t * P0 + u * P1 + v * P2;
-      V src_N = normalize(t * N0 + u * N1 + v * N2);
-      src_N.y = src_N.y < .1 ? src_N.y : .1;                 // Min(src_N.y, .1)
-      if (src_N.x < .1 && src_N.z < .1) {
-        src_N.x /= src_N.x;                                   // (sic) 1, or NaN for 0
-        src_N.z /= src_N.z;
-        src_N.x *= .5;
-        src_N.z *= .5;
-      }
-      src_N = normalize(src_N);
-      V next_P = src_P, next_N = src_N;
-      for (int k = 0; k < N_CURVES_PER_HAIR; k++) {
-        curve.indices[curve_id] = cp_id;
-        for (int vtx = 0; vtx < 4; vtx++) {
-          const double w[4] = {1, .5, .2, .05};
-          curve.P[3 * cp_id] = next_P.x; curve.P[3 * cp_id + 1] = next_P.y; curve.P[3 * cp_id + 2] = next_P.z;
-          curve.Cd[3 * cp_id] = .9f; curve.Cd[3 * cp_id + 1] = .8f; curve.Cd[3 * cp_id + 2] = .5f;
-          curve.width[cp_id] = (k == N_CURVES_PER_HAIR - 1) ? .0005 * w[vtx] : .0005;
-          const V curr_P = next_P;
-          if (vtx != 3) {
-            const double amp = .002 * .1, freq = 100, segment_len = .01;
-            const V Q = mulv(curr_P, V{freq, 2, freq});
-            const V noise_vec = perlin_noise3d(Q, 2, .5, 2);
-            next_P = next_P + (segment_len * next_N + mulv(V{amp, 0, amp}, noise_vec));
-            next_N = normalize(next_P - curr_P);
-            next_N.y += -.5;
-            next_N = normalize(next_N);
-          }
-          {
-            const double amp = .01, freq = 1;
-            const V Q = freq * curr_P + V{0, 5, 0};
-            const V noise_vec = perlin_noise3d(Q, 2, .5, 2);
-            const double vmult = smooth_step(1, N_CURVES_PER_HAIR, k);
-            const V curr_v = (vmult * amp) * noise_vec;
-            curve.velocity[3 * cp_id] = curr_v.x; curve.velocity[3 * cp_id + 1] = curr_v.y; curve.velocity[3 * cp_id + 2] = curr_v.z;
-          }
-          cp_id++;
+  std::vector<double> uv(2 * (size_t) n_strands);
+  { XorShiftHost rng; for (long s = 0; s < n_strands; s++) { const double u = rng.f01(); uv[2 * s] = u; uv[2 * s + 1] = (1 - u) * rng.f01(); } }
+
+  for_each_job(n_strands, [&](long s) {
+    const Corner3 c = face_corners(mesh, face_of(first, s));
+    const double u = uv[2 * s], v = uv[2 * s + 1], t = 1 - u - v;
+    V at_p = t * c.p[0] + u * c.p[1] + v * c.p[2];
+    V dir = normalize(t * c.n[0] + u * c.n[1] + v * c.n[2]);
+    dir.y = dir.y < .1 ? dir.y : .1;
+    if (dir.x < .1 && dir.z < .1) {            // (the reference divides a component by itself here: 1, or NaN for 0)
+      dir.x /= dir.x; dir.z /= dir.z;
+      dir.x *= .5; dir.z *= .5;
+    }
+    dir = normalize(dir);
+    size_t cp = 4 * (size_t) s * kLinks;
+    for (int link = 0; link < kLinks; link++) {
+      curve.indices[(size_t) s * kLinks + link] = (int32_t) cp;
+      for (int k = 0; k < 4; k++, cp++) {
+        static const double taper[4] = {1, .5, .2, .05};
+        put3(curve.P, cp, at_p);
+        curve.Cd[3 * cp] = .9f; curve.Cd[3 * cp + 1] = .8f; curve.Cd[3 * cp + 2] = .5f;
+        curve.width[cp] = (link == kLinks - 1) ? .0005 * taper[k] : .0005;
+        const V here = at_p;
+        if (k != 3) {
+          // the next control point: a step along the strand plus noise in x and z, then the direction is pulled down
+          const V wob = perlin_noise3d(mulv(here, V{100, 2, 100}), 2, .5, 2);
+          at_p = at_p + (.01 * dir + mulv(V{.002 * .1, 0, .002 * .1}, wob));
+          dir = normalize(at_p - here);
+          dir.y += -.5;
+          dir = normalize(dir);
         }
-        curve_id++;
+        const V drift = perlin_noise3d(1 * here + V{0, 5, 0}, 2, .5, 2);
+        put3(curve.velocity, cp, (smooth_step(1, kLinks, link) * .01) * drift);
       }
     }
-  }
+  });
+  curve.ComputeBounds();
+  return 0;
+}
+
+// fur mode
+static int GenerateFur(const Mesh &mesh, Curve &curve, std::string *err)
+{
+  const int n_faces = mesh.face_count();
+  std::vector<int> per_face(n_faces);
+  for (int f = 0; f < n_faces; f++) per_face[f] = 100000 * face_area(face_corners(mesh, f));
+  std::vector<long> first;
+  const long n_strands = strand_table(per_face, &first);
+  if (n_strands > 50000000) { *err = "CurveGeneratorProcedure: more than 5e7 curves requested"; return -1; }
+  const size_t n_cp = 4 * (size_t) n_strands;
+  curve.P.assign(n_cp * 3, 0.);
+  curve.width.assign(n_cp, 0.);
+  curve.Cd.assign(n_cp * 3, 0.f);
+  curve.indices.assign((size_t) n_strands, 0);
+  curve.uv.clear();
+  curve.velocity.clear();
+
+  for_each_job(n_strands, [&](long s) {
+    const int f = face_of(first, s);
+    const long j = s - first[f];                                   // the strand's number on its face
+    const Corner3 c = face_corners(mesh, f);
+    // root and direction: three seeds per (face, strand), one draw each
+    const double u = SeededRand(seed_of(12.34 * f + 1232 * j)).unit();
+    const double v = (1 - u) * SeededRand(seed_of(21.43 * f + 213 * j)).unit();
+    const double t = 1 - u - v;
+    const V root = t * c.p[0] + u * c.p[1] + v * c.p[2];
+    V lean = normalize(t * c.n[0] + u * c.n[1] + v * c.n[2]);
+    lean.y -= .5 + .5 * SeededRand(seed_of((long) f + j)).unit();  // "gravity"
+    lean = normalize(lean);
+    // colour: one value per strand (the reference evaluates it per control point from the same root)
+    double tone = 1 * perlin_noise(mulv(root, V{3, 3, 3}) + V{0, 1, 0}, 2, .5, 2);
+    tone = smooth_step(.55, .75, tone);
+    const float w = (float) tone;                                   // Lerp(Color, Color, float)
+    static const float dark[3] = {.8f, .5f, .3f}, light[3] = {.9f, .88f, .85f};
+    static const double width[4] = {.003, .002, .001, .0001};
+    const double len = .02;
+    for (int k = 0; k < 4; k++) {
+      const size_t cp = 4 * (size_t) s + k;
+      V jitter{0, 0, 0};
+      if (k > 0) { SeededRand r(seed_of(12 * s + 49 * (long) k)); jitter.x = r.unit(); jitter.y = r.unit(); jitter.z = r.unit(); }
+      put3(curve.P, cp, root + (.75 * len) * jitter + k * len / 3. * lean);
+      curve.width[cp] = width[k];
+      for (int a = 0; a < 3; a++) curve.Cd[3 * cp + a] = (1 - w) * dark[a] + w * light[a];
+    }
+    curve.indices[(size_t) s] = (int32_t) (4 * s);
+  });
   curve.ComputeBounds();
   return 0;
 }
@@ -268,90 +382,11 @@ static int GenerateHair(const Mesh &mesh, Curve &curve, std::string *err)
 int RunCurveGenerator(Scene *sc, Procedure *proc, std::string *err)
 {
   if (proc->mesh < 0 || proc->curve < 0) { *err = "CurveGeneratorProcedure: mesh and curve must be assigned"; return -1; }
-  auto hair = proc->numbers.find("is_hair");
-  if (hair != proc->numbers.end() && !hair->second.empty() && hair->second[0] > 0)
-    return GenerateHair(*sc->meshes[proc->mesh], *sc->curves[proc->curve], err);
   const Mesh &mesh = *sc->meshes[proc->mesh];
   Curve &curve = *sc->curves[proc->curve];
-  const int FACE_COUNT = mesh.face_count();
-
-  std::vector<int> ncurves_on_face(FACE_COUNT);
-  long total = 0;
-  for (int i = 0; i < FACE_COUNT; i++) {
-    const int32_t *ix = &mesh.indices[3 * i];
-    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
-    const V c = cross(P1 - P0, P2 - P0);
-    const double area = .5 * std::sqrt(dot(c, c));           // TriComputeArea
-    ncurves_on_face[i] = 100000 * area;
-    total += ncurves_on_face[i];
-  }
-  if (total > 50000000) { *err = "CurveGeneratorProcedure: more than 5e7 curves requested"; return -1; }
-  const int total_ncurves = (int) total;
-  const int total_ncps = 4 * total_ncurves;
-
-  std::vector<V> sourceP(total_ncurves), sourceN(total_ncurves);
-  int curve_id = 0;
-  const bool has_N = !mesh.N.empty();
-  for (int i = 0; i < FACE_COUNT; i++) {
-    const int32_t *ix = &mesh.indices[3 * i];
-    const V P0 = at(mesh.P, ix[0]), P1 = at(mesh.P, ix[1]), P2 = at(mesh.P, ix[2]);
-    const V zero{0, 0, 0};
-    const V N0 = has_N ? at(mesh.N, ix[0]) : zero, N1 = has_N ? at(mesh.N, ix[1]) : zero, N2 = has_N ? at(mesh.N, ix[2]) : zero;
-    for (int j = 0; j < ncurves_on_face[i]; j++) {
-      std::srand(12.34 * i + 1232 * j);
-      const double u = unit_rand();
-      std::srand(21.43 * i + 213 * j);
-      const double v = (1 - u) * unit_rand();
-      const double t = 1 - u - v;
-      const V src_P = t * P0 + u * P1 + v * P2;
-      V src_N = normalize(t * N0 + u * N1 + v * N2);
-      std::srand(i + j);
-      const double gravity = .5 + .5 * unit_rand();
-      src_N.y -= gravity;
-      src_N = normalize(src_N);
-      sourceP[curve_id] = src_P;
-      sourceN[curve_id] = src_N;
-      curve_id++;
-    }
-  }
-
-  curve.P.assign((size_t) total_ncps * 3, 0.);
-  curve.width.assign(total_ncps, 0.);
-  curve.Cd.assign((size_t) total_ncps * 3, 0.f);
-  curve.indices.assign(total_ncurves, 0);
-  curve.uv.clear();
-  curve.velocity.clear();
-  int cp_id = 0;
-  for (int i = 0; i < total_ncurves; i++) {
-    for (int vtx = 0; vtx < 4; vtx++) {
-      V noisevec{0, 0, 0};
-      std::srand(12 * i + 49 * vtx);
-      if (vtx > 0) {
-        noisevec.x = unit_rand();
-        noisevec.y = unit_rand();
-        noisevec.z = unit_rand();
-      }
-      const V src_P = sourceP[i], src_N = sourceN[i];
-      const double LENGTH = .02;
-      const double noiseamp = .75 * LENGTH;
-      const V dst_P = src_P + noiseamp * noisevec + vtx * LENGTH / 3. * src_N;
-      curve.P[3 * cp_id] = dst_P.x; curve.P[3 * cp_id + 1] = dst_P.y; curve.P[3 * cp_id + 2] = dst_P.z;
-      if (vtx == 0) {
-        curve.width[cp_id] = .003; curve.width[cp_id + 1] = .002; curve.width[cp_id + 2] = .001; curve.width[cp_id + 3] = .0001;
-      }
-      const double amp = 1;
-      const float dark[3] = {.8f, .5f, .3f}, light[3] = {.9f, .88f, .85f};
-      const V src_Q = mulv(src_P, V{3, 3, 3}) + V{0, 1, 0};
-      double C_noise = amp * perlin_noise(src_Q, 2, .5, 2);
-      C_noise = smooth_step(.55, .75, C_noise);
-      const float tt = (float) C_noise;                       // Lerp(Color, Color, float)
-      for (int k = 0; k < 3; k++) curve.Cd[3 * cp_id + k] = (1 - tt) * dark[k] + tt * light[k];
-      cp_id++;
-    }
-    curve.indices[i] = 4 * i;
-  }
-  curve.ComputeBounds();
-  return 0;
+  auto hair = proc->numbers.find("is_hair");
+  const bool is_hair = hair != proc->numbers.end() && !hair->second.empty() && hair->second[0] > 0;
+  return is_hair ? GenerateHair(mesh, curve, err) : GenerateFur(mesh, curve, err);
 }
 
 }  // namespace fjhost
