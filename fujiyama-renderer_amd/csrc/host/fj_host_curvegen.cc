@@ -172,8 +172,6 @@ void Curve::ComputeBounds()
 //   * SeededRand: glibc's rand() stream after srand(seed) computed locally (TYPE_3 additive-feedback generator seeded by the Park-Miller
 //     LCG, 310 outputs discarded -- stdlib/random_r.c), thread-safe and the same on any libc: the reference's goldens were made with glibc;
 //   * results written straight into the Curve's flat arrays (P, width, Cd, velocity, indices).
-namespace {
-
 // glibc: srand(seed) then rand(), rand(), ... (TYPE_3: r[i] = r[i-3] + r[i-31], output r[i] >> 1)
 class SeededRand {
  public:
@@ -204,6 +202,8 @@ class SeededRand {
   uint32_t r_[31];
   int f_, b_;
 };
+
+namespace {
 
 // srand()'s argument is `unsigned`: the reference passes doubles and ints, converted the C way
 inline uint32_t seed_of(double x) { return (uint32_t) x; }
@@ -378,6 +378,18 @@ static int GenerateFur(const Mesh &mesh, Curve &curve, std::string *err)
   curve.ComputeBounds();
   return 0;
 }
+
+}  // namespace fjhost
+
+// Diagnostics (include/fj_scene_interface.h): the first n values of the rand() stream the fur generator draws after srand(seed), so that a test
+// can hold them against the C library's own (tests/test_host_boundary.py)
+extern "C" void fj_dev_seeded_rand(uint32_t seed, int n, uint32_t *out)
+{
+  fjhost::SeededRand r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.next();
+}
+
+namespace fjhost {
 
 int RunCurveGenerator(Scene *sc, Procedure *proc, std::string *err)
 {

@@ -255,6 +255,11 @@ int fj_write_fb_file(const char *filename, int width, int height, int nchannels,
  * tools/hdr2mip (resampled to powers of two, tiles of 64; src/fj_mipmap.cc:246-300).  0 or -1. */
 int fj_hdr2mip(const char *hdr_path, const char *mip_path);
 
+/* Diagnostics: the first n values of the rand() stream CurveGeneratorProcedure draws after srand(seed) -- glibc's generator computed by the
+ * library itself (thread-safe, the same on any C library; the reference's fur depends on it: procedures/curve_generator_procedure/
+ * curve_generator_procedure.cc:171-186,209-215) */
+void fj_dev_seeded_rand(uint32_t seed, int n, uint32_t *out);
+
 /* Float framebuffer of a FrameBuffer ID: returns pointer (W*H*C floats) or NULL */
 const float *fj_framebuffer_data(long framebuffer, int *width, int *height, int *nchannels);
 

@@ -250,6 +250,24 @@ def test_wavefront_obj_procedure_errors(tmp_path, asset_dir):
             host.run_scene_text(head % path, deferred=True)
 
 
+def test_curve_generator_random_stream_is_glibc_rand():
+    """CurveGeneratorProcedure seeds libc's generator per (face, strand) and takes the first values after it (curve_generator_procedure.cc:171-186);
+    the library computes that stream itself (thread-safe, libc-independent): held here against the C library's own srand / rand on this host
+    (glibc -- the library the reference's golden frames were made with)"""
+    L = host.lib()
+    L.fj_dev_seeded_rand.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    L.fj_dev_seeded_rand.restype = None
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    rng = np.random.RandomState(5)
+    seeds = [0, 1, 2, 12, 49, 1232, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1] + [int(x) for x in rng.randint(0, 2 ** 32, size=200, dtype=np.uint64)]
+    out = (C.c_uint32 * 40)()
+    for sd in seeds:
+        L.fj_dev_seeded_rand(sd, 40, out)
+        libc.srand(C.c_uint(sd))
+        assert [libc.rand() for _ in range(40)] == list(out), sd
+
+
 def test_save_framebuffer_text_format(tmp_path):
     out = tmp_path / "x.fb"
     text = ("NewCamera cam1 PerspectiveCamera\nNewFrameBuffer fb1 rgba\nNewRenderer ren1\nAssignCamera ren1 cam1\n"
