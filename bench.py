@@ -53,9 +53,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI3
 # algorithmic bytes per traversal event (SURVEY.md 8d / DESIGN.md 7)
 # (node and triangle record sizes are those of the built layout: fjgpu_scene_query)
 # instance test = its 48-B box (the 96-B inverse matrix read on entry is not counted);
-# closest-hit ray = DRay 64 B in + DHit 32 B out; a shadow ray that survives the
+# closest-hit ray = DRay 48 B in (origin, direction: the range follows from the ray's class since round 6) + DHit 32 B out; a shadow ray that survives the
 # instance-box cull = its 80-B queue entry (culled ones are never materialised)
-S_INST, S_RAY_IN, S_HIT_OUT, S_SHADOW = 48, 64, 32, 80
+S_INST, S_RAY_IN, S_HIT_OUT, S_SHADOW = 48, 48, 32, 80
 
 
 def parse_args():

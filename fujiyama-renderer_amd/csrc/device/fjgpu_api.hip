@@ -167,7 +167,9 @@ struct fjgpu_scene {
   uint8_t *d_apstate = nullptr, *d_acells = nullptr;
   const void *a_owner = nullptr;
   size_t a_samples = 0, a_cell_bytes = 0;
-  struct Level { DRay *rays; DPath *paths; size_t cap; uint32_t *keys; };     // keys: sort keys of the level's rays (written by the shading kernel that emits them) or null
+  struct Level { DRay *rays; DPath *paths; size_t cap; uint32_t *keys; float *fc; };     // keys: sort keys of the level's rays (written by the shading kernel that emits them) or null;
+                                   // fc: filter colours of refraction children, 3 floats per slot (scenes with a glass / pathtracing shader) or null
+  bool has_filter_rays = false;    // some shader emits refraction children that carry a filter colour (DPath.flags bit 0)
   std::vector<Level> levels;       // ray queue per recursion level (allocated on first use)
   bool uses_sample_uid;            // some random stream or sample time of the scene is keyed by the sample's uid / index in its tile
   int max_children;                // most child rays one shading event can emit in this scene
@@ -850,6 +852,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   for (int i = 0; i < desc->n_shaders; i++) {
     const fj_shader_desc &sh = desc->shaders[i];
     if (sh.type == FJ_SHADER_PATHTRACING) sc->uses_sample_uid = true;
+    if (sh.type == FJ_SHADER_GLASS || sh.type == FJ_SHADER_PATHTRACING) sc->has_filter_rays = true;     // (refraction children may carry a filter colour)
     auto lum = [](const float *c) { return .298912 * c[0] + .586611 * c[1] + .114478 * c[2] > 0.; };
     int k = 0;
     if (sh.type == FJ_SHADER_PLASTIC) { k = sh.do_reflect ? 1 : 0; if (k) sc->bounce_reflect = true; }
@@ -866,6 +869,7 @@ static int upload_scene(const fj_scene_desc *desc, fjgpu::HostScene &hs, int dev
   if (const char *e = getenv("FJGPU_PHASED_CLOSEST")) S.incoherent_rays = atoi(e) != 0;
   S.ray_perm = nullptr;
   S.trace_n_dev = nullptr;
+  S.trace_ranges = nullptr;
   S.cam_uv = nullptr; S.cam_slot0 = 0; S.cam_tk = nullptr;
   S.shadow_join = nullptr;
   sc->split_shadow = S.multi_shadow_groups && S.all_opaque && !S.has_curves && !S.has_motion && S.blas_base && g_split_shadow;
@@ -1210,6 +1214,8 @@ int ensure_level(fjgpu_scene *sc, int level, size_t cap)
   DeviceBuffers &W = *sc->work;
   if (W.alloc(cap, &L.rays) || W.alloc(cap, &L.paths)) return -1;   // older, smaller buffers stay owned by `work`
   L.keys = nullptr;
+  L.fc = nullptr;
+  if (sc->has_filter_rays && level >= 1 && W.alloc(cap * 3, &L.fc)) return -1;
   if (sc->ray_sort_bits > 0 && level >= 1 && W.alloc(cap, &L.keys)) return -1;
   L.cap = cap;
   return 0;
@@ -1322,7 +1328,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
     if (on) bt = std::max<long>(1, (long) ((size_t) g_cold_batch_samples / full_tile_samples));
   }
   if (bt <= 0) {
-    const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
+    const size_t per_sample = 32 + (size_t) (deepest + 1) * (sizeof(DRay) + sizeof(DPath) + (sc->has_filter_rays ? 12 : 0)) + sizeof(DHit) + 2 * sizeof(DLightRec) + (adaptive ? 72 : 0) +
         ((sc->ray_sort_bits > 0 && deepest >= 1) ? 24 : 0);       // (the ray sort's keys, slots, permutation and scratch)
     // (a scene without lights queues no shadow rays: the fifth of the HBM that queue may take goes to the ray queues --
     // C4, nine recursion levels: 1010 -> 994 ms per frame.  Walking a whole level in one launch with per-level hit
@@ -1411,6 +1417,7 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
   shp.max_diffuse_depth = r->max_diffuse_depth; shp.max_reflect_depth = r->max_reflect_depth; shp.max_refract_depth = r->max_refract_depth;
   shp.count_all_shadow = (int) sc->count_all_shadow;
   shp.ray_capacity = (uint32_t) cap_rays; shp.light_capacity = (uint32_t) cap_rays;
+  shp.fc_in = nullptr; shp.fc_out = nullptr;
   shp.next_keys = nullptr; shp.sort_bits = std::max(1, std::min(9, sc->ray_sort_bits)); shp.pad_ = 0;
   ray_sort_grid(sc->scene_box, shp.sort_bits, shp.sort_lo, shp.sort_scale);
   ShadowParams swp;
@@ -1602,6 +1609,8 @@ static int render_tiles_once(fjgpu_scene *sc, const fj_render_desc *r, const int
         Sl.lrec_hair = sc->d_lhair[lb];
         ShadeParams shl = shp;
         shl.next_keys = (can_emit && sc->ray_sort_bits > 0) ? sc->levels[level + 1].keys : nullptr;
+        shl.fc_in = (!implicit && sc->levels[level].fc) ? sc->levels[level].fc + 3 * (size_t) off : nullptr;
+        shl.fc_out = can_emit ? sc->levels[level + 1].fc : nullptr;
         e = timed(st, &acc.shade_ms, [&]() {
           return launch_shade(st, Sl, shl, rays, paths, sc->d_hits, n, sc->d_accum,
               can_emit ? sc->levels[level + 1].rays : nullptr, can_emit ? sc->levels[level + 1].paths : nullptr, sc->d_lrecs[lb], sc->d_cnt);
@@ -1948,12 +1957,24 @@ int fjgpu_trace(fjgpu_scene *sc, int group, int n, const double *rays, double *o
   HIP_TRY(hipSetDevice(sc->device));
   DeviceBuffers W;
   DRay *d_rays; DHit *d_hits; DCounters *d_cnt;
-  if (W.alloc((size_t) n, &d_rays) || W.alloc((size_t) n, &d_hits) || W.alloc(1, &d_cnt))
+  double *d_ranges;
+  if (W.alloc((size_t) n, &d_rays) || W.alloc((size_t) n * 2, &d_ranges) || W.alloc((size_t) n, &d_hits) || W.alloc(1, &d_cnt))
     return fail(FJGPU_ENOMEM, "device allocation failed");
-  HIP_TRY(hipMemcpy(d_rays, rays, sizeof(DRay) * (size_t) n, hipMemcpyHostToDevice));
+  {
+    // the caller's rays are Ray records of 8 doubles (o, d, tmin, tmax: include/fjgpu.h); the device keeps origin / direction and the ranges apart
+    std::vector<DRay> hr((size_t) n);
+    std::vector<double> hg((size_t) n * 2);
+    for (int i = 0; i < n; i++) {
+      for (int k = 0; k < 3; k++) { hr[i].o[k] = rays[8 * (size_t) i + k]; hr[i].d[k] = rays[8 * (size_t) i + 3 + k]; }
+      hg[2 * (size_t) i] = rays[8 * (size_t) i + 6]; hg[2 * (size_t) i + 1] = rays[8 * (size_t) i + 7];
+    }
+    HIP_TRY(hipMemcpy(d_rays, hr.data(), sizeof(DRay) * (size_t) n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ranges, hg.data(), sizeof(double) * 2 * (size_t) n, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemset(d_cnt, 0, sizeof(DCounters)));
   DScene S = sc->S;
   S.target_group = group;
+  S.trace_ranges = d_ranges;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));

@@ -27,8 +27,7 @@ __device__ __forceinline__ DRay static_camera_ray(const DScene &S, double u, dou
   DRay r;
   r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
   r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
-  r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
-  return r;
+  return r;                    // (range: S.cam_znear .. S.cam_zfar, ray_range)
 }
 __device__ __forceinline__ DPath camera_path(const DScene &S, uint32_t slot, uint32_t k, uint32_t uid)
 {
@@ -37,7 +36,6 @@ __device__ __forceinline__ DPath camera_path(const DScene &S, uint32_t slot, uin
   p.T[0] = p.T[1] = p.T[2] = 1.f;
   p.cxt = CXT_CAMERA_RAY; p.ddepth = p.rdepth = p.tdepth = 0;
   p.group = S.target_group;
-  p.fc[0] = p.fc[1] = p.fc[2] = 1.f;
   p.flags = k << 1; p.rng = 0; p.uid = uid;
   return p;
 }
@@ -69,7 +67,6 @@ __device__ __forceinline__ void camera_ray(const DScene &S, double u, double v, 
     DRay r;
     r.o[0] = eye.x; r.o[1] = eye.y; r.o[2] = eye.z;
     r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
-    r.tmin = S.cam_znear; r.tmax = S.cam_zfar;
     *ray_out = r;
   }
   *path_out = camera_path(S, slot, k, sample_uid(tile_id, k));
@@ -345,18 +342,17 @@ __device__ __forceinline__ void emit_child(const ChildRay &c, uint32_t slot, int
   DRay r;
   r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
   r.d[0] = c.d.x; r.d[1] = c.d.y; r.d[2] = c.d.z;
-  r.tmin = c.tmin < .0005f ? .0001 : .001; r.tmax = 1000;
-  next_rays[slot] = r;
+  next_rays[slot] = r;           // (range: tmin by class below, tmax 1000)
   if (sp.next_keys) sp.next_keys[slot] = ray_sort_key(o, c.d, sp.sort_lo, sp.sort_scale, sp.sort_bits);
   DPath p;
   p.sample = sample;
   p.T[0] = c.T[0]; p.T[1] = c.T[1]; p.T[2] = c.T[2];
-  p.cxt = (uint8_t) cxt;
+  p.cxt = (uint8_t) (cxt | (c.tmin < .0005f ? FJ_CXT_TMIN_1E4 : 0u));
   p.ddepth = parent.ddepth + (cxt == CXT_DIFFUSE_RAY ? 1 : 0);
   p.rdepth = parent.rdepth + (cxt == CXT_REFLECT_RAY ? 1 : 0);
   p.tdepth = parent.tdepth + (cxt == CXT_REFRACT_RAY ? 1 : 0);
   p.group = c.group;
-  p.fc[0] = fc ? fc[0] : 1.f; p.fc[1] = fc ? fc[1] : 1.f; p.fc[2] = fc ? fc[2] : 1.f;
+  if (fc && (c.flags & 1u) && sp.fc_out) { float *fo = sp.fc_out + 3 * (size_t) slot; fo[0] = fc[0]; fo[1] = fc[1]; fo[2] = fc[2]; }
   p.flags = c.flags | tbits; p.rng = key; p.uid = uid;     // tbits: the sample's time index << 1
   next_paths[slot] = p;
 }
@@ -482,9 +478,10 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
 
     // pending pow(filter, t_hit) of a refraction child (glass_shader.cc:117-121)
     if (p.flags & 1u) {
-      p.T[0] = (float) (p.T[0] * pow((double) p.fc[0], h.t));
-      p.T[1] = (float) (p.T[1] * pow((double) p.fc[1], h.t));
-      p.T[2] = (float) (p.T[2] * pow((double) p.fc[2], h.t));
+      const float *pfc = sp.fc_in + 3 * (size_t) i;
+      p.T[0] = (float) (p.T[0] * pow((double) pfc[0], h.t));
+      p.T[1] = (float) (p.T[1] * pow((double) pfc[1], h.t));
+      p.T[2] = (float) (p.T[2] * pow((double) pfc[2], h.t));
     }
 
     float Cs[3] = {.5f, 1.f, 0.f};   // NO_SHADER_COLOR, src/fj_shading.cc:24
@@ -689,7 +686,7 @@ __global__ void __launch_bounds__(BLOCK, FJ_SHADE_MINB) k_shade(DScene S, ShadeP
       if (r1 != 0.f) atomicAdd(acc + 1, r1);
       if (r2 != 0.f) atomicAdd(acc + 2, r2);
     }
-    if (p.cxt == CXT_CAMERA_RAY) acc[3] = Os;   // one camera ray per sample
+    if ((p.cxt & 0x7fu) == CXT_CAMERA_RAY) acc[3] = Os;   // one camera ray per sample
   }
 
   // ---- compaction: ballot + prefix count, one atomic per block and queue

@@ -804,7 +804,14 @@ struct ClosestPolicy {
     const uint32_t i = slot(k);
     const DRay q = rays ? rays[i] : implicit_camera_ray(*S, i);     // (DScene.cam_uv: level 0 of a static camera)
     r->o = mk(q.o[0], q.o[1], q.o[2]); r->d = mk(q.d[0], q.d[1], q.d[2]);
-    r->tmin = q.tmin; r->tmax = q.tmax;
+    // the range is a function of the ray's class (DRay): camera rays (znear, zfar) -- Camera::GetRay, src/fj_camera.cc:105-106 --, SlTrace children
+    // tmax 1000 and the tmin their shader passes (.001 or .0001: DPath.cxt bit 7); fjgpu_trace hands ranges over per ray
+    if (S->trace_ranges) { r->tmin = S->trace_ranges[2 * (size_t) i]; r->tmax = S->trace_ranges[2 * (size_t) i + 1]; }
+    else {
+      const uint32_t cx = (rays && paths) ? paths[i].cxt : (uint32_t) CXT_CAMERA_RAY;
+      if ((cx & 0x7fu) == CXT_CAMERA_RAY) { r->tmin = S->cam_znear; r->tmax = S->cam_zfar; }
+      else { r->tmin = (cx & FJ_CXT_TMIN_1E4) ? .0001 : .001; r->tmax = 1000; }
+    }
     r->time = (S->has_motion && paths) ? sample_time(*S, paths[i].flags >> 1) : 0.;   // fjgpu_trace: time 0
     r->group = paths ? paths[i].group : default_group;
     r->anyhit = false;

@@ -36,6 +36,10 @@ struct ShadeParams {
   // ray-queue sort (fjgpu_raysort.hip): the key of a child ray is computed where the ray is emitted -- origin and direction
   // are in registers there -- instead of by a pass of its own over the queue (C4: 1.6 G rays x 48 B less read per frame)
   uint32_t *next_keys;         // key of the child in slot k of the next queue, or null (no sort in this scene / for this level)
+  // filter colour of refraction children (DPath.flags bit 0), 3 floats per queue slot: of the rays being shaded / of the children emitted; null in
+  // scenes without a glass or pathtracing shader (no ray ever sets the bit there)
+  const float *fc_in;
+  float *fc_out;
   double sort_lo[3], sort_scale[3];
   int32_t sort_bits, pad_;
 };

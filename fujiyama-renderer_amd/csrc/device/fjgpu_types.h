@@ -297,6 +297,7 @@ struct DScene {
   const uint32_t *cam_tk;      // ... in scenes whose random streams are keyed by the sample's uid (pathtracing shader, area lights): (tile id, index of
                                // the sample in its tile), two words per sample slot of the batch: 8 bytes instead of the 48-byte path record; else null
   const uint32_t *ray_perm;    // closest-hit launch over a SORTED ray queue: entry k of the launch is ray ray_perm[k]
+  const double *trace_ranges;  // fjgpu_trace: (tmin, tmax) per ray, given by the caller (render calls: null, the range follows from the ray's class)
   const uint32_t *trace_n_dev; // closest-hit launch enqueued BEFORE the host knows its ray count: the walk takes min(n, *trace_n_dev) rays (null: n)
                                // (hits are written to the ray's own slot); null = queue order
   // time-sampled transforms (motion blur): evaluated per ray at the sample's time
@@ -314,24 +315,26 @@ struct DScene {
 };
 
 // ---- wavefront records
-struct DRay {                  // 64 B, Ray of src/fj_ray.h:11-22
-  double o[3], d[3], tmin, tmax;
-};
+struct DRay {                  // 48 B: origin and direction of Ray (src/fj_ray.h:11-22).  Its RANGE is not stored (round 6): a queued ray's [tmin, tmax]
+  double o[3], d[3];           // follows from its class -- camera rays: (znear, zfar); every SlTrace child: tmax 1000 and tmin .001 or .0001 (DPath.cxt bit 7) --,
+};                             // and fjgpu_trace's caller-given ranges travel in DScene.trace_ranges
+static_assert(sizeof(DRay) == 48, "DRay must be 48 bytes");
+#define FJ_CXT_TMIN_1E4 0x80u   // DPath.cxt bit 7: the ray's tmin is .0001 (else .001); the low bits are the context
 
 enum { CXT_CAMERA_RAY = 0, CXT_SHADOW_RAY, CXT_DIFFUSE_RAY, CXT_REFLECT_RAY, CXT_REFRACT_RAY };
 
-struct DPath {                 // 48 B per-ray path state
+struct DPath {                 // 36 B per-ray path state
   uint32_t sample;             // destination sample slot in the batch
   float T[3];                  // RGB throughput down to this ray
-  uint8_t cxt, ddepth, rdepth, tdepth;   // ray context + diffuse / reflect / refract depths
+  uint8_t cxt, ddepth, rdepth, tdepth;   // ray context (+ FJ_CXT_TMIN_1E4) + diffuse / reflect / refract depths
   int32_t group;               // trace target group
-  float fc[3];                 // pending pow(filter, t_hit) colour (glass / pathtracing refraction)
-  uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit; bits 1..31: index of the sample in its tile
+  uint32_t flags;              // bit0: apply pow(fc, t_hit) at this ray's hit -- fc, the filter colour a refraction child carries (glass / pathtracing), sits in
+                               // a side array of its own (3 floats per slot, ShadeParams.fc_in / fc_out: only scenes with such shaders have it); bits 1..31: index of the sample in its tile
                                // (its time is time_tab[flags >> 1]; every ray of the sample's path tree carries it)
   uint32_t rng;                // pathtracing RNG contract: path key (child k of key p = 4 p + k)
   uint32_t uid;                // RNG contract: sample_uid(tile id, sample index in the tile) (fjgpu_dev_shade.h)
 };
-static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
+static_assert(sizeof(DPath) == 36, "DPath must be 36 bytes");
 
 struct DHit {                  // 32 B
   double t, u, v;
