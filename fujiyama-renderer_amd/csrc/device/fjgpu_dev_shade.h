@@ -43,7 +43,7 @@ __device__ __forceinline__ DPath camera_path(const DScene &S, uint32_t slot, uin
 // sample's uid anywhere in the scene, a camera ray is a function of its sample's (u, v) alone, and its path state is a
 // constant but for the sample slot.  k_gen_camera then writes only the (u, v) table the pixel filter needs anyway, and
 // the closest-hit walk and the shading kernel rebuild ray i of level 0 from cam_uv[i] -- ~50 instructions -- instead of
-// reading the 64 + 48 bytes per sample that k_gen_camera would have written (C3: 141 M samples, 15.8 GB less written
+// reading the ray and path records (64 + 48 bytes per sample then; 48 + 36 since round 6) that k_gen_camera would have written (C3: 141 M samples, 15.8 GB less written
 // and 25 GB less read per frame).  The same arithmetic in the same order as camera_ray: the same rays bit for bit.
 __device__ __forceinline__ DRay implicit_camera_ray(const DScene &S, uint32_t i)
 {
