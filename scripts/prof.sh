@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 # (whole-frame batches from the first call on: the profiles are of the steady-state launches, not of a cold start's 16 M-sample batches)
 export FJGPU_COLD_START=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name.stats -- python $root/bench.py --steps 2 --warmup 1 --cpu-tiles 0 "$@" > $out/$name.bench.json 2>$out/$name.err
-find $out/$name.stats -name "*kernel_stats.csv" -exec cp {} $out/${name}_kernel_stats.csv \;
+# (the bench starts the gather calibration tool as a child, which rocprofv3 traces too: the bench's own file is the one with the walks in it)
+for f in $(find $out/$name.stats -name "*kernel_stats.csv"); do grep -q 'k_trace_closest\|k_shadow' $f && cp $f $out/${name}_kernel_stats.csv; done
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_SMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$name.pmc_$tag -- python $root/bench.py --steps 1 --warmup 0 --cpu-tiles 0 "$@" > /dev/null 2>>$out/$name.err
