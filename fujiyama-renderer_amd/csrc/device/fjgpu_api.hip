@@ -435,6 +435,7 @@ int fjgpu_global_option(const char *name, long value)
   if (std::string(name) == "device_build") { g_device_build = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }
   if (std::string(name) == "single_frame_build") { g_single_frame = value != 0; return 0; }
   if (std::string(name) == "speculative_walk") { g_spec_walk = value != 0; return 0; }
+  if (std::string(name) == "anyhit_filter_off") { set_anyhit_filter_off(value); return 0; }
   if (std::string(name) == "cold_start") { g_cold_start = value != 0; return 0; }
   if (std::string(name) == "cold_batch_samples") { g_cold_batch_samples = value > 0 ? value : (long) FJ_COLD_BATCH_SAMPLES; return 0; }
   if (std::string(name) == "multi_exchange") { if (value < 0 || value > 1) return fail(FJGPU_EINVAL, "multi_exchange: 0 peer copies, 1 RCCL send / recv"); g_multi_exchange = value; return 0; }

@@ -333,7 +333,7 @@ __device__ void traverse_anyhit(const DScene &S, const DShadowRay *squeue, float
             float tfl = om * 2.3841864e-7f;
             // (magnitudes beyond the error analysis of the filter -- or a NaN anywhere: the comparison fails -- poison the ray: every verdict MAYBE.  The
             //  ray's tmax needs no guard: tmax32 x D may overflow to +inf, which makes "t > tmax" unprovable and "t < tmax" true, as they are.)
-            if (!(dm <= 1073741824.f && om + A->fbound <= 536870912.f)) { dx32 = dy32 = dz32 = tfl = __builtin_nanf(""); }
+            if (!(dm <= 1073741824.f && om + A->fbound <= 536870912.f) || tune.filter_off) { dx32 = dy32 = dz32 = tfl = __builtin_nanf(""); }
             ah_lds_f32 *const wp_ = &s_ray[AH_TID()];
             wp_[0] = ohx; wp_[BLOCK] = ohy; wp_[2 * BLOCK] = ohz;
             wp_[3 * BLOCK] = (float) (oo_.x - (double) ohx); wp_[4 * BLOCK] = (float) (oo_.y - (double) ohy); wp_[5 * BLOCK] = (float) (oo_.z - (double) ohz);

@@ -79,7 +79,7 @@ __device__ unsigned long long g_rayhist[64];
 #define FJ_TL_ITER(dry) do { } while (0)
 #define FJ_TL_END() do { } while (0)
 #endif
-struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased, refill_canyhit, steps_canyhit, min_inner_canyhit, leaf_wait_canyhit, refill_flat, steps_flat, min_inner_flat, leaf_bias8, leaf_bias8_flat, leaf_bias8_phased, leaf_bias8_canyhit, exact_min; };
+struct TravTune { uint32_t refill, steps, grab, leaf_wait, min_inner, anyhit_steps, refill_curves, steps_curves, steps_phased, min_inner_phased, refill_canyhit, steps_canyhit, min_inner_canyhit, leaf_wait_canyhit, refill_flat, steps_flat, min_inner_flat, leaf_bias8, leaf_bias8_flat, leaf_bias8_phased, leaf_bias8_canyhit, exact_min, filter_off; };
 #define TRAV_REFILL tune.refill   // refill when at least this many lanes are idle
 #define TRAV_STEPS (int) tune.steps   // inner-node steps between leaf / refill checks
 #define TRAV_GRAB tune.grab       // queue entries a wave claims per global atomic

@@ -75,6 +75,7 @@ int launch_quantize_nodes(hipStream_t st, const DNode *nodes, uint32_t n, const 
 // multi-GPU frame: pack a device's tiles (d_rects [n][4] = xmin ymin xmax ymax) into a slab of
 // tile_px pixels per tile, or scatter such a slab into the framebuffer (unpack)
 int launch_move_tiles(hipStream_t st, bool unpack, float *fb, int xres, const int32_t *d_rects, int n_tiles, int tile_px, float *slab);
+void set_anyhit_filter_off(long v);     // diagnostics: fjgpu_global_option("anyhit_filter_off")
 void debug_phase_stats();     // FJ_PHASE_STATS builds: print and reset the any-hit walk's phase tallies (stderr)
 // threads of the largest persistent grid (sizes per-thread scratch such as the stack overflow area)
 size_t persistent_threads();

@@ -183,6 +183,9 @@ static int canyhit_blocks_per_cu()
   return b < 1 ? 1 : (b > PERSIST_BLOCKS_PER_CU_MAX ? PERSIST_BLOCKS_PER_CU_MAX : b);
 }
 
+static long g_anyhit_filter_off = 0;     // diagnostics ("anyhit_filter_off"): every triangle test of the lean any-hit walk is left to its exact phase
+void set_anyhit_filter_off(long v) { g_anyhit_filter_off = v != 0; }
+
 static TravTune trav_tune()
 {
   static TravTune t = {};
@@ -228,6 +231,7 @@ static TravTune trav_tune()
     if (t.steps < 1) t.steps = 1;
     if (t.grab < 64) t.grab = 64;
   }
+  t.filter_off = (uint32_t) g_anyhit_filter_off;
   return t;
 }
 

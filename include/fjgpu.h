@@ -164,6 +164,9 @@ int fjgpu_set_option(fjgpu_scene *scene, const char *name, long value);
  * "cold_start" 1/0 (default 1): a scene's FIRST fjgpu_render_tiles call renders in batches of 16 M samples whatever the memory would hold (a work
  * arena of ~14 GB instead of ~110 GB at 1080p / 64 spp: the first image after 0.15 s instead of the seconds the large allocation can take);
  * the second call sizes its batches by memory and pays for the growth once.  0: the first call already does.
+ * "anyhit_filter_off" 0/1 (diagnostics, default 0): the lean any-hit walk's conservative f32 triangle filter decides nothing -- every leaf test goes
+ * through the walk's exact phase (the reference's FP64 statements on the ray rebuilt from the queue entry).  Same image, several times the
+ * walk's time: what tests use to put that phase under load.
  * "speculative_walk" 1/0 (default 1): the closest-hit walk of the next recursion level is enqueued behind a level's shading launch, before the
  * host has read how many rays that launch emitted (the walk reads the count from device memory): no host round trip between the levels.
  * "cold_batch_samples" n: ... in batches of n samples instead (0 = back to 16 M).

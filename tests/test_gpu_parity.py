@@ -902,6 +902,32 @@ def test_full_size_c3_on_other_shapes(shape, asset_dir):
         assert float(rel_err(out[y0:y1, x0:x1], ref[y0:y1, x0:x1]).max()) <= REL_TOL, (shape, t, pick)
 
 
+@pytest.mark.parametrize("builder,kw", [("dragon", dict(res=(160, 90), spp=(3, 3), mesh="teapot")),
+                                        ("buddhas", dict(res=(96, 54), spp=(2, 2), mesh="bunny")),
+                                        ("ibl", dict(res=(64, 48), spp=(2, 2), mesh="small", sample_count=48))])
+def test_anyhit_exact_phase_under_load(builder, kw, asset_dir):
+    """the lean any-hit walk's EXACT phase (the reference's FP64 triangle test on a ray rebuilt from the queue entry: what settles the 0.1 %
+    of leaf tests its f32 filter leaves undecided) with EVERY test sent through it (global option anyhit_filter_off): parked triangles, lanes
+    that find a second one while the first is pending, rays that end with one pending -- same ray counts, same pixels as the oracle, and
+    the frame of the filtered walk"""
+    sp, rd = prepare(workloads.BUILDERS[builder](asset_dir, **kw))
+    gs = gpu.Scene(sp)
+    assert gs.query("lean_anyhit") == 1
+    fb0, st0 = gs.render_frame(rd)
+    gpu.global_option("anyhit_filter_off", 1)
+    try:
+        fb1, st1 = gs.render_frame(rd)
+    finally:
+        gpu.global_option("anyhit_filter_off", 0)
+        gs.close()
+    osc = oracle_ffi.OracleScene(sp)
+    ref, rc = osc.render(rd)
+    osc.close()
+    assert st0.rays.as_dict() == rc.as_dict() and st1.rays.as_dict() == rc.as_dict()
+    assert float(rel_err(fb1, ref).max()) <= REL_TOL and float(rel_err(fb0, ref).max()) <= REL_TOL
+    assert float(rel_err(fb1, fb0).max()) <= 1e-5
+
+
 def test_multi_device_frame_equals_single_device_frame(asset_dir):
     """fjgpu_render_frame_multi (the worker pool with GPUs for workers, src/fj_renderer.cc:747-791):
     two replicas -- on one device here -- deal the tiles k % 2, pack, peer-copy and scatter their
