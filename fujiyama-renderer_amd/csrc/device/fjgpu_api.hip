@@ -184,7 +184,8 @@ struct fjgpu_scene {
   hipEvent_t ev_frame[2] = {nullptr, nullptr};   // frame start / end
   long early_shadow = 0;           // FJGPU_EARLY_SHADOW = k > 0 (only where the light loops run on their own stream: small batches, a rank's share of a frame): the shadow
                                    // queue is flushed after level k - 1's light loops, so that the one big any-hit walk runs BESIDE the deeper levels' closest-hit walks
-                                   // instead of after them.  Round 6, a rank's share: C3 0 / 1 / 2 / 3 -> 18.7 / 18.1-18.6 / 18.3 / 18.5 ms, but C2 14.0 -> 15.1 with 1: off.
+                                   // instead of after them.  Round 6, a rank's share: C3 0 / 1 / 2 / 3 -> 18.7 / 18.1-18.6 / 18.3 / 18.5 ms, C6 +0.3, arealights +0.3, C2
+                                   // 14.0 -> 15.1 with 1; switched on for single-instance shadow groups only, the SLOWEST of C3's eight shares went 17.95 -> 19.2 ms: off.
   hipStream_t shadow_stream;       // light loop + shadow traversal run here, overlapping the next level's closest-hit work
   hipStream_t read_stream = nullptr;   // the counters of a shading launch come back on this one while the main stream already runs the next level's walk
   hipEvent_t ev_shaded = nullptr;
